@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the raymarch + illumination hot path on MI355X.
+
+Metric (BASELINE.json): volume Msamples/s (rays x steps) at 512^3, 1024^2 view; % HBM roofline.
+Workload at N=1: BASELINE config 3 — 512^3 UNORM16 volume, UNORM8 light volume, 1024^2 RGBA f32
+framebuffer, 512 steps, lights L0-L3, TF-A, window C=0.5 W=0.9 (low cutoff on, high off), jitter off.
+
+One "step" = one frame in which a light moved: ChangeDirLightInSingleVolume on one of the four lights (the
+selective light-volume update; a 5 degree rotation about Z, fused path) followed by the lit raymarch of this
+rank's share of the framebuffer, and (N>1) the RCCL all-gather of the tiles. Inputs are resident in HBM before
+the timed region; the initial ResetAllLights (clear + 4 adds) is untimed setup and reported separately.
+
+N>1 (one process per GPU, torch.distributed/RCCL): weak scaling by image tiles — the framebuffer grows to
+~N x 1024^2 pixels at the same field of view, rank r renders every N-th group of 8 rows (load-balanced
+interleave), volumes are replicated, the selective light update is computed redundantly on every GPU (no
+data-path collective), and the only exchange is the final all_gather of the tiles.
+
+value = nominal samples of all ranks per step / step time, in Msamples/s (nominal sample = one loop iteration of
+PerformWindowedLitRaymarch that geometry prescribes, independent of early termination and skipping).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+
+
+def framebuffer_for(n_gpus, base):
+    """~n_gpus*base^2 pixels, near-square, height a multiple of 8*n_gpus (interleaved 8-row groups)."""
+    if n_gpus == 1:
+        return base, base
+    w = int(round(base * math.sqrt(n_gpus) / 16.0)) * 16
+    unit = 8 * n_gpus
+    h = int(round(n_gpus * base * base / w / unit)) * unit
+    return w, h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=3, help="SURVEY.md §8d config number (3 = the metric's config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--no-skipping", action="store_true")
+    ap.add_argument("--raymarch-only", action="store_true", help="diagnostic: leave the light update out of the step")
+    args = ap.parse_args()
+
+    import torch
+
+    from tbraymarcherplugin_amd import abi, synthetic as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    if world_size != n_gpus and not (n_gpus == 1 and world_size == 1):
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {n_gpus}")
+    dist = None
+    if n_gpus > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    abi.load()
+
+    cfg = S.CONFIGS[args.config]
+    n = cfg["n"]
+    dims = (n, n, n)
+    seed = S.seed_for_config(args.config)
+    fb_w, fb_h = framebuffer_for(n_gpus, cfg["fb"])
+    rows_per_rank = fb_h // n_gpus
+    steps = float(cfg["steps"])
+
+    # ---- setup (untimed): inputs resident in HBM ---------------------------------------------------------
+    vol_dev = S.make_volume_torch(dims, cfg["dtype"], seed, device)
+    res = abi.Resources(dims, abi.DTYPE_FMT[np.dtype(cfg["dtype"])], cfg["light_32bit"], False, local_rank)
+    res.upload_volume_device(vol_dev.data_ptr(), vol_dev.numel() * vol_dev.element_size())
+    lut = abi.color_curve_to_lut(S.tf_keys(cfg["tf"]))
+    res.set_tf_lut(lut)
+    win = abi.WindowingParams(*cfg["window"])
+    res.set_windowing(win)
+    world = S.default_world()
+    cam = S.default_camera(fb_w, fb_h)
+    tile = abi.Tile(0, 8 * rank, fb_w, rows_per_rank, n_gpus)
+    rp = abi.RaymarchParams(steps, -1, not args.no_skipping)
+
+    lights = [S.light(i) for i in cfg["lights"]]
+    light_dirs = [S.LIGHTS[i][0] for i in cfg["lights"]]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res.clear_light_volume(0.0)  # ResetAllLights (RaymarchVolume.cpp:418-451)
+    for l in lights:
+        res.add_dir_light(l, True, world)
+    res.flush()
+    reset_ms = (time.perf_counter() - t0) * 1e3
+
+    out = torch.empty((rows_per_rank, fb_w, 4), dtype=torch.float32, device=device)
+    gathered = torch.empty((n_gpus, rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) if n_gpus > 1 else None
+    my_samples = res.count_nominal_samples(cam, tile, rp, world)
+    total_samples = my_samples
+    if dist is not None:
+        t = torch.tensor([my_samples], dtype=torch.int64, device=device)
+        dist.all_reduce(t)
+        total_samples = int(t.item())
+
+    angle = [0.0] * len(lights)
+    ms_illum, ms_ray = [], []
+
+    def one_step(k, record):
+        if not args.raymarch_only:
+            li = k % len(lights)
+            angle[li] += 5.0
+            new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li]), lights[li].light_intensity)
+            res.change_dir_light(lights[li], new, world)
+            lights[li] = new
+        res.raymarch_lit_device(cam, tile, rp, world, out.data_ptr())
+        if dist is not None:
+            res.flush()  # the tile must be complete before RCCL reads it on torch's stream
+            dist.all_gather_into_tensor(gathered, out)
+        if record:
+            if not args.raymarch_only:
+                ms_illum.append(res.last_gpu_time_ms(0))
+            ms_ray.append(res.last_gpu_time_ms(1))
+
+    for k in range(args.warmup):
+        one_step(k, False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k, False)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel GPU time with HIP events on the library's stream (separate, untimed pass) -------------
+    for k in range(max(3, min(args.steps, 10))):
+        one_step(args.warmup + args.steps + k, True)
+    torch.cuda.synchronize()
+    ray_ms = float(np.mean(ms_ray))
+    illum_ms = float(np.mean(ms_illum)) if ms_illum else 0.0
+
+    # ---- roofline of the dominant kernel (algorithmic bytes) -------------------------------
+    b_data = np.dtype(cfg["dtype"]).itemsize
+    b_light = 4 if cfg["light_32bit"] else 1
+    V = n ** 3
+    ray_bytes = V * b_data + V * b_light + fb_w * rows_per_rank * 16 + 2048
+    pass_bytes = V * b_data + 2 * V * b_light
+    illum_bytes = 2 * pass_bytes  # fused Change = 2 axis passes
+    if ray_ms >= illum_ms:
+        dom = dict(kernel="k_raymarch_lit", achieved=ray_bytes / (ray_ms * 1e-3) / 1e9, launch_ms=ray_ms, alg_bytes=ray_bytes)
+    else:
+        dom = dict(kernel="change_dir_light (2 axis passes)", achieved=illum_bytes / (illum_ms * 1e-3) / 1e9,
+                   launch_ms=illum_ms, alg_bytes=illum_bytes)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get(dom["kernel"].split(" ")[0])
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic,
+                "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4)}
+
+    # ---- CPU baseline: the oracle on this host's cores, rank 0, N=1 only, bounded sample -------------------
+    cpu = None
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h)
+
+    if rank == 0:
+        value = total_samples * args.steps / elapsed / 1e6
+        line = {
+            "metric": "volume Msamples/s (rays x steps) at 512^3, 1024^2 view; % HBM roofline",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: {n}^3 {np.dtype(cfg['dtype']).name} volume, "
+                                   f"{'f32' if cfg['light_32bit'] else 'u8'} light volume, {fb_w}x{fb_h} RGBA f32 framebuffer, "
+                                   f"{int(steps)} steps, {len(lights)} dir lights, TF-{cfg['tf']}, 1 selective light update "
+                                   f"(ChangeDirLight) + 1 lit raymarch per step",
+                       "volume": [n, n, n], "framebuffer": [fb_w, fb_h], "steps": int(steps), "lights": len(lights),
+                       "parallelism": f"image tiles x{n_gpus} (interleaved 8-row groups), volumes replicated"
+                                      if n_gpus > 1 else "single GPU",
+                       "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only)},
+            "nominal_samples_per_step": total_samples,
+            "gpu_ms": {"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4), "reset_all_lights_setup": round(reset_ms, 2)},
+            "raymarch_only_msamples_per_s": round(my_samples / (ray_ms * 1e-3) / 1e6, 2),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    res.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h):
+    """Times the oracle (oracle/, test infrastructure) on a bounded sample of the same workload: the lit raymarch of
+    every g-th group of 8 rows of the same frame, reading the light volume the GPU just produced. g is chosen so the
+    sample takes about --cpu-seconds."""
+    from oracle import oracle
+    from tbraymarcherplugin_amd import abi
+
+    vol = vol_dev.cpu().numpy()
+    orc = oracle.OracleScene(vol, cfg["light_32bit"])
+    orc.set_tf_lut(lut)
+    orc.set_windowing(win)
+    orc.light[...] = res.download_light_volume()
+    cores = oracle.load().orc_num_threads()
+    groups = fb_h // 8
+    # probe: 2 row groups from the middle of the frame
+    probe = abi.Tile(0, 8 * (groups // 2), fb_w, 16, 1)
+    t0 = time.perf_counter()
+    _, n_probe = orc.raymarch_lit(cam, probe, rp, world)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    rate = n_probe / dt
+    _, n_full = orc.raymarch_lit(cam, abi.Tile(0, 0, fb_w, fb_h, 1), rp, world, count_only=True)
+    g = 1
+    while g < groups and n_full / g / rate > args.cpu_seconds:
+        g *= 2
+    sample = abi.Tile(0, 0, fb_w, (groups // g) * 8, g)
+    t0 = time.perf_counter()
+    _, n_s = orc.raymarch_lit(cam, sample, rp, world)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_s / dt / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
+            "sample": f"oracle lit raymarch of every {g}-th 8-row group of the same {fb_w}x{fb_h} frame "
+                      f"({n_s} nominal samples, {dt:.1f} s, OpenMP x{cores}); light volume taken from the GPU; "
+                      f"the light update is not part of the CPU sample"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,256 @@
+/*
+ * tbrm.h — C-ABI of the MI355X-native raymarch + illumination hot path.
+ *
+ * Drop-in boundary for the one hot path of tommybazar/TBRaymarcherPlugin:
+ * the operator library URaymarchUtils (reference Source/Raymarcher/Public/Util/RaymarchUtils.h:33-93),
+ * its render-thread drivers (Public/Rendering/LightingShaders.h:17-22) and the material entry point
+ * PerformWindowedLitRaymarch (Shaders/Private/WindowedRaymarchMaterials.usf:36-96) preceded by
+ * PerformRaymarchCubeSetup (Shaders/Private/RaymarchMaterialCommon.usf:23-69).
+ *
+ * Everything here is plain C: PODs, pointers, sizes. No HIP or torch types appear in signatures; a
+ * "stream" is passed as an opaque void* (a hipStream_t) only in the *_device entry points.
+ * Every struct below names the reference type it stands for. All calls on one tbrm_resources handle
+ * are enqueued on that handle's HIP stream in FIFO order (the reference's game thread -> render thread
+ * command queue, RaymarchUtils.cpp:63-66); tbrm_flush is the join (FlushRenderingCommands()).
+ */
+#ifndef TBRM_H
+#define TBRM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBRM_API __attribute__((visibility("default")))
+
+/* ---- status codes (the reference has no return codes; RaymarchUtils.cpp:39-49 reports through
+ *      `bool& LightAdded`, which every light entry point below keeps as an out-flag) ---- */
+enum {
+    TBRM_OK = 0,
+    TBRM_ERR_INVALID_ARG = 1,   /* null handle / null pointer / bad enum */
+    TBRM_ERR_NOT_INITIALIZED = 2, /* a resource the reference null-checks is missing -> light_added=false */
+    TBRM_ERR_NO_DEVICE = 3,     /* no HIP device / HIP runtime error (message via tbrm_last_error) */
+    TBRM_ERR_OUT_OF_MEMORY = 4,
+    TBRM_ERR_UNSUPPORTED = 5
+};
+
+/* ---- pixel formats of UVolumeTexture-shaped buffers (VolumeInfo.cpp:96-119) ---- */
+enum {
+    TBRM_FMT_G8 = 0,        /* PF_G8        UNORM8  */
+    TBRM_FMT_G16 = 1,       /* PF_G16       UNORM16 */
+    TBRM_FMT_R32_FLOAT = 2  /* PF_R32_FLOAT float   */
+};
+
+/* Address mode of the *material's* data-volume sampler (the texture asset's sampler, never set by the
+ * reference -> UVolumeTexture default TA_Wrap). The light volume is always sampled with
+ * wrap (Material.Wrap_WorldGroupSettings, WindowedRaymarchMaterials.usf:30) and the propagation shaders
+ * always sample the data volume with border addressing (LightingShaders.h:82-89). */
+enum { TBRM_ADDRESS_WRAP = 0, TBRM_ADDRESS_CLAMP = 1 };
+
+/* How sampler border colours are formed (engine behaviour outside the reference):
+ * ENGINE_8BIT : read-buffer border = sRGB-8-bit round trip of clamp01(I*w)  (LightingShaderUtils.cpp:197-203),
+ *               data-volume border = round(clamp01(C - W/2)*255)/255         (LightingShaders.h:82-85);
+ * EXACT_FLOAT : both borders keep their float value (diagnostics). */
+enum { TBRM_BORDER_ENGINE_8BIT = 0, TBRM_BORDER_EXACT_FLOAT = 1 };
+
+/* ERaymarchMaterial (RaymarchVolume.h:24-29). Only Lit is on the hot path this round. */
+enum { TBRM_MATERIAL_LIT = 0, TBRM_MATERIAL_INTENSITY = 1, TBRM_MATERIAL_OCTREE = 2 };
+
+/* FVector / FQuat / FTransform — double precision in UE5. */
+typedef struct tbrm_vec3d { double x, y, z; } tbrm_vec3d;
+typedef struct tbrm_quatd { double x, y, z, w; } tbrm_quatd;
+typedef struct tbrm_transform {
+    tbrm_quatd rotation;    /* unit quaternion */
+    tbrm_vec3d translation;
+    tbrm_vec3d scale3d;
+} tbrm_transform;
+
+/* FDirLightParameters (RaymarchTypes.h:20-41). */
+typedef struct tbrm_dir_light_params {
+    tbrm_vec3d light_direction; /* world space, need not be normalised */
+    float light_intensity;
+    int32_t _pad;
+} tbrm_dir_light_params;
+
+/* FClippingPlaneParameters (RaymarchTypes.h:45-71): Center + the direction that is NOT clipped away. */
+typedef struct tbrm_clipping_plane_params {
+    tbrm_vec3d center;
+    tbrm_vec3d direction;
+} tbrm_clipping_plane_params;
+
+/* FRaymarchWorldParameters (RaymarchTypes.h:136-153). */
+typedef struct tbrm_world_params {
+    tbrm_transform volume_transform;
+    tbrm_clipping_plane_params clipping_plane;
+} tbrm_world_params;
+
+/* FWindowingParameters (VolumeTextureToolkit/Public/VolumeAsset/VolumeInfo.h:31-53). */
+typedef struct tbrm_windowing_params {
+    float center;        /* default 0.5 */
+    float width;         /* default 1.0 */
+    int32_t low_cutoff;  /* default true */
+    int32_t high_cutoff; /* default true */
+} tbrm_windowing_params;
+
+/* What InitializeRaymarchResources (RaymarchVolume.cpp:821-920) decides from the data volume + flags. */
+typedef struct tbrm_resources_desc {
+    int32_t dim_x, dim_y, dim_z;              /* data volume size in voxels */
+    int32_t data_format;                      /* TBRM_FMT_* */
+    int32_t light_volume_32bit;               /* bLightVolume32Bit: PF_R32_FLOAT instead of PF_G8 (:857-861) */
+    int32_t light_volume_half_resolution;     /* LightVolumeHalfResolution: ceil(dim/2) (:850-855) */
+    int32_t device;                           /* HIP device ordinal */
+    int32_t data_address_mode;                /* TBRM_ADDRESS_* for the raymarch material's data sampler */
+    int32_t border_mode;                      /* TBRM_BORDER_* */
+    int32_t _reserved;
+} tbrm_resources_desc;
+
+/* The view uniforms PerformRaymarchCubeSetup reads from the engine (ResolvedView.WorldCameraOrigin,
+ * ViewToTranslatedWorld, CameraVector; RaymarchMaterialCommon.usf:26-48) restated as an explicit pinhole
+ * camera. Pixel (px,py) looks along normalize(forward + sx*right + sy*up) with
+ * sx = (2*(px+0.5)/width - 1)*tan_half_fov_x, sy = (1 - 2*(py+0.5)/height)*tan_half_fov_y. */
+typedef struct tbrm_camera {
+    tbrm_vec3d position;  /* world */
+    tbrm_vec3d forward;   /* world, unit */
+    tbrm_vec3d right;     /* world, unit */
+    tbrm_vec3d up;        /* world, unit */
+    double tan_half_fov_x;
+    double tan_half_fov_y;
+    int32_t width;        /* full framebuffer size in pixels */
+    int32_t height;
+} tbrm_camera;
+
+/* The part of the framebuffer one call renders (image-tile sharding). Output row j of the
+ * w x h result is framebuffer row  y0 + (j/8)*8*row_group_step + (j%8)  (row_group_step = 1: plain
+ * rectangle; = N: every N-th group of 8 rows, the load-balanced interleave used across N GPUs). */
+typedef struct tbrm_tile {
+    int32_t x0, y0;
+    int32_t w, h;
+    int32_t row_group_step;
+    int32_t _pad;
+} tbrm_tile;
+
+/* Per-call raymarch parameters = the material parameters ARaymarchVolume sets by name
+ * (RaymarchMaterialParameters.h:13-23, RaymarchVolume.cpp:671-728). */
+typedef struct tbrm_raymarch_params {
+    float steps;              /* "Steps" (RaymarchingSteps, default 150; RaymarchVolume.h:188-189) */
+    int32_t jitter_frame;     /* View.StateFrameIndexMod8 (0..7); < 0 disables JitterEntryPos */
+    int32_t enable_skipping;  /* empty-space skipping on/off (results are identical either way) */
+    int32_t _pad;
+} tbrm_raymarch_params;
+
+/* Host-side parameter block of ONE propagation axis pass — everything LightingShaders.cpp:91-131 computes
+ * before its slice loop, already narrowed to what the shader binds (LightingShaders.h:100-160). Exposed so
+ * the host math can be tested without a GPU. */
+typedef struct tbrm_light_pass {
+    int32_t face;              /* FCubeFace 0..5 = +X,-X,+Y,-Y,+Z,-Z (LightingShaderUtils.h:21-29) */
+    int32_t axis;              /* face / 2 */
+    float weight;              /* FaceWeight[i].second after the 0.99 snap / 1-w0 rule */
+    float light_alpha;         /* GetLightAlpha = Intensity * weight: buffer clear value */
+    float border_light;        /* read-buffer sampler border colour (see TBRM_BORDER_*) */
+    float prev_pixel_offset[2];/* PrevPixelOffset (GetUVOffset) */
+    float uvw_offset[3];       /* UVWOffset after renormalisation to 1/min(TD) */
+    float step_size;           /* StepSize */
+    int32_t td[3];             /* TransposedDimensions of the light volume */
+    int32_t start, stop, dir;  /* GetLoopStartStopIndexes */
+} tbrm_light_pass;
+
+typedef struct tbrm_resources tbrm_resources; /* opaque: FBasicRaymarchRenderingResources (RaymarchTypes.h:87-129) */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* library                                                                                           */
+TBRM_API const char* tbrm_version(void);
+TBRM_API const char* tbrm_last_error(void);       /* thread-local message of the last failing call */
+TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the HIP runtime has none */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* resources: ARaymarchVolume::InitializeRaymarchResources / FreeRaymarchResources                   */
+/* (RaymarchVolume.cpp:821-949). The handle owns every device allocation (data volume copy, TF LUT,   */
+/* light volume, 4 read/write buffers per axis, skipping metadata) and one HIP stream.                */
+TBRM_API int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out);
+TBRM_API int tbrm_resources_destroy(tbrm_resources* res);
+TBRM_API int tbrm_resources_light_volume_dims(const tbrm_resources* res, int32_t out_dims[3]);
+TBRM_API int tbrm_resources_is_initialized(const tbrm_resources* res); /* bIsInitialized: volume + TF present */
+
+/* UVolumeTexture-shaped input: dense x-fastest array in desc.data_format (CreateVolumeTextureMip memcpy,
+ * TextureUtilities.cpp:43-78). Host pointer variant copies over PCIe; device variant reads HBM.        */
+TBRM_API int tbrm_upload_volume(tbrm_resources* res, const void* host_voxels, size_t n_bytes);
+TBRM_API int tbrm_upload_volume_device(tbrm_resources* res, const void* device_voxels, size_t n_bytes);
+
+/* Transfer function. tbrm_set_tf_lut takes the 256 x RGBA float samples ColorCurveToTexture would take from
+ * the curve and stores them as FFloat16 (RaymarchUtils.cpp:143-174). tbrm_color_curve_to_lut evaluates
+ * piecewise-linear colour-curve keys (UCurveLinearColor with RCIM_Linear keys, constant extrapolation)
+ * at i/255. tbrm_make_default_tf_lut = MakeDefaultTFTexture (RaymarchUtils.cpp:113-141).                */
+TBRM_API int tbrm_set_tf_lut(tbrm_resources* res, const float* rgba_256x4);
+TBRM_API int tbrm_color_curve_to_lut(const float* key_times[4], const float* key_values[4],
+                                     const int32_t n_keys[4], float* out_rgba_256x4);
+TBRM_API int tbrm_make_default_tf_lut(float* out_rgba_256x4);
+
+/* FBasicRaymarchRenderingResources::WindowingParameters. */
+TBRM_API int tbrm_set_windowing(tbrm_resources* res, const tbrm_windowing_params* windowing);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* illumination operators (URaymarchUtils, RaymarchUtils.h:33-49)                                     */
+
+/* AddDirLightToSingleVolume(Resources, LightParameters, Added, WorldParameters, LightAdded, bGPUSync).
+ * gpu_sync is accepted and ignored (the reference's bGPUSync branch is a no-op, RaymarchUtils.cpp:51-59;
+ * this library always runs the real propagation). Zero light direction: TBRM_OK, nothing enqueued,
+ * *light_added = 1 (LightingShaders.cpp:41-46). */
+TBRM_API int tbrm_add_dir_light(tbrm_resources* res, const tbrm_dir_light_params* light, int added,
+                                const tbrm_world_params* world, int* light_added, int gpu_sync);
+
+/* ChangeDirLightInSingleVolume(Resources, Old, New, WorldParameters, LightAdded). Falls back to
+ * remove + add when the two major axes differ (LightingShaders.cpp:192-198). */
+TBRM_API int tbrm_change_dir_light(tbrm_resources* res, const tbrm_dir_light_params* old_light,
+                                   const tbrm_dir_light_params* new_light, const tbrm_world_params* world,
+                                   int* light_added);
+
+/* ClearResourceLightVolumes(Resources, ClearValue) (RaymarchUtils.cpp:104-111). */
+TBRM_API int tbrm_clear_light_volume(tbrm_resources* res, float clear_value);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* raymarch: PerformRaymarchCubeSetup + PerformWindowedLitRaymarch for every pixel of `tile`.         */
+/* Output: premultiplied RGBA float, tile.w x tile.h x 4, row-major (what BLEND_AlphaComposite receives). */
+/* scene_depth (optional, may be NULL): CalcSceneDepth per full-framebuffer pixel, world units.        */
+TBRM_API int tbrm_raymarch_lit(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                               const tbrm_raymarch_params* params, const tbrm_world_params* world,
+                               float* host_out_rgba);
+TBRM_API int tbrm_raymarch_lit_device(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                      const tbrm_raymarch_params* params, const tbrm_world_params* world,
+                                      const float* device_scene_depth, float* device_out_rgba);
+
+/* Nominal samples of one tile: sum over rays of floor(Steps*thickness) + [frac > 0]. Runs on
+ * the GPU with the same cube-setup arithmetic as the raymarch; result is written to *out_samples.        */
+TBRM_API int tbrm_count_nominal_samples(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                        const tbrm_raymarch_params* params, const tbrm_world_params* world,
+                                        uint64_t* out_samples);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* readback / sync / interop                                                                          */
+TBRM_API int tbrm_download_light_volume(tbrm_resources* res, void* host_out, size_t n_bytes);
+TBRM_API int tbrm_upload_light_volume(tbrm_resources* res, const void* host_in, size_t n_bytes);
+TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, size_t* out_bytes);
+TBRM_API int tbrm_flush(tbrm_resources* res);                 /* FlushRenderingCommands() */
+TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
+/* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's
+ * stream; blocks until that work is complete. kind: 0 = add/change/clear (illumination), 1 = raymarch.  */
+TBRM_API int tbrm_last_gpu_time_ms(tbrm_resources* res, int kind, float* out_ms);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* host parameter math, no GPU needed (LightingShaderUtils.cpp:29-265, LightingShaders.cpp:48-131)     */
+/* Fills out[0..1]; *n_passes = number of axis passes an Add would run (it breaks on weight == 0).      */
+TBRM_API int tbrm_host_light_passes(const tbrm_dir_light_params* light, const tbrm_world_params* world,
+                                    const int32_t light_volume_dims[3], int border_mode,
+                                    tbrm_light_pass out[2], int* n_passes);
+/* GetLocalClippingParameters (LightingShaderUtils.cpp:205-220), narrowed to float[3] + float[3].        */
+TBRM_API int tbrm_host_local_clipping(const tbrm_world_params* world, float out_center[3], float out_dir[3]);
+/* Data-volume border colour of the propagation sampler (LightingShaders.h:82-85).                      */
+TBRM_API float tbrm_host_data_border(const tbrm_windowing_params* windowing, int border_mode);
+/* WorldToLocal of the cube mesh (row-vector 4x3: rows 0-2 = 3x3 incl. 1/scale, row 3 = translation).    */
+TBRM_API int tbrm_host_world_to_local(const tbrm_transform* volume_transform, float out_m[12]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBRM_H */

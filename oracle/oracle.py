@@ -1,0 +1,180 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY — see tbrm_oracle.c).
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only. Parameter structs are the
+ABI PODs of include/tbrm.h (mirrored in tbraymarcherplugin_amd.abi) so both sides receive identical bytes.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tbraymarcherplugin_amd import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libtbrm_oracle.so")
+
+ADDR_WRAP, ADDR_CLAMP, ADDR_BORDER = 0, 1, 2
+
+
+class VolumeView(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dim_x", C.c_int32), ("dim_y", C.c_int32), ("dim_z", C.c_int32), ("format", C.c_int32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("data", VolumeView), ("tf", C.c_void_p), ("windowing", abi.WindowingParams), ("light", C.c_void_p),
+                ("light_dims", C.c_int32 * 3), ("light_format", C.c_int32), ("data_address_mode", C.c_int32),
+                ("border_mode", C.c_int32)]
+
+
+_lib = None
+
+
+def build(force=False):
+    src = [os.path.join(HERE, f) for f in ("tbrm_oracle.c", "tbrm_oracle.h", "Makefile")] + [
+        os.path.join(HERE, "..", "include", "tbrm.h")]
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
+    if force or stale:
+        subprocess.run(["make", "-C", HERE] + (["-B"] if force else []), check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    # idle OpenMP workers should sleep, not spin (the slice loop forks/joins once per slice)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    lib = C.CDLL(LIB_PATH)
+    P, vp, f = C.POINTER, C.c_void_p, C.c_float
+    lib.orc_log2f.restype = f; lib.orc_log2f.argtypes = [f]
+    lib.orc_exp2f.restype = f; lib.orc_exp2f.argtypes = [f]
+    lib.orc_powf.restype = f; lib.orc_powf.argtypes = [f, f]
+    lib.orc_round_to_half.restype = f; lib.orc_round_to_half.argtypes = [f]
+    lib.orc_bake_tf.argtypes = [vp, vp]
+    lib.orc_color_curve_to_lut.argtypes = [P(vp * 4), P(vp * 4), P(C.c_int32 * 4), vp]
+    lib.orc_make_default_tf_lut.argtypes = [vp]
+    lib.orc_world_to_local.argtypes = [P(abi.Transform), P(f * 12)]
+    lib.orc_local_clipping.argtypes = [P(abi.WorldParams), P(f * 3), P(f * 3)]
+    lib.orc_data_border.restype = f; lib.orc_data_border.argtypes = [P(abi.WindowingParams), C.c_int]
+    lib.orc_light_passes.argtypes = [P(abi.DirLightParams), P(abi.WorldParams), P(C.c_int32 * 3), C.c_int, P(abi.LightPass * 2), P(C.c_int)]
+    lib.orc_add_dir_light.argtypes = [P(Scene), P(abi.DirLightParams), C.c_int, P(abi.WorldParams)]
+    lib.orc_change_dir_light.argtypes = [P(Scene), P(abi.DirLightParams), P(abi.DirLightParams), P(abi.WorldParams)]
+    lib.orc_clear_light_volume.argtypes = [P(Scene), f]
+    lib.orc_raymarch_lit.argtypes = [P(Scene), P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp, P(C.c_uint64)]
+    lib.orc_probe_sample_volume.restype = f
+    lib.orc_probe_sample_volume.argtypes = [P(VolumeView), f, f, f, C.c_int, f]
+    lib.orc_probe_windowed_tf.argtypes = [f, f, vp, P(abi.WindowingParams), P(f * 4)]
+    lib.orc_probe_ray_aabb.argtypes = [P(f * 3), P(f * 3), P(f * 2)]
+    lib.orc_probe_encode_unorm8.restype = C.c_uint8; lib.orc_probe_encode_unorm8.argtypes = [f]
+    lib.orc_probe_srgb8_round_trip.restype = f; lib.orc_probe_srgb8_round_trip.argtypes = [f]
+    lib.orc_set_num_threads.argtypes = [C.c_int]
+    _lib = lib
+    return lib
+
+
+def powf(x, y):
+    return float(load().orc_powf(x, y))
+
+
+def bake_tf(lut):
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    out = np.empty_like(lut)
+    load().orc_bake_tf(lut.ctypes.data, out.ctypes.data)
+    return out
+
+
+def color_curve_to_lut(keys):
+    arrs = [(np.ascontiguousarray(t, dtype=np.float32), np.ascontiguousarray(v, dtype=np.float32)) for t, v in keys]
+    times = (C.c_void_p * 4)(*[a[0].ctypes.data for a in arrs])
+    vals = (C.c_void_p * 4)(*[a[1].ctypes.data for a in arrs])
+    n = (C.c_int32 * 4)(*[len(a[0]) for a in arrs])
+    out = np.empty((256, 4), dtype=np.float32)
+    load().orc_color_curve_to_lut(C.byref(times), C.byref(vals), C.byref(n), out.ctypes.data)
+    return out
+
+
+def make_default_tf_lut():
+    out = np.empty((256, 4), dtype=np.float32)
+    load().orc_make_default_tf_lut(out.ctypes.data)
+    return out
+
+
+def light_passes(light, world, lv_dims, border_mode=abi.BORDER_ENGINE_8BIT):
+    out = (abi.LightPass * 2)()
+    n = C.c_int(0)
+    dims = (C.c_int32 * 3)(*lv_dims)
+    load().orc_light_passes(C.byref(light), C.byref(world), C.byref(dims), border_mode, C.byref(out), C.byref(n))
+    return [out[0], out[1]], n.value
+
+
+def local_clipping(world):
+    c, d = (C.c_float * 3)(), (C.c_float * 3)()
+    load().orc_local_clipping(C.byref(world), C.byref(c), C.byref(d))
+    return np.array(c[:], dtype=np.float32), np.array(d[:], dtype=np.float32)
+
+
+def world_to_local(transform):
+    m = (C.c_float * 12)()
+    load().orc_world_to_local(C.byref(transform), C.byref(m))
+    return np.array(m[:], dtype=np.float32)
+
+
+def data_border(windowing, border_mode=abi.BORDER_ENGINE_8BIT):
+    return float(load().orc_data_border(C.byref(windowing), border_mode))
+
+
+class OracleScene:
+    """Host-side twin of abi.Resources: same setters, same operators, numpy storage."""
+
+    def __init__(self, volume, light_32bit=False, half_res=False, data_address_mode=abi.ADDRESS_WRAP,
+                 border_mode=abi.BORDER_ENGINE_8BIT):
+        self.lib = load()
+        self.volume = np.ascontiguousarray(volume)
+        nz, ny, nx = self.volume.shape
+        self.dims = (nx, ny, nz)
+        self.light_dims = tuple((d + 1) // 2 if half_res else d for d in self.dims)
+        self.light_dtype = np.float32 if light_32bit else np.uint8
+        self.light = np.zeros(self.light_dims[::-1], dtype=self.light_dtype)
+        self.tf = bake_tf(make_default_tf_lut())
+        self.windowing = abi.WindowingParams()
+        self.data_address_mode = data_address_mode
+        self.border_mode = border_mode
+
+    def set_tf_lut(self, lut):
+        self.tf = bake_tf(np.asarray(lut, dtype=np.float32).reshape(256, 4))
+
+    def set_windowing(self, w):
+        self.windowing = abi.WindowingParams(w.center, w.width, w.low_cutoff, w.high_cutoff)
+
+    def _scene(self):
+        return Scene(VolumeView(self.volume.ctypes.data, self.dims[0], self.dims[1], self.dims[2], abi.DTYPE_FMT[self.volume.dtype]),
+                     self.tf.ctypes.data, self.windowing, self.light.ctypes.data, (C.c_int32 * 3)(*self.light_dims),
+                     abi.FMT_R32_FLOAT if self.light_dtype == np.float32 else abi.FMT_G8,
+                     self.data_address_mode, self.border_mode)
+
+    def add_dir_light(self, light, added, world):
+        sc = self._scene()
+        return self.lib.orc_add_dir_light(C.byref(sc), C.byref(light), int(bool(added)), C.byref(world))
+
+    def change_dir_light(self, old, new, world):
+        sc = self._scene()
+        return self.lib.orc_change_dir_light(C.byref(sc), C.byref(old), C.byref(new), C.byref(world))
+
+    def clear_light_volume(self, value=0.0):
+        sc = self._scene()
+        self.lib.orc_clear_light_volume(C.byref(sc), float(value))
+
+    def raymarch_lit(self, camera, tile, params, world, scene_depth=None, count_only=False):
+        sc = self._scene()
+        out = None if count_only else np.empty((tile.h, tile.w, 4), dtype=np.float32)
+        n = C.c_uint64(0)
+        depth_ptr = None
+        if scene_depth is not None:
+            scene_depth = np.ascontiguousarray(scene_depth, dtype=np.float32)
+            depth_ptr = scene_depth.ctypes.data
+        self.lib.orc_raymarch_lit(C.byref(sc), C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
+                                  depth_ptr, None if out is None else out.ctypes.data, C.byref(n))
+        return out, int(n.value)

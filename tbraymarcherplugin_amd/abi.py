@@ -1,0 +1,351 @@
+"""ctypes mirror of include/tbrm.h and a thin handle wrapper over libtbrm.so.
+
+This is plumbing for tests and bench.py: every method is one C-ABI call. There is no Python or CPU
+implementation of the path here; if libtbrm.so (the HIP extension) is missing, loading raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtbrm.so")
+
+# enums (include/tbrm.h)
+OK, ERR_INVALID_ARG, ERR_NOT_INITIALIZED, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED = range(6)
+FMT_G8, FMT_G16, FMT_R32_FLOAT = 0, 1, 2
+ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
+BORDER_ENGINE_8BIT, BORDER_EXACT_FLOAT = 0, 1
+
+FMT_DTYPE = {FMT_G8: np.uint8, FMT_G16: np.uint16, FMT_R32_FLOAT: np.float32}
+DTYPE_FMT = {np.dtype(np.uint8): FMT_G8, np.dtype(np.uint16): FMT_G16, np.dtype(np.float32): FMT_R32_FLOAT}
+
+
+class Vec3d(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        super().__init__(float(x), float(y), float(z))
+
+
+class Quatd(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double), ("w", C.c_double)]
+
+    def __init__(self, x=0.0, y=0.0, z=0.0, w=1.0):
+        super().__init__(float(x), float(y), float(z), float(w))
+
+
+class Transform(C.Structure):  # FTransform
+    _fields_ = [("rotation", Quatd), ("translation", Vec3d), ("scale3d", Vec3d)]
+
+
+class DirLightParams(C.Structure):  # FDirLightParameters
+    _fields_ = [("light_direction", Vec3d), ("light_intensity", C.c_float), ("_pad", C.c_int32)]
+
+    def __init__(self, direction=(0.0, 0.0, 0.0), intensity=0.0):
+        super().__init__(Vec3d(*direction), float(intensity), 0)
+
+
+class ClippingPlaneParams(C.Structure):  # FClippingPlaneParameters
+    _fields_ = [("center", Vec3d), ("direction", Vec3d)]
+
+
+class WorldParams(C.Structure):  # FRaymarchWorldParameters
+    _fields_ = [("volume_transform", Transform), ("clipping_plane", ClippingPlaneParams)]
+
+
+class WindowingParams(C.Structure):  # FWindowingParameters
+    _fields_ = [("center", C.c_float), ("width", C.c_float), ("low_cutoff", C.c_int32), ("high_cutoff", C.c_int32)]
+
+    def __init__(self, center=0.5, width=1.0, low_cutoff=True, high_cutoff=True):
+        super().__init__(float(center), float(width), int(bool(low_cutoff)), int(bool(high_cutoff)))
+
+
+class ResourcesDesc(C.Structure):
+    _fields_ = [("dim_x", C.c_int32), ("dim_y", C.c_int32), ("dim_z", C.c_int32), ("data_format", C.c_int32),
+                ("light_volume_32bit", C.c_int32), ("light_volume_half_resolution", C.c_int32),
+                ("device", C.c_int32), ("data_address_mode", C.c_int32), ("border_mode", C.c_int32),
+                ("_reserved", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("position", Vec3d), ("forward", Vec3d), ("right", Vec3d), ("up", Vec3d),
+                ("tan_half_fov_x", C.c_double), ("tan_half_fov_y", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Tile(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("row_group_step", C.c_int32), ("_pad", C.c_int32)]
+
+    def __init__(self, x0=0, y0=0, w=0, h=0, row_group_step=1):
+        super().__init__(int(x0), int(y0), int(w), int(h), int(row_group_step), 0)
+
+
+class RaymarchParams(C.Structure):
+    _fields_ = [("steps", C.c_float), ("jitter_frame", C.c_int32), ("enable_skipping", C.c_int32), ("_pad", C.c_int32)]
+
+    def __init__(self, steps=150.0, jitter_frame=-1, enable_skipping=True):
+        super().__init__(float(steps), int(jitter_frame), int(bool(enable_skipping)), 0)
+
+
+class LightPass(C.Structure):
+    _fields_ = [("face", C.c_int32), ("axis", C.c_int32), ("weight", C.c_float), ("light_alpha", C.c_float),
+                ("border_light", C.c_float), ("prev_pixel_offset", C.c_float * 2), ("uvw_offset", C.c_float * 3),
+                ("step_size", C.c_float), ("td", C.c_int32 * 3), ("start", C.c_int32), ("stop", C.c_int32),
+                ("dir", C.c_int32)]
+
+    def as_dict(self):
+        return {"face": self.face, "axis": self.axis, "weight": self.weight, "light_alpha": self.light_alpha,
+                "border_light": self.border_light, "prev_pixel_offset": list(self.prev_pixel_offset),
+                "uvw_offset": list(self.uvw_offset), "step_size": self.step_size, "td": list(self.td),
+                "start": self.start, "stop": self.stop, "dir": self.dir}
+
+
+# every symbol include/tbrm.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    "tbrm_version", "tbrm_last_error", "tbrm_device_count",
+    "tbrm_resources_create", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
+    "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
+    "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_set_windowing",
+    "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
+    "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_count_nominal_samples",
+    "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
+    "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
+]
+
+_lib = None
+
+
+class TbrmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"tbrm error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Loads libtbrm.so. Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension with `python tbraymarcherplugin_amd/build.py` "
+            "(__graft_entry__.build()). There is no CPU fallback for this path.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib.tbrm_version.restype = C.c_char_p
+    lib.tbrm_last_error.restype = C.c_char_p
+    lib.tbrm_host_data_border.restype = C.c_float
+    lib.tbrm_host_data_border.argtypes = [C.POINTER(WindowingParams), C.c_int]
+    P = C.POINTER
+    vp = C.c_void_p
+    lib.tbrm_device_count.argtypes = [P(C.c_int)]
+    lib.tbrm_resources_create.argtypes = [P(ResourcesDesc), P(vp)]
+    lib.tbrm_resources_destroy.argtypes = [vp]
+    lib.tbrm_resources_light_volume_dims.argtypes = [vp, P(C.c_int32 * 3)]
+    lib.tbrm_resources_is_initialized.argtypes = [vp]
+    lib.tbrm_upload_volume.argtypes = [vp, vp, C.c_size_t]
+    lib.tbrm_upload_volume_device.argtypes = [vp, vp, C.c_size_t]
+    lib.tbrm_set_tf_lut.argtypes = [vp, vp]
+    lib.tbrm_color_curve_to_lut.argtypes = [P(vp * 4), P(vp * 4), P(C.c_int32 * 4), vp]
+    lib.tbrm_make_default_tf_lut.argtypes = [vp]
+    lib.tbrm_set_windowing.argtypes = [vp, P(WindowingParams)]
+    lib.tbrm_add_dir_light.argtypes = [vp, P(DirLightParams), C.c_int, P(WorldParams), P(C.c_int), C.c_int]
+    lib.tbrm_change_dir_light.argtypes = [vp, P(DirLightParams), P(DirLightParams), P(WorldParams), P(C.c_int)]
+    lib.tbrm_clear_light_volume.argtypes = [vp, C.c_float]
+    lib.tbrm_raymarch_lit.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
+    lib.tbrm_raymarch_lit_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
+    lib.tbrm_count_nominal_samples.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), P(C.c_uint64)]
+    lib.tbrm_download_light_volume.argtypes = [vp, vp, C.c_size_t]
+    lib.tbrm_upload_light_volume.argtypes = [vp, vp, C.c_size_t]
+    lib.tbrm_light_volume_device_ptr.argtypes = [vp, P(vp), P(C.c_size_t)]
+    lib.tbrm_flush.argtypes = [vp]
+    lib.tbrm_stream.argtypes = [vp, P(vp)]
+    lib.tbrm_last_gpu_time_ms.argtypes = [vp, C.c_int, P(C.c_float)]
+    lib.tbrm_host_light_passes.argtypes = [P(DirLightParams), P(WorldParams), P(C.c_int32 * 3), C.c_int, P(LightPass * 2), P(C.c_int)]
+    lib.tbrm_host_local_clipping.argtypes = [P(WorldParams), P(C.c_float * 3), P(C.c_float * 3)]
+    lib.tbrm_host_world_to_local.argtypes = [P(Transform), P(C.c_float * 12)]
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != OK:
+        raise TbrmError(code, load().tbrm_last_error().decode())
+
+
+def identity_transform(scale=100.0, translation=(0.0, 0.0, 0.0), rotation=(0.0, 0.0, 0.0, 1.0)):
+    """The cube mesh component's transform; scale 100 = WorldDimensions/10 of a unit cube (RaymarchVolume.cpp:47)."""
+    s = (scale, scale, scale) if np.isscalar(scale) else scale
+    return Transform(Quatd(*rotation), Vec3d(*translation), Vec3d(*s))
+
+
+def make_world(transform=None, clip_center=(0.0, 0.0, 100000.0), clip_direction=(0.0, 0.0, -1.0)):
+    """FRaymarchWorldParameters; the defaults are the 'no clipping plane' values of RaymarchVolume.cpp:637-642."""
+    return WorldParams(transform if transform is not None else identity_transform(),
+                       ClippingPlaneParams(Vec3d(*clip_center), Vec3d(*clip_direction)))
+
+
+def look_at_camera(eye, target, up, vfov_deg, width, height):
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    r = np.cross(f, up)
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    thy = np.tan(np.deg2rad(vfov_deg) / 2.0)
+    thx = thy * width / height
+    return Camera(Vec3d(*eye), Vec3d(*f), Vec3d(*r), Vec3d(*u), thx, thy, int(width), int(height))
+
+
+def host_light_passes(light, world, lv_dims, border_mode=BORDER_ENGINE_8BIT):
+    out = (LightPass * 2)()
+    n = C.c_int(0)
+    dims = (C.c_int32 * 3)(*lv_dims)
+    check(load().tbrm_host_light_passes(C.byref(light), C.byref(world), C.byref(dims), border_mode, C.byref(out), C.byref(n)))
+    return [out[0], out[1]], n.value
+
+
+def host_local_clipping(world):
+    c, d = (C.c_float * 3)(), (C.c_float * 3)()
+    check(load().tbrm_host_local_clipping(C.byref(world), C.byref(c), C.byref(d)))
+    return np.array(c[:], dtype=np.float32), np.array(d[:], dtype=np.float32)
+
+
+def host_world_to_local(transform):
+    m = (C.c_float * 12)()
+    check(load().tbrm_host_world_to_local(C.byref(transform), C.byref(m)))
+    return np.array(m[:], dtype=np.float32)
+
+
+def host_data_border(windowing, border_mode=BORDER_ENGINE_8BIT):
+    return float(load().tbrm_host_data_border(C.byref(windowing), border_mode))
+
+
+def color_curve_to_lut(keys):
+    """keys: 4 (times, values) pairs, R,G,B,A. Returns the 256x4 float LUT ColorCurveToTexture samples."""
+    arrs = [(np.ascontiguousarray(t, dtype=np.float32), np.ascontiguousarray(v, dtype=np.float32)) for t, v in keys]
+    times = (C.c_void_p * 4)(*[a[0].ctypes.data for a in arrs])
+    vals = (C.c_void_p * 4)(*[a[1].ctypes.data for a in arrs])
+    n = (C.c_int32 * 4)(*[len(a[0]) for a in arrs])
+    out = np.empty((256, 4), dtype=np.float32)
+    check(load().tbrm_color_curve_to_lut(C.byref(times), C.byref(vals), C.byref(n), out.ctypes.data))
+    return out
+
+
+def make_default_tf_lut():
+    out = np.empty((256, 4), dtype=np.float32)
+    check(load().tbrm_make_default_tf_lut(out.ctypes.data))
+    return out
+
+
+def device_count():
+    n = C.c_int(0)
+    code = load().tbrm_device_count(C.byref(n))
+    return n.value if code == OK else 0
+
+
+class Resources:
+    """Owns one tbrm_resources handle (FBasicRaymarchRenderingResources)."""
+
+    def __init__(self, dims, data_format, light_32bit=False, half_res=False, device=0,
+                 data_address_mode=ADDRESS_WRAP, border_mode=BORDER_ENGINE_8BIT):
+        self.lib = load()
+        self.desc = ResourcesDesc(int(dims[0]), int(dims[1]), int(dims[2]), int(data_format), int(bool(light_32bit)),
+                                  int(bool(half_res)), int(device), int(data_address_mode), int(border_mode), 0)
+        self.handle = C.c_void_p()
+        check(self.lib.tbrm_resources_create(C.byref(self.desc), C.byref(self.handle)))
+        d = (C.c_int32 * 3)()
+        check(self.lib.tbrm_resources_light_volume_dims(self.handle, C.byref(d)))
+        self.light_dims = tuple(d[:])
+        self.light_dtype = np.float32 if light_32bit else np.uint8
+
+    def close(self):
+        if self.handle:
+            self.lib.tbrm_resources_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # volume arrays are indexed [z, y, x] (x fastest), like the dense UVolumeTexture mip
+    def upload_volume(self, vol):
+        vol = np.ascontiguousarray(vol)
+        assert DTYPE_FMT[vol.dtype] == self.desc.data_format
+        assert vol.shape == (self.desc.dim_z, self.desc.dim_y, self.desc.dim_x)
+        check(self.lib.tbrm_upload_volume(self.handle, vol.ctypes.data, vol.nbytes))
+
+    def upload_volume_device(self, ptr, nbytes):
+        check(self.lib.tbrm_upload_volume_device(self.handle, C.c_void_p(ptr), nbytes))
+
+    def set_tf_lut(self, lut):
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        assert lut.shape == (256, 4)
+        check(self.lib.tbrm_set_tf_lut(self.handle, lut.ctypes.data))
+
+    def set_windowing(self, w):
+        check(self.lib.tbrm_set_windowing(self.handle, C.byref(w)))
+
+    def is_initialized(self):
+        return bool(self.lib.tbrm_resources_is_initialized(self.handle))
+
+    def add_dir_light(self, light, added, world, gpu_sync=False):
+        flag = C.c_int(0)
+        check(self.lib.tbrm_add_dir_light(self.handle, C.byref(light), int(bool(added)), C.byref(world), C.byref(flag), int(gpu_sync)))
+        return bool(flag.value)
+
+    def change_dir_light(self, old, new, world):
+        flag = C.c_int(0)
+        check(self.lib.tbrm_change_dir_light(self.handle, C.byref(old), C.byref(new), C.byref(world), C.byref(flag)))
+        return bool(flag.value)
+
+    def clear_light_volume(self, value=0.0):
+        check(self.lib.tbrm_clear_light_volume(self.handle, float(value)))
+
+    def raymarch_lit(self, camera, tile, params, world):
+        out = np.empty((tile.h, tile.w, 4), dtype=np.float32)
+        check(self.lib.tbrm_raymarch_lit(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world), out.ctypes.data))
+        return out
+
+    def raymarch_lit_device(self, camera, tile, params, world, out_ptr, depth_ptr=None):
+        check(self.lib.tbrm_raymarch_lit_device(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
+                                                C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
+
+    def count_nominal_samples(self, camera, tile, params, world):
+        n = C.c_uint64(0)
+        check(self.lib.tbrm_count_nominal_samples(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world), C.byref(n)))
+        return int(n.value)
+
+    def download_light_volume(self):
+        out = np.empty(self.light_dims[::-1], dtype=self.light_dtype)
+        check(self.lib.tbrm_download_light_volume(self.handle, out.ctypes.data, out.nbytes))
+        return out
+
+    def upload_light_volume(self, lv):
+        lv = np.ascontiguousarray(lv, dtype=self.light_dtype)
+        assert lv.shape == self.light_dims[::-1]
+        check(self.lib.tbrm_upload_light_volume(self.handle, lv.ctypes.data, lv.nbytes))
+
+    def light_volume_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.tbrm_light_volume_device_ptr(self.handle, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def flush(self):
+        check(self.lib.tbrm_flush(self.handle))
+
+    def stream(self):
+        s = C.c_void_p()
+        check(self.lib.tbrm_stream(self.handle, C.byref(s)))
+        return s.value
+
+    def last_gpu_time_ms(self, kind):
+        ms = C.c_float(0)
+        check(self.lib.tbrm_last_gpu_time_ms(self.handle, int(kind), C.byref(ms)))
+        return float(ms.value)

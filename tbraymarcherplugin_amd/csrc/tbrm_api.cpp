@@ -1,0 +1,653 @@
+// tbrm_api.cpp — the C-ABI of include/tbrm.h over the gfx950 kernels.
+//
+// Plays the role of the reference's game-thread operator library + render-thread drivers:
+//   URaymarchUtils::AddDirLightToSingleVolume / ChangeDirLightInSingleVolume / ClearResourceLightVolumes
+//       Source/Raymarcher/Private/Util/RaymarchUtils.cpp:35-111
+//   AddDirLightToSingleLightVolume_RenderThread / ChangeDirLightInSingleLightVolume_RenderThread
+//       Source/Raymarcher/Private/Rendering/LightingShaders.cpp:35-326
+//   ARaymarchVolume::InitializeRaymarchResources / FreeRaymarchResources
+//       Source/Raymarcher/Private/Actor/RaymarchVolume.cpp:821-949
+// Every call enqueues on the handle's HIP stream (FIFO, like ENQUEUE_RENDER_COMMAND) and returns; parameter
+// structs are copied at call time (the reference captures them by value, RaymarchUtils.cpp:63-66).
+// There is no CPU path: without a HIP device every data call fails with TBRM_ERR_NO_DEVICE.
+#include "../../include/tbrm.h"
+#include "tbrm_host_math.h"
+#include "tbrm_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace tbrm;
+
+namespace {
+
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        const hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? TBRM_ERR_OUT_OF_MEMORY : TBRM_ERR_NO_DEVICE, "%s failed: %s", \
+                #expr, hipGetErrorString(e_));                                                                \
+    } while (0)
+
+size_t format_bytes(int fmt) { return fmt == TBRM_FMT_G8 ? 1 : (fmt == TBRM_FMT_G16 ? 2 : 4); }
+
+} // namespace
+
+struct tbrm_resources {
+    tbrm_resources_desc desc{};
+    int32_t lv_dims[3]{};
+    int lv_fmt = FMT_U8;
+    hipStream_t stream = nullptr;
+
+    void* d_data = nullptr;
+    size_t data_bytes = 0;
+    bool has_volume = false;
+
+    float4* d_tf = nullptr;
+    float tf_host[1024]{};
+    bool has_tf = false;
+
+    tbrm_windowing_params win{0.5f, 1.0f, 1, 1};
+
+    void* d_light = nullptr;
+    size_t light_bytes = 0;
+    void* d_buf[3][4]{};
+
+    // empty-space-skipping metadata
+    int bn[3]{};
+    float2* d_minmax = nullptr;
+    uint32_t* d_empty = nullptr;
+    int* d_alpha_prefix = nullptr;
+    bool minmax_valid = false, empty_valid = false;
+
+    unsigned long long* d_counter = nullptr;
+    float* d_out = nullptr; // staging for the host-pointer raymarch variant
+    size_t out_bytes = 0;
+
+    hipEvent_t ev[2][2]{};
+    bool ev_valid[2]{};
+};
+
+namespace {
+
+int bind(const tbrm_resources* r)
+{
+    HIP_TRY(hipSetDevice(r->desc.device));
+    return TBRM_OK;
+}
+
+bool initialized(const tbrm_resources* r) { return r && r->has_volume && r->has_tf && r->d_light; }
+
+VolumeDev data_view(const tbrm_resources* r)
+{
+    return VolumeDev{r->d_data, r->desc.dim_x, r->desc.dim_y, r->desc.dim_z, r->desc.data_format};
+}
+WindowDev window_dev(const tbrm_resources* r)
+{
+    return WindowDev{r->win.center, r->win.width, r->win.low_cutoff ? 1.0f : 0.0f, r->win.high_cutoff ? 1.0f : 0.0f};
+}
+
+// The clip plane is inert for the propagation when every sample position (uvw + UVWOffset, inside
+// [-1/min(res), 1+1/min(res)]^3) sits >= 2 light-volume voxels on the kept side: AlphaWeight then clamps to
+// exactly 1 (AddDirLightShader.usf:105). Requires a unit direction (a zero direction gives weight 0.5).
+int propagation_clip_mode(const float cc[3], const float cd[3], const int32_t lv[3])
+{
+    const double n2 = (double) cd[0] * cd[0] + (double) cd[1] * cd[1] + (double) cd[2] * cd[2];
+    if (!(n2 > 0.98 && n2 < 1.02)) return 1;
+    const int rmin = std::min({lv[0], lv[1], lv[2]});
+    const double pad = 1.0 / (double) rmin + 0.01;
+    const double dmin = host_min_plane_distance(cc, cd, -pad, 1.0 + pad);
+    return (dmin * (double) rmin >= 2.0) ? 0 : 1;
+}
+// Raymarch positions stay within one step of the unit cube; IsCurPosClipped is never true when the whole
+// box [-1,2]^3 is strictly on the kept side.
+int raymarch_clip_mode(const float cc[3], const float cd[3])
+{
+    const double dmin = host_min_plane_distance(cc, cd, -1.0, 2.0);
+    return (dmin > 1e-3) ? 0 : 1;
+}
+
+void fill_stream(PropStream& s, const tbrm_light_pass& p)
+{
+    s.border_light = p.border_light;
+    s.off_u = p.prev_pixel_offset[0];
+    s.off_v = p.prev_pixel_offset[1];
+    s.uvw_off[0] = p.uvw_offset[0];
+    s.uvw_off[1] = p.uvw_offset[1];
+    s.uvw_off[2] = p.uvw_offset[2];
+    s.step100 = p.step_size * 100.0f; // StepSize * VOLUME_DENSITY (AddDirLightShader.usf:112)
+}
+
+PropParams base_prop_params(const tbrm_resources* r, const tbrm_world_params& world)
+{
+    PropParams p{};
+    p.data = data_view(r);
+    p.data_border = host_data_border(r->win, r->desc.border_mode);
+    p.tf = r->d_tf;
+    p.win = window_dev(r);
+    p.light = r->d_light;
+    for (int c = 0; c < 3; ++c) p.lv_dims[c] = r->lv_dims[c];
+    p.lv_fmt = r->lv_fmt;
+    host_local_clipping(world, p.cc, p.cd);
+    p.clip_mode = propagation_clip_mode(p.cc, p.cd, r->lv_dims);
+    return p;
+}
+
+int begin_timed(tbrm_resources* r, int kind)
+{
+    HIP_TRY(hipEventRecord(r->ev[kind][0], r->stream));
+    return TBRM_OK;
+}
+int end_timed(tbrm_resources* r, int kind)
+{
+    HIP_TRY(hipEventRecord(r->ev[kind][1], r->stream));
+    r->ev_valid[kind] = true;
+    return TBRM_OK;
+}
+
+// AddDirLightToSingleLightVolume_RenderThread (LightingShaders.cpp:35-166)
+int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world)
+{
+    tbrm_light_pass passes[2];
+    int n = 0;
+    if (!host_light_passes(light, world, r->lv_dims, r->desc.border_mode, passes, &n)) return TBRM_OK;
+    PropParams p = base_prop_params(r, world);
+    p.b_added = added ? 1.0f : -1.0f;
+    for (int i = 0; i < n; ++i) { // clear the two buffers of each axis first (:62-80)
+        const tbrm_light_pass& lp = passes[i];
+        const size_t npx = (size_t) lp.td[0] * lp.td[1];
+        HIP_TRY(launch_fill(r->d_buf[lp.axis][0], r->lv_fmt, npx, lp.light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[lp.axis][1], r->lv_fmt, npx, lp.light_alpha, r->stream));
+    }
+    for (int i = 0; i < n; ++i) {
+        const tbrm_light_pass& lp = passes[i];
+        p.axis = lp.axis;
+        for (int c = 0; c < 3; ++c) p.td[c] = lp.td[c];
+        fill_stream(p.a, lp);
+        for (int j = lp.start; j != lp.stop; j += lp.dir) { // :132-158
+            p.loop = j;
+            const int rd = (j % 2 == 0) ? 0 : 1;
+            p.a.read = r->d_buf[lp.axis][rd];
+            p.a.write = r->d_buf[lp.axis][1 - rd];
+            HIP_TRY(launch_propagate_slice(p, false, r->stream));
+        }
+    }
+    return TBRM_OK;
+}
+
+// ChangeDirLightInSingleLightVolume_RenderThread (LightingShaders.cpp:168-326)
+int enqueue_change(tbrm_resources* r, const tbrm_dir_light_params& removed, const tbrm_dir_light_params& added_light,
+                   const tbrm_world_params& world)
+{
+    tbrm_light_pass rp[2], ap[2];
+    int rn = 0, an = 0;
+    const bool r_ok = host_light_passes(removed, world, r->lv_dims, r->desc.border_mode, rp, &rn);
+    const bool a_ok = host_light_passes(added_light, world, r->lv_dims, r->desc.border_mode, ap, &an);
+    if (!r_ok || !a_ok) return TBRM_OK; // :173-179
+    if (rp[0].face != ap[0].face || rp[1].face != ap[1].face) { // :192-198
+        const int e = enqueue_add(r, removed, false, world);
+        if (e != TBRM_OK) return e;
+        return enqueue_add(r, added_light, true, world);
+    }
+    PropParams p = base_prop_params(r, world);
+    for (int i = 0; i < 2; ++i) { // :203-223
+        const size_t npx = (size_t) rp[i].td[0] * rp[i].td[1];
+        const int ax = rp[i].axis;
+        HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, rp[i].light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, rp[i].light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][2], r->lv_fmt, npx, ap[i].light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][3], r->lv_fmt, npx, ap[i].light_alpha, r->stream));
+    }
+    for (int i = 0; i < 2; ++i) { // no break on weight 0 (:238)
+        // Both streams dark (weight 0 on this axis for old and new light): buffers and borders are 0, every
+        // propagated value is 0*(1-s) = 0 and |0-0| > 1e-3 never holds: the pass cannot touch the light volume.
+        if (rp[i].light_alpha == 0.0f && ap[i].light_alpha == 0.0f && rp[i].border_light == 0.0f && ap[i].border_light == 0.0f)
+            continue;
+        p.axis = rp[i].axis;
+        for (int c = 0; c < 3; ++c) p.td[c] = rp[i].td[c];
+        fill_stream(p.r, rp[i]);
+        fill_stream(p.a, ap[i]);
+        for (int j = rp[i].start; j != rp[i].stop; j += rp[i].dir) { // :289-318
+            p.loop = j;
+            const int e = (j % 2 == 0) ? 0 : 1;
+            p.r.read = r->d_buf[p.axis][e];
+            p.r.write = r->d_buf[p.axis][1 - e];
+            p.a.read = r->d_buf[p.axis][2 + e];
+            p.a.write = r->d_buf[p.axis][3 - e];
+            HIP_TRY(launch_propagate_slice(p, true, r->stream));
+        }
+    }
+    return TBRM_OK;
+}
+
+int ensure_skipping(tbrm_resources* r)
+{
+    const int nb = r->bn[0] * r->bn[1] * r->bn[2];
+    if (!r->minmax_valid) {
+        BrickParams bp{data_view(r), r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP,
+            r->bn[0], r->bn[1], r->bn[2], r->d_minmax};
+        HIP_TRY(launch_brick_minmax(bp, r->stream));
+        r->minmax_valid = true;
+        r->empty_valid = false;
+    }
+    if (!r->empty_valid) {
+        int prefix[257];
+        prefix[0] = 0;
+        for (int i = 0; i < 256; ++i) {
+            const float a = r->tf_host[i * 4 + 3];
+            prefix[i + 1] = prefix[i] + ((a > 0.0f || a != a) ? 1 : 0);
+        }
+        // stream-ordered copy from a stack buffer: stage through a pageable memcpy that completes before return
+        HIP_TRY(hipMemcpyAsync(r->d_alpha_prefix, prefix, sizeof(prefix), hipMemcpyHostToDevice, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        EmptyParams ep{r->d_minmax, nb, window_dev(r), r->d_alpha_prefix, r->d_empty};
+        HIP_TRY(launch_brick_empty(ep, r->stream));
+        r->empty_valid = true;
+    }
+    return TBRM_OK;
+}
+
+int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                     const tbrm_world_params* world, RayParams& p)
+{
+    if (!(rp->steps > 0.0f)) return fail(TBRM_ERR_INVALID_ARG, "steps must be > 0");
+    if (tile->w < 0 || tile->h < 0 || cam->width <= 0 || cam->height <= 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile/camera size");
+    p = RayParams{};
+    p.data = data_view(r);
+    p.data_addr_mode = r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP;
+    p.tf = r->d_tf;
+    p.win = window_dev(r);
+    p.light = r->d_light;
+    for (int c = 0; c < 3; ++c) p.lv_dims[c] = r->lv_dims[c];
+    p.lv_fmt = r->lv_fmt;
+    const tbrm_vec3d* v[4] = {&cam->position, &cam->forward, &cam->right, &cam->up};
+    float* dst[4] = {p.cam_pos, p.fwd, p.right, p.up};
+    for (int k = 0; k < 4; ++k) {
+        dst[k][0] = (float) v[k]->x; dst[k][1] = (float) v[k]->y; dst[k][2] = (float) v[k]->z;
+    }
+    p.thx = (float) cam->tan_half_fov_x;
+    p.thy = (float) cam->tan_half_fov_y;
+    p.width = cam->width;
+    p.height = cam->height;
+    host_world_to_local(world->volume_transform, p.m);
+    host_local_clipping(*world, p.cc, p.cd);
+    p.clip_mode = raymarch_clip_mode(p.cc, p.cd);
+    p.tile_x0 = tile->x0; p.tile_y0 = tile->y0; p.tile_w = tile->w; p.tile_h = tile->h;
+    p.row_group_step = tile->row_group_step > 0 ? tile->row_group_step : 1;
+    p.steps = rp->steps;
+    p.jitter_frame = rp->jitter_frame;
+    p.bnx = r->bn[0]; p.bny = r->bn[1]; p.bnz = r->bn[2];
+    return TBRM_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+const char* tbrm_version(void) { return "tbrm-mi355x 0.1.0 (gfx950)"; }
+const char* tbrm_last_error(void) { return g_error; }
+
+int tbrm_device_count(int* out_count)
+{
+    if (!out_count) return fail(TBRM_ERR_INVALID_ARG, "out_count is null");
+    *out_count = 0;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(TBRM_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+    *out_count = n;
+    return TBRM_OK;
+}
+
+int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
+{
+    if (!desc || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (desc->dim_x <= 0 || desc->dim_y <= 0 || desc->dim_z <= 0) return fail(TBRM_ERR_INVALID_ARG, "volume size must be > 0");
+    if (desc->data_format < TBRM_FMT_G8 || desc->data_format > TBRM_FMT_R32_FLOAT) return fail(TBRM_ERR_INVALID_ARG, "bad data_format");
+    int ndev = 0;
+    const int dc = tbrm_device_count(&ndev);
+    if (dc != TBRM_OK) return dc;
+    if (desc->device < 0 || desc->device >= ndev) return fail(TBRM_ERR_INVALID_ARG, "device %d out of range (%d devices)", desc->device, ndev);
+
+    tbrm_resources* r = new (std::nothrow) tbrm_resources();
+    if (!r) return fail(TBRM_ERR_OUT_OF_MEMORY, "host allocation failed");
+    r->desc = *desc;
+    // RaymarchVolume.cpp:850-861
+    r->lv_dims[0] = desc->light_volume_half_resolution ? (desc->dim_x + 1) / 2 : desc->dim_x;
+    r->lv_dims[1] = desc->light_volume_half_resolution ? (desc->dim_y + 1) / 2 : desc->dim_y;
+    r->lv_dims[2] = desc->light_volume_half_resolution ? (desc->dim_z + 1) / 2 : desc->dim_z;
+    r->lv_fmt = desc->light_volume_32bit ? FMT_F32 : FMT_U8;
+    r->data_bytes = (size_t) desc->dim_x * desc->dim_y * desc->dim_z * format_bytes(desc->data_format);
+    const size_t lv_elem = desc->light_volume_32bit ? 4 : 1;
+    r->light_bytes = (size_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] * lv_elem;
+    for (int c = 0; c < 3; ++c) {
+        const int d = c == 0 ? desc->dim_x : (c == 1 ? desc->dim_y : desc->dim_z);
+        r->bn[c] = (d + kBrick - 1) / kBrick;
+    }
+    const size_t nb = (size_t) r->bn[0] * r->bn[1] * r->bn[2];
+    const size_t nb_pad = (nb + 255) / 256 * 256;
+
+#define CREATE_TRY(expr)                                                                           \
+    do {                                                                                           \
+        const hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                                    \
+            const int code_ = fail(e_ == hipErrorOutOfMemory ? TBRM_ERR_OUT_OF_MEMORY : TBRM_ERR_NO_DEVICE, \
+                "%s failed: %s", #expr, hipGetErrorString(e_));                                    \
+            tbrm_resources_destroy(r);                                                             \
+            return code_;                                                                          \
+        }                                                                                          \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(desc->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc(&r->d_data, r->data_bytes));
+    CREATE_TRY(hipMalloc((void**) &r->d_tf, 256 * sizeof(float4)));
+    CREATE_TRY(hipMalloc(&r->d_light, r->light_bytes));
+    // XYZReadWriteBuffers: 4 buffers per axis in the light volume's format (RaymarchVolume.cpp:864-866,:889-891)
+    const size_t buf_px[3] = {(size_t) r->lv_dims[1] * r->lv_dims[2], (size_t) r->lv_dims[0] * r->lv_dims[2],
+        (size_t) r->lv_dims[0] * r->lv_dims[1]};
+    for (int a = 0; a < 3; ++a)
+        for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc(&r->d_buf[a][k], buf_px[a] * lv_elem));
+    CREATE_TRY(hipMalloc((void**) &r->d_minmax, nb * sizeof(float2)));
+    CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
+    CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**) &r->d_counter, sizeof(unsigned long long)));
+    for (int k = 0; k < 2; ++k)
+        for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));
+    // the light volume render target starts cleared
+    CREATE_TRY(hipMemsetAsync(r->d_light, 0, r->light_bytes, r->stream));
+#undef CREATE_TRY
+    *out = r;
+    return TBRM_OK;
+}
+
+int tbrm_resources_destroy(tbrm_resources* r)
+{
+    if (!r) return TBRM_OK;
+    (void) hipSetDevice(r->desc.device);
+    if (r->stream) (void) hipStreamSynchronize(r->stream);
+    (void) hipFree(r->d_data);
+    (void) hipFree(r->d_tf);
+    (void) hipFree(r->d_light);
+    for (auto& axis : r->d_buf)
+        for (void* b : axis) (void) hipFree(b);
+    (void) hipFree(r->d_minmax);
+    (void) hipFree(r->d_empty);
+    (void) hipFree(r->d_alpha_prefix);
+    (void) hipFree(r->d_counter);
+    (void) hipFree(r->d_out);
+    for (auto& k : r->ev)
+        for (hipEvent_t e : k)
+            if (e) (void) hipEventDestroy(e);
+    if (r->stream) (void) hipStreamDestroy(r->stream);
+    delete r;
+    return TBRM_OK;
+}
+
+int tbrm_resources_light_volume_dims(const tbrm_resources* r, int32_t out_dims[3])
+{
+    if (!r || !out_dims) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    for (int c = 0; c < 3; ++c) out_dims[c] = r->lv_dims[c];
+    return TBRM_OK;
+}
+
+int tbrm_resources_is_initialized(const tbrm_resources* r) { return initialized(r) ? 1 : 0; }
+
+int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_bytes)
+{
+    if (!r || !host_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipMemcpyAsync(r->d_data, host_voxels, n_bytes, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream)); // the caller may free its buffer on return
+    r->has_volume = true;
+    r->minmax_valid = false;
+    return TBRM_OK;
+}
+
+int tbrm_upload_volume_device(tbrm_resources* r, const void* device_voxels, size_t n_bytes)
+{
+    if (!r || !device_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipMemcpyAsync(r->d_data, device_voxels, n_bytes, hipMemcpyDeviceToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    r->has_volume = true;
+    r->minmax_valid = false;
+    return TBRM_OK;
+}
+
+int tbrm_set_tf_lut(tbrm_resources* r, const float* rgba_256x4)
+{
+    if (!r || !rgba_256x4) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (int e = bind(r)) return e;
+    host_bake_tf(rgba_256x4, r->tf_host); // FFloat16 storage (RaymarchUtils.cpp:151-161)
+    HIP_TRY(hipMemcpyAsync(r->d_tf, r->tf_host, sizeof(r->tf_host), hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    r->has_tf = true;
+    r->empty_valid = false;
+    return TBRM_OK;
+}
+
+int tbrm_color_curve_to_lut(const float* key_times[4], const float* key_values[4], const int32_t n_keys[4], float* out)
+{
+    if (!key_times || !key_values || !n_keys || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    for (int c = 0; c < 4; ++c)
+        if (n_keys[c] > 0 && (!key_times[c] || !key_values[c])) return fail(TBRM_ERR_INVALID_ARG, "null key array");
+    host_color_curve_to_lut(key_times, key_values, n_keys, out);
+    return TBRM_OK;
+}
+
+int tbrm_make_default_tf_lut(float* out)
+{
+    if (!out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    host_default_tf_lut(out);
+    return TBRM_OK;
+}
+
+int tbrm_set_windowing(tbrm_resources* r, const tbrm_windowing_params* w)
+{
+    if (!r || !w) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    r->win = *w;
+    r->empty_valid = false;
+    return TBRM_OK;
+}
+
+int tbrm_add_dir_light(tbrm_resources* r, const tbrm_dir_light_params* light, int added, const tbrm_world_params* world,
+                       int* light_added, int gpu_sync)
+{
+    (void) gpu_sync; // accepted and ignored (RaymarchUtils.cpp:51-59)
+    if (light_added) *light_added = 0;
+    if (!r || !light || !world) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function"); // :39-45
+    if (light_added) *light_added = 1;
+    if (int e = bind(r)) return e;
+    if (int e = begin_timed(r, 0)) return e;
+    if (int e = enqueue_add(r, *light, added != 0, *world)) return e;
+    return end_timed(r, 0);
+}
+
+int tbrm_change_dir_light(tbrm_resources* r, const tbrm_dir_light_params* old_light, const tbrm_dir_light_params* new_light,
+                          const tbrm_world_params* world, int* light_added)
+{
+    if (light_added) *light_added = 0;
+    if (!r || !old_light || !new_light || !world) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function"); // :74-80
+    if (light_added) *light_added = 1;
+    if (int e = bind(r)) return e;
+    if (int e = begin_timed(r, 0)) return e;
+    if (int e = enqueue_change(r, *old_light, *new_light, *world)) return e;
+    return end_timed(r, 0);
+}
+
+int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)
+{
+    if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!r->d_light) return TBRM_OK; // RaymarchUtils.cpp:106-109
+    if (int e = bind(r)) return e;
+    if (int e = begin_timed(r, 0)) return e;
+    const size_t n = (size_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2];
+    HIP_TRY(launch_fill(r->d_light, r->lv_fmt, n, clear_value, r->stream));
+    return end_timed(r, 0);
+}
+
+int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                             const tbrm_world_params* world, const float* device_scene_depth, float* device_out_rgba)
+{
+    if (!r || !cam || !tile || !rp || !world || !device_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
+    if (int e = bind(r)) return e;
+    RayParams p;
+    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
+    p.depth = device_scene_depth;
+    p.out = device_out_rgba;
+    if (rp->enable_skipping) {
+        if (int e = ensure_skipping(r)) return e;
+        p.empty_bits = r->d_empty;
+    }
+    if (int e = begin_timed(r, 1)) return e;
+    HIP_TRY(launch_raymarch(p, r->stream));
+    return end_timed(r, 1);
+}
+
+int tbrm_raymarch_lit(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                      const tbrm_world_params* world, float* host_out_rgba)
+{
+    if (!r || !tile || !host_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (tile->w < 0 || tile->h < 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile size");
+    const size_t bytes = (size_t) tile->w * tile->h * 4 * sizeof(float);
+    if (bytes == 0) return TBRM_OK;
+    if (int e = bind(r)) return e;
+    if (bytes > r->out_bytes) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->d_out);
+        r->d_out = nullptr;
+        r->out_bytes = 0;
+        HIP_TRY(hipMalloc((void**) &r->d_out, bytes));
+        r->out_bytes = bytes;
+    }
+    if (int e = tbrm_raymarch_lit_device(r, cam, tile, rp, world, nullptr, r->d_out)) return e;
+    HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
+int tbrm_count_nominal_samples(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                               const tbrm_world_params* world, uint64_t* out_samples)
+{
+    if (!r || !cam || !tile || !rp || !world || !out_samples) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (int e = bind(r)) return e;
+    RayParams p;
+    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
+    p.sample_counter = r->d_counter;
+    HIP_TRY(hipMemsetAsync(r->d_counter, 0, sizeof(unsigned long long), r->stream));
+    HIP_TRY(launch_count_samples(p, r->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, r->d_counter, sizeof(v), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    *out_samples = v;
+    return TBRM_OK;
+}
+
+int tbrm_download_light_volume(tbrm_resources* r, void* host_out, size_t n_bytes)
+{
+    if (!r || !host_out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (n_bytes != r->light_bytes) return fail(TBRM_ERR_INVALID_ARG, "light volume is %zu bytes, got %zu", r->light_bytes, n_bytes);
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipMemcpyAsync(host_out, r->d_light, n_bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
+int tbrm_upload_light_volume(tbrm_resources* r, const void* host_in, size_t n_bytes)
+{
+    if (!r || !host_in) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (n_bytes != r->light_bytes) return fail(TBRM_ERR_INVALID_ARG, "light volume is %zu bytes, got %zu", r->light_bytes, n_bytes);
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipMemcpyAsync(r->d_light, host_in, n_bytes, hipMemcpyHostToDevice, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
+int tbrm_light_volume_device_ptr(tbrm_resources* r, void** out_ptr, size_t* out_bytes)
+{
+    if (!r || !out_ptr) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    *out_ptr = r->d_light;
+    if (out_bytes) *out_bytes = r->light_bytes;
+    return TBRM_OK;
+}
+
+int tbrm_flush(tbrm_resources* r)
+{
+    if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
+int tbrm_stream(tbrm_resources* r, void** out_hip_stream)
+{
+    if (!r || !out_hip_stream) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    *out_hip_stream = (void*) r->stream;
+    return TBRM_OK;
+}
+
+int tbrm_last_gpu_time_ms(tbrm_resources* r, int kind, float* out_ms)
+{
+    if (!r || !out_ms || kind < 0 || kind > 1) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
+    if (!r->ev_valid[kind]) return fail(TBRM_ERR_INVALID_ARG, "no timed call of kind %d yet", kind);
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipEventSynchronize(r->ev[kind][1]));
+    HIP_TRY(hipEventElapsedTime(out_ms, r->ev[kind][0], r->ev[kind][1]));
+    return TBRM_OK;
+}
+
+int tbrm_host_light_passes(const tbrm_dir_light_params* light, const tbrm_world_params* world, const int32_t lv_dims[3],
+                           int border_mode, tbrm_light_pass out[2], int* n_passes)
+{
+    if (!light || !world || !lv_dims || !out || !n_passes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    host_light_passes(*light, *world, lv_dims, border_mode, out, n_passes);
+    return TBRM_OK;
+}
+
+int tbrm_host_local_clipping(const tbrm_world_params* world, float out_center[3], float out_dir[3])
+{
+    if (!world || !out_center || !out_dir) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    host_local_clipping(*world, out_center, out_dir);
+    return TBRM_OK;
+}
+
+float tbrm_host_data_border(const tbrm_windowing_params* w, int border_mode)
+{
+    if (!w) return 0.0f;
+    return host_data_border(*w, border_mode);
+}
+
+int tbrm_host_world_to_local(const tbrm_transform* t, float out_m[12])
+{
+    if (!t || !out_m) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    host_world_to_local(*t, out_m);
+    return TBRM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,113 @@
+// tbrm_device_math.h — gfx950 device-side scalar arithmetic of the raymarch + illumination path.
+//
+// This header IS the "arithmetic spec" of DESIGN.md in code form: fp32, no contraction (the translation
+// unit is compiled with -ffp-contract=off), fused multiply-add only where spelled __builtin_fmaf, IEEE
+// division/sqrt (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt). The CPU oracle restates the
+// same sequence independently; the UNORM8 light volume is compared bit-for-bit against it.
+//
+// Reference functions restated here (paths relative to Source/Raymarcher/Shaders/Private/):
+//   GetTransferFuncPosition / SampleWindowedTransferFunction   WindowedSampling.usf:14-37
+//   IsCurPosClipped / GetUVW                                   RaymarcherCommon.usf:22-43
+//   AccumulateLightEnergy                                      RaymarchMaterialCommon.usf:82-88
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tbrm {
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float lerp_(float a, float b, float f) { return fma_(f, b - a, a); }
+__device__ __forceinline__ float saturate_(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); } // NaN -> 0
+
+// ---- pow(x,y) = exp2(y*log2(x)); polynomial coefficients from tools/gen_pow_coeffs.py -----------------
+// HLSL pow (WindowedSampling.usf:35) has no bit-level definition; v_log_f32/v_exp_f32 are not reproducible
+// on a CPU, so the build defines pow through these two polynomials (max rel. error 2.7e-8 / 5.2e-9 before
+// fp32 rounding).
+__device__ __forceinline__ float log2_poly(float x) // x normal, > 0
+{
+    const uint32_t ix = __float_as_uint(x);
+    int e = (int) (ix >> 23) - 127;
+    float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
+    if (m >= 0x1.6a09e6p+0f) { m = m * 0.5f; e += 1; }
+    const float r = m - 1.0f;
+    float q = 0x1.025a2p-3f;
+    q = fma_(q, r, -0x1.a8cc5cp-3f);
+    q = fma_(q, r, 0x1.b9b11ep-3f);
+    q = fma_(q, r, -0x1.e94f12p-3f);
+    q = fma_(q, r, 0x1.26d41p-2f);
+    q = fma_(q, r, -0x1.715c9cp-2f);
+    q = fma_(q, r, 0x1.ec73d4p-2f);
+    q = fma_(q, r, -0x1.71547p-1f);
+    q = fma_(q, r, 0x1.715476p+0f);
+    return fma_(r, q, (float) e);
+}
+
+__device__ __forceinline__ float exp2_poly(float p)
+{
+    if (!(p >= -150.0f)) return (p != p) ? p : 0.0f;
+    if (p >= 128.0f) return __builtin_inff();
+    const float n = floorf(p + 0.5f);
+    const float g = p - n;
+    float r = 0x1.444004p-13f;
+    r = fma_(r, g, 0x1.5f0896p-10f);
+    r = fma_(r, g, 0x1.3b2a1cp-7f);
+    r = fma_(r, g, 0x1.c6af6cp-5f);
+    r = fma_(r, g, 0x1.ebfbep-3f);
+    r = fma_(r, g, 0x1.62e43p-1f);
+    float v = fma_(g, r, 1.0f);
+    int ni = (int) n;
+    if (ni > 127) { v = v * 2.0f; ni -= 1; }
+    if (ni < -126) { v = v * 0x1p-64f; ni += 64; }
+    return v * __uint_as_float((uint32_t) (ni + 127) << 23);
+}
+
+__device__ __forceinline__ float pow_(float x, float y)
+{
+    if (!(x >= 0x1p-126f)) {
+        if (x != x) return x;
+        return (y > 0.0f) ? 0.0f : ((y == 0.0f) ? 1.0f : __builtin_inff());
+    }
+    if (x == __builtin_inff()) return (y > 0.0f) ? x : ((y == 0.0f) ? 1.0f : 0.0f);
+    return exp2_poly(y * log2_poly(x));
+}
+
+// ---- UNORM conversion (D3D11 functional spec: load c/(2^n-1); store trunc(clamp(x,0,1)*255+0.5), NaN->0)
+__device__ __forceinline__ float decode_u8(uint32_t c) { return (float) c / 255.0f; }
+__device__ __forceinline__ float decode_u16(uint32_t c) { return (float) c / 65535.0f; }
+__device__ __forceinline__ uint32_t encode_u8(float x)
+{
+    if (x != x) return 0;
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    return (uint32_t) (x * 255.0f + 0.5f);
+}
+
+// Texel split of a normalised coordinate: floor/frac of u*N - 0.5 (clamped to +-2^30 so the conversion is defined).
+__device__ __forceinline__ void texel_split(float u, float n, int& i0, float& f)
+{
+    float x = u * n - 0.5f;
+    x = fminf(fmaxf(x, -0x1p30f), 0x1p30f);
+    const float fl = floorf(x);
+    i0 = (int) fl;
+    f = x - fl;
+}
+
+__device__ __forceinline__ int wrap_index(int i, int n)
+{
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+__device__ __forceinline__ int clamp_index(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+// GetTransferFuncPosition (WindowedSampling.usf:14-17)
+__device__ __forceinline__ float tf_position(float value, float center, float width)
+{
+    return (value - center + (width / 2.0f)) / width;
+}
+
+// IsCurPosClipped (RaymarcherCommon.usf:22-25)
+__device__ __forceinline__ bool is_clipped(float px, float py, float pz, const float* cc, const float* cd)
+{
+    return (((px - cc[0]) * cd[0] + (py - cc[1]) * cd[1]) + (pz - cc[2]) * cd[2]) <= 0.0f;
+}
+
+} // namespace tbrm

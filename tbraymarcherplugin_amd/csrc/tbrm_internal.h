@@ -1,0 +1,101 @@
+// tbrm_internal.h — parameter blocks passed by value from the host C-ABI layer (tbrm_api.cpp) to the gfx950
+// kernels (tbrm_kernels.hip). Plain PODs; field meanings follow the reference shader uniforms they replace
+// (AddDirLightShader.usf:15-66, ChangeDirLightShader.usf:15-72, M_Raymarch material parameters).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tbrm {
+
+enum : int { FMT_U8 = 0, FMT_U16 = 1, FMT_F32 = 2 };
+enum : int { ADDR_WRAP = 0, ADDR_CLAMP = 1, ADDR_BORDER = 2 };
+
+constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
+constexpr int kBrickShift = 3;
+
+struct VolumeDev {
+    const void* data;
+    int nx, ny, nz;
+    int fmt;
+};
+
+struct WindowDev { // WindowingParameters float4 (VolumeInfo.h:49-52)
+    float center, width, low_cutoff, high_cutoff;
+};
+
+// One light stream of one axis pass (what LightingShaders.cpp:100-124 computes per axis).
+struct PropStream {
+    float border_light;  // ReadBufferSampler border colour
+    float off_u, off_v;  // PrevPixelOffset
+    float uvw_off[3];    // UVWOffset
+    float step100;       // StepSize * VOLUME_DENSITY
+    const void* read;    // ReadBuffer
+    void* write;         // WriteBuffer
+};
+
+struct PropParams {
+    VolumeDev data;
+    float data_border; // VolumeSampler border colour
+    const float4* tf;  // 256 texels, fp16-rounded values held as fp32
+    WindowDev win;
+    void* light;       // ALightVolume
+    int lv_dims[3];
+    int lv_fmt;        // FMT_U8 or FMT_F32 (buffers share it)
+    float cc[3], cd[3];// LocalClippingCenter / LocalClippingDirection
+    int clip_mode;     // 0: plane provably leaves every sample weight at exactly 1; 1: general
+    int axis;          // 0,1,2: permutation (LightingShaderUtils.cpp:227-249)
+    int td[3];         // TransposedDimensions
+    int loop;          // Loop (slice index along the axis)
+    float b_added;     // +1 / -1 (Add only)
+    PropStream a;      // the added light (Add: the only stream)
+    PropStream r;      // the removed light (Change only)
+};
+
+struct RayParams {
+    VolumeDev data;
+    int data_addr_mode; // ADDR_WRAP / ADDR_CLAMP
+    const float4* tf;
+    WindowDev win;
+    const void* light;
+    int lv_dims[3];
+    int lv_fmt;
+    float cam_pos[3], fwd[3], right[3], up[3];
+    float thx, thy;
+    int width, height;  // full framebuffer
+    float m[12];        // WorldToLocal rows (3x3 + translation)
+    float cc[3], cd[3];
+    int clip_mode;      // 0: clip plane provably never clips a sample position; 1: general
+    int tile_x0, tile_y0, tile_w, tile_h, row_group_step;
+    float steps;
+    int jitter_frame;
+    const float* depth; // may be null
+    float* out;         // tile_w*tile_h*4
+    const uint32_t* empty_bits; // one bit per brick; null when skipping is off
+    int bnx, bny, bnz;  // brick grid
+    unsigned long long* sample_counter; // count kernel only
+};
+
+struct BrickParams {
+    VolumeDev data;
+    int addr_mode;
+    int bnx, bny, bnz;
+    float2* minmax;
+};
+
+struct EmptyParams {
+    const float2* minmax;
+    int n_bricks;
+    WindowDev win;
+    const int* alpha_prefix; // 257 entries: # of TF texels j < i with alpha > 0 (or NaN)
+    uint32_t* bits;
+};
+
+// launchers (tbrm_kernels.hip)
+hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
+hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
+hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
+hipError_t launch_count_samples(const RayParams& p, hipStream_t s);
+hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s);
+hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s);
+
+} // namespace tbrm

@@ -1,0 +1,579 @@
+// tbrm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the raymarch + illumination hot path.
+//
+//   k_propagate_slice  : AddDirLightShader.usf:68-128 / ChangeDirLightShader.usf:74-156, one slice per launch
+//                        (the reference's dispatch structure, LightingShaders.cpp:132-158).
+//   k_raymarch_lit     : PerformRaymarchCubeSetup + PerformWindowedLitRaymarch
+//                        (RaymarchMaterialCommon.usf:23-78, WindowedRaymarchMaterials.usf:21-96).
+//   k_fill             : ClearTextureShader.usf:12-16 / ClearVolumeTextureShader.usf:14-20.
+//   k_brick_minmax/k_brick_empty : empty-space-skipping metadata (no reference counterpart; skipped samples are
+//                        exactly the ones whose corrected opacity is 0, so results are unchanged).
+//
+// Compiled with -ffp-contract=off; see tbrm_device_math.h for the arithmetic contract.
+#include "tbrm_device_math.h"
+#include "tbrm_internal.h"
+
+namespace tbrm {
+
+// ------------------------------------------------------------------------------------------------------------
+// voxel access
+
+template <int FMT>
+__device__ __forceinline__ float load_voxel(const void* p, size_t i)
+{
+    if constexpr (FMT == FMT_U8) return decode_u8(((const uint8_t*) p)[i]);
+    else if constexpr (FMT == FMT_U16) return decode_u16(((const uint16_t*) p)[i]);
+    else return ((const float*) p)[i];
+}
+
+template <int FMT>
+__device__ __forceinline__ void store_voxel(void* p, size_t i, float v)
+{
+    if constexpr (FMT == FMT_U8) ((uint8_t*) p)[i] = (uint8_t) encode_u8(v);
+    else ((float*) p)[i] = v;
+}
+
+__device__ __forceinline__ int wrap_fast(int i, int n)
+{
+    if ((unsigned) i >= (unsigned) n) {
+        i = i < 0 ? i + n : i - n;
+        if ((unsigned) i >= (unsigned) n) i = wrap_index(i, n);
+    }
+    return i;
+}
+
+template <int MODE>
+__device__ __forceinline__ int address(int i, int n)
+{
+    if constexpr (MODE == ADDR_WRAP) return wrap_fast(i, n);
+    else return clamp_index(i, n);
+}
+
+// Trilinear fetch, wrap or clamp addressing (the material samplers).
+template <int FMT, int MODE>
+__device__ __forceinline__ float sample_trilinear(const void* data, int nx, int ny, int nz, int ix, int iy, int iz,
+                                                  float fx, float fy, float fz)
+{
+    const int x0 = address<MODE>(ix, nx), x1 = address<MODE>(ix + 1, nx);
+    const int y0 = address<MODE>(iy, ny), y1 = address<MODE>(iy + 1, ny);
+    const int z0 = address<MODE>(iz, nz), z1 = address<MODE>(iz + 1, nz);
+    const size_t r00 = ((size_t) z0 * ny + y0) * (size_t) nx, r10 = ((size_t) z0 * ny + y1) * (size_t) nx;
+    const size_t r01 = ((size_t) z1 * ny + y0) * (size_t) nx, r11 = ((size_t) z1 * ny + y1) * (size_t) nx;
+    const float t000 = load_voxel<FMT>(data, r00 + x0), t001 = load_voxel<FMT>(data, r00 + x1);
+    const float t010 = load_voxel<FMT>(data, r10 + x0), t011 = load_voxel<FMT>(data, r10 + x1);
+    const float t100 = load_voxel<FMT>(data, r01 + x0), t101 = load_voxel<FMT>(data, r01 + x1);
+    const float t110 = load_voxel<FMT>(data, r11 + x0), t111 = load_voxel<FMT>(data, r11 + x1);
+    const float c00 = lerp_(t000, t001, fx), c10 = lerp_(t010, t011, fx);
+    const float c01 = lerp_(t100, t101, fx), c11 = lerp_(t110, t111, fx);
+    const float c0 = lerp_(c00, c10, fy), c1 = lerp_(c01, c11, fy);
+    return lerp_(c0, c1, fz);
+}
+
+// Trilinear fetch with border addressing (the propagation shaders' VolumeSampler, LightingShaders.h:82-89).
+template <int FMT>
+__device__ __forceinline__ float sample_trilinear_border(const VolumeDev& v, float u, float vv, float w, float border)
+{
+    int ix, iy, iz;
+    float fx, fy, fz;
+    texel_split(u, (float) v.nx, ix, fx);
+    texel_split(vv, (float) v.ny, iy, fy);
+    texel_split(w, (float) v.nz, iz, fz);
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = ix + (k & 1), y = iy + ((k >> 1) & 1), z = iz + (k >> 2);
+        const bool in = (unsigned) x < (unsigned) v.nx && (unsigned) y < (unsigned) v.ny && (unsigned) z < (unsigned) v.nz;
+        t[k] = in ? load_voxel<FMT>(v.data, ((size_t) z * v.ny + y) * (size_t) v.nx + x) : border;
+    }
+    const float c00 = lerp_(t[0], t[1], fx), c10 = lerp_(t[2], t[3], fx);
+    const float c01 = lerp_(t[4], t[5], fx), c11 = lerp_(t[6], t[7], fx);
+    const float c0 = lerp_(c00, c10, fy), c1 = lerp_(c01, c11, fy);
+    return lerp_(c0, c1, fz);
+}
+
+// TF.SampleLevel(clamp-bilinear, (pos, 0.5)) — 1D linear between neighbouring texels of the 256-wide row.
+__device__ __forceinline__ float4 sample_tf(const float4* tf, float pos)
+{
+    int i0;
+    float f;
+    texel_split(pos, 256.0f, i0, f);
+    const int i1 = min(max(i0 + 1, 0), 255);
+    i0 = min(max(i0, 0), 255);
+    const float4 a = tf[i0], b = tf[i1];
+    return make_float4(lerp_(a.x, b.x, f), lerp_(a.y, b.y, f), lerp_(a.z, b.z, f), lerp_(a.w, b.w, f));
+}
+__device__ __forceinline__ float sample_tf_alpha(const float4* tf, float pos)
+{
+    int i0;
+    float f;
+    texel_split(pos, 256.0f, i0, f);
+    const int i1 = min(max(i0 + 1, 0), 255);
+    i0 = min(max(i0, 0), 255);
+    return lerp_(tf[i0].w, tf[i1].w, f);
+}
+
+// SampleWindowedTransferFunction(...).a  (WindowedSampling.usf:20-37)
+__device__ __forceinline__ float windowed_alpha(float value, float step, const float4* tf, const WindowDev& w)
+{
+    const float pos = tf_position(value, w.center, w.width);
+    if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return 0.0f;
+    const float a = saturate_(sample_tf_alpha(tf, pos));
+    return 1.0f - pow_(1.0f - a, step);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fill
+
+template <int FMT>
+__global__ void k_fill(void* dst, size_t n, float value)
+{
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) store_voxel<FMT>(dst, i, value);
+}
+
+hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (fmt == FMT_U8) {
+        // every byte gets the same UNORM8 code -> a plain memset (host replicates encode_u8)
+        float x = value;
+        if (x != x) x = 0.0f;
+        x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+        const int code = (int) (x * 255.0f + 0.5f);
+        return hipMemsetAsync(dst, code, n, s);
+    }
+    const int block = 256;
+    const size_t want = (n + block - 1) / block;
+    const int grid = (int) (want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(k_fill<FMT_F32>, dim3(grid), dim3(block), 0, s, dst, n, value);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// illumination: one slice of one axis pass
+
+// AlphaWeight (AddDirLightShader.usf:87-105)
+__device__ __forceinline__ float clip_alpha_weight(float u, float v, float w, const float* cc, const float* cd, const int* res)
+{
+    const float dist = ((u - cc[0]) * cd[0] + (v - cc[1]) * cd[1]) + (w - cc[2]) * cd[2];
+    const float ipx = u + cd[0] * dist, ipy = v + cd[1] * dist, ipz = w + cd[2] * dist;
+    const float ox = (u - ipx) * (float) (uint32_t) res[0];
+    const float oy = (v - ipy) * (float) (uint32_t) res[1];
+    const float oz = (w - ipz) * (float) (uint32_t) res[2];
+    const float vd = sqrtf((ox * ox + oy * oy) + oz * oz);
+    const float sg = dist > 0.0f ? 1.0f : (dist < 0.0f ? -1.0f : 0.0f);
+    return fminf(fmaxf(0.5f + ((0.57735026919f * vd) * sg), 0.0f), 1.0f);
+}
+
+template <int LFMT>
+__device__ __forceinline__ float sample_buffer_bilinear(const void* buf, int w, int h, float u, float v, float border)
+{
+    int ix, iy;
+    float fx, fy;
+    texel_split(u, (float) w, ix, fx);
+    texel_split(v, (float) h, iy, fy);
+    float t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = ix + (k & 1), y = iy + (k >> 1);
+        const bool in = (unsigned) x < (unsigned) w && (unsigned) y < (unsigned) h;
+        t[k] = in ? load_voxel<LFMT>(buf, (size_t) y * w + x) : border;
+    }
+    return lerp_(lerp_(t[0], t[1], fx), lerp_(t[2], t[3], fx), fy);
+}
+
+template <int DFMT, int LFMT, bool GUARD>
+__device__ __forceinline__ float propagate_stream(const PropParams& p, const PropStream& s, int px, int py, const int* pos)
+{
+    const float pu = (((float) (uint32_t) px + 0.5f) / (float) p.td[0]) + s.off_u;
+    const float pv = (((float) (uint32_t) py + 0.5f) / (float) p.td[1]) + s.off_v;
+    const float prev = sample_buffer_bilinear<LFMT>(s.read, p.td[0], p.td[1], pu, pv, s.border_light);
+
+    const float u = (((float) (uint32_t) pos[0] + 0.5f) / (float) (uint32_t) p.lv_dims[0]) + s.uvw_off[0];
+    const float v = (((float) (uint32_t) pos[1] + 0.5f) / (float) (uint32_t) p.lv_dims[1]) + s.uvw_off[1];
+    const float w = (((float) (uint32_t) pos[2] + 0.5f) / (float) (uint32_t) p.lv_dims[2]) + s.uvw_off[2];
+
+    const float aw = p.clip_mode ? clip_alpha_weight(u, v, w, p.cc, p.cd, p.lv_dims) : 1.0f;
+    float cur = 0.0f;
+    bool inside = true;
+    if constexpr (GUARD) inside = (u == saturate_(u)) && (v == saturate_(v)) && (w == saturate_(w));
+    if (aw > 0.0f && inside) {
+        const float val = sample_trilinear_border<DFMT>(p.data, u, v, w, p.data_border);
+        cur = windowed_alpha(val, s.step100, p.tf, p.win) * aw;
+    }
+    return prev * (1 - cur);
+}
+
+template <int DFMT, int LFMT, bool CHANGE>
+__global__ __launch_bounds__(256) void k_propagate_slice(const PropParams p)
+{
+    const int px = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (px >= p.td[0] || py >= p.td[1]) return; // D3D drops the overhanging threads' writes
+    int pos[3];
+    if (p.axis == 0) { pos[0] = p.loop; pos[1] = px; pos[2] = py; }
+    else if (p.axis == 1) { pos[0] = px; pos[1] = p.loop; pos[2] = py; }
+    else { pos[0] = px; pos[1] = py; pos[2] = p.loop; }
+    const size_t bi = (size_t) py * p.td[0] + px;
+    const size_t li = ((size_t) pos[2] * p.lv_dims[1] + pos[1]) * (size_t) p.lv_dims[0] + pos[0];
+    if constexpr (!CHANGE) {
+        const float l = propagate_stream<DFMT, LFMT, true>(p, p.a, px, py, pos);
+        store_voxel<LFMT>(p.a.write, bi, l);
+        if (fabsf(l) > 1e-3f) store_voxel<LFMT>(p.light, li, load_voxel<LFMT>(p.light, li) + (l * p.b_added));
+    } else {
+        const float lr = propagate_stream<DFMT, LFMT, false>(p, p.r, px, py, pos);
+        const float la = propagate_stream<DFMT, LFMT, false>(p, p.a, px, py, pos);
+        store_voxel<LFMT>(p.r.write, bi, lr);
+        store_voxel<LFMT>(p.a.write, bi, la);
+        if (fabsf(la - lr) > 1e-3f) store_voxel<LFMT>(p.light, li, load_voxel<LFMT>(p.light, li) + la - lr);
+    }
+}
+
+template <int DFMT, int LFMT>
+static hipError_t launch_prop2(const PropParams& p, bool change, hipStream_t s)
+{
+    const dim3 grid((p.td[0] + 15) / 16, (p.td[1] + 15) / 16), block(256);
+    if (change) hipLaunchKernelGGL((k_propagate_slice<DFMT, LFMT, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_propagate_slice<DFMT, LFMT, false>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+template <int DFMT>
+static hipError_t launch_prop1(const PropParams& p, bool change, hipStream_t s)
+{
+    return p.lv_fmt == FMT_U8 ? launch_prop2<DFMT, FMT_U8>(p, change, s) : launch_prop2<DFMT, FMT_F32>(p, change, s);
+}
+hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s)
+{
+    switch (p.data.fmt) {
+        case FMT_U8: return launch_prop1<FMT_U8>(p, change, s);
+        case FMT_U16: return launch_prop1<FMT_U16>(p, change, s);
+        default: return launch_prop1<FMT_F32>(p, change, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// raymarch
+
+__device__ __forceinline__ void rand3d_pcg16(int px, int py, int pz, uint32_t& ox)
+{
+    uint32_t x = (uint32_t) px, y = (uint32_t) py, z = (uint32_t) pz;
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    x += y * z; y += z * x; z += x * y;
+    x += y * z; y += z * x; z += x * y;
+    ox = x >> 16;
+}
+
+struct Ray {
+    float pos[3];
+    float lcv[3];
+    float thickness;
+};
+
+__device__ __forceinline__ void normalize3(float* v)
+{
+    const float l = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    v[0] = v[0] / l; v[1] = v[1] / l; v[2] = v[2] / l;
+}
+
+// PerformRaymarchCubeSetup (RaymarchMaterialCommon.usf:23-69) for framebuffer pixel (px,py).
+__device__ __forceinline__ void cube_setup(const RayParams& p, int px, int py, Ray& ray)
+{
+    const float sx = (((2.0f * ((float) px + 0.5f)) / (float) p.width) - 1.0f) * p.thx;
+    const float sy = (1.0f - ((2.0f * ((float) py + 0.5f)) / (float) p.height)) * p.thy;
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = (p.fwd[c] + p.right[c] * sx) + p.up[c] * sy;
+    normalize3(d);
+    const float camvec[3] = {-d[0], -d[1], -d[2]};
+    float lcp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lcp[c] = ((p.cam_pos[0] * p.m[0 + c] + p.cam_pos[1] * p.m[3 + c]) + p.cam_pos[2] * p.m[6 + c]) + p.m[9 + c];
+        ray.lcv[c] = (camvec[0] * p.m[0 + c] + camvec[1] * p.m[3 + c]) + camvec[2] * p.m[6 + c];
+    }
+    normalize3(ray.lcv);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        ray.lcv[c] = -ray.lcv[c];
+        lcp[c] = lcp[c] + 0.5f;
+    }
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { // RayAABBIntersection (RaymarcherCommon.usf:66-88), box [0,1]^3
+        const float inv = 1.0f / ray.lcv[c];
+        const float tmin = (0.0f - lcp[c]) * inv, tmax = (1.0f - lcp[c]) * inv;
+        const float lo = fminf(tmax, tmin), hi = fmaxf(tmax, tmin);
+        if (c == 0) { t0 = lo; t1 = hi; }
+        else { t0 = fmaxf(t0, lo); t1 = fminf(t1, hi); }
+    }
+    t0 = fmaxf(0.0f, t0);
+    if (p.depth) {
+        float nv[3] = {camvec[0], camvec[1], camvec[2]};
+        normalize3(nv);
+        const float depth = p.depth[(size_t) py * p.width + px];
+        const float wdv[3] = {nv[0] * depth, nv[1] * depth, nv[2] * depth};
+        float ldv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ldv[c] = (wdv[0] * p.m[0 + c] + wdv[1] * p.m[3 + c]) + wdv[2] * p.m[6 + c];
+        float lsd = sqrtf((ldv[0] * ldv[0] + ldv[1] * ldv[1]) + ldv[2] * ldv[2]);
+        lsd = lsd / fabsf((p.fwd[0] * camvec[0] + p.fwd[1] * camvec[1]) + p.fwd[2] * camvec[2]);
+        t1 = fminf(lsd, t1);
+    }
+    ray.thickness = fmaxf(0.0f, t1 - t0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ray.pos[c] = lcp[c] + (t0 * ray.lcv[c]);
+}
+
+__device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, int& px, int& py)
+{
+    // 16x16 pixel block per workgroup, one 8x8 sub-tile per wave64 (coherent rays per wave)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    j = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    px = p.tile_x0 + i;
+    py = p.tile_y0 + (j >> 3) * 8 * p.row_group_step + (j & 7);
+    return i < p.tile_w && j < p.tile_h;
+}
+
+template <int DFMT, int LFMT, int DMODE>
+__global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
+{
+    __shared__ float4 s_tf[256];
+    s_tf[threadIdx.x] = p.tf[threadIdx.x];
+    __syncthreads();
+
+    int i, j, px, py;
+    const bool valid = tile_pixel(p, i, j, px, py);
+    if (!valid) return;
+
+    Ray ray;
+    cube_setup(p, px, py, ray);
+
+    // PerformWindowedLitRaymarch (WindowedRaymarchMaterials.usf:36-96)
+    const float step_size = 1 / p.steps;
+    const float actual = p.steps * ray.thickness;
+    const float fl = floorf(actual);
+    const int max_steps = (int) fl;
+    const float final_step = actual - fl;
+    const float sv0 = ray.lcv[0] * step_size, sv1 = ray.lcv[1] * step_size, sv2 = ray.lcv[2] * step_size;
+    const float step_world = 100.0f * step_size;
+    float pos0 = ray.pos[0], pos1 = ray.pos[1], pos2 = ray.pos[2];
+    if (p.jitter_frame >= 0) { // JitterEntryPos (RaymarchMaterialCommon.usf:73-78)
+        uint32_t r;
+        rand3d_pcg16(px, py, p.jitter_frame & 7, r);
+        const float rnd = (float) r / 65535.0f;
+        pos0 = pos0 - (sv0 * rnd); pos1 = pos1 - (sv1 * rnd); pos2 = pos2 - (sv2 * rnd);
+    }
+
+    const float nx = (float) p.data.nx, ny = (float) p.data.ny, nz = (float) p.data.nz;
+    const float lnx = (float) p.lv_dims[0], lny = (float) p.lv_dims[1], lnz = (float) p.lv_dims[2];
+    float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f;
+    int cached_brick = -1;
+    bool cached_empty = false;
+
+    // one sample; returns true when the early-exit threshold was crossed
+    auto sample = [&](float step) -> bool {
+        int ix, iy, iz;
+        float fx, fy, fz;
+        texel_split(pos0, nx, ix, fx);
+        texel_split(pos1, ny, iy, fy);
+        texel_split(pos2, nz, iz, fz);
+        if (p.empty_bits) {
+            const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
+            const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
+            const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
+            const int b = (bz * p.bny + by) * p.bnx + bx;
+            if (b != cached_brick) {
+                cached_brick = b;
+                cached_empty = (p.empty_bits[b >> 5] >> (b & 31)) & 1u;
+            }
+            if (cached_empty) return false; // every tap of this sample maps to opacity 0: exact no-op
+        }
+        const float v = sample_trilinear<DFMT, DMODE>(p.data.data, p.data.nx, p.data.ny, p.data.nz, ix, iy, iz, fx, fy, fz);
+        // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
+        const float tpos = tf_position(v, p.win.center, p.win.width);
+        if ((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f)) return false;
+        float4 cs = sample_tf(s_tf, tpos);
+        const float a_sat = saturate_(cs.w);
+        if (a_sat == 0.0f) return false; // 1 - pow(1, s) = 0: the sample contributes exactly nothing
+        const float a = 1.0f - pow_(1.0f - a_sat, step);
+        // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
+        int lx, ly, lz;
+        float gx, gy, gz;
+        texel_split(saturate_(pos0), lnx, lx, gx);
+        texel_split(saturate_(pos1), lny, ly, gy);
+        texel_split(saturate_(pos2), lnz, lz, gz);
+        const float l = sample_trilinear<LFMT, ADDR_WRAP>(p.light, p.lv_dims[0], p.lv_dims[1], p.lv_dims[2], lx, ly, lz, gx, gy, gz);
+        cs.x = cs.x * l; cs.y = cs.y * l; cs.z = cs.z * l;
+        // AccumulateLightEnergy (RaymarchMaterialCommon.usf:82-88)
+        const float om = 1.0f - le3;
+        le0 = le0 + ((cs.x * a) * om);
+        le1 = le1 + ((cs.y * a) * om);
+        le2 = le2 + ((cs.z * a) * om);
+        le3 = le3 + (a * om);
+        return le3 > 0.95f;
+    };
+
+    int k = 0;
+    for (k = 0; k < max_steps; k++) {
+        pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2;
+        if (p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd)) continue;
+        if (sample(step_world)) { le3 = 1.0f; break; }
+    }
+    if (k == max_steps && final_step > 0.0f) {
+        pos0 = pos0 + (sv0 * final_step); pos1 = pos1 + (sv1 * final_step); pos2 = pos2 + (sv2 * final_step);
+        if (!(p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd))) sample(100.0f * final_step);
+    }
+    reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
+}
+
+template <int DFMT, int LFMT>
+static hipError_t launch_ray2(const RayParams& p, hipStream_t s)
+{
+    const dim3 grid((p.tile_w + 15) / 16, (p.tile_h + 15) / 16), block(256);
+    if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+template <int DFMT>
+static hipError_t launch_ray1(const RayParams& p, hipStream_t s)
+{
+    return p.lv_fmt == FMT_U8 ? launch_ray2<DFMT, FMT_U8>(p, s) : launch_ray2<DFMT, FMT_F32>(p, s);
+}
+hipError_t launch_raymarch(const RayParams& p, hipStream_t s)
+{
+    if (p.tile_w <= 0 || p.tile_h <= 0) return hipSuccess;
+    switch (p.data.fmt) {
+        case FMT_U8: return launch_ray1<FMT_U8>(p, s);
+        case FMT_U16: return launch_ray1<FMT_U16>(p, s);
+        default: return launch_ray1<FMT_F32>(p, s);
+    }
+}
+
+// Nominal samples: sum over rays of floor(Steps*thickness) + [frac > 0].
+__global__ __launch_bounds__(256) void k_count_samples(const RayParams p)
+{
+    int i, j, px, py;
+    const bool valid = tile_pixel(p, i, j, px, py);
+    unsigned long long n = 0;
+    if (valid) {
+        Ray ray;
+        cube_setup(p, px, py, ray);
+        const float actual = p.steps * ray.thickness;
+        const float fl = floorf(actual);
+        n = (unsigned long long) (int) fl + ((actual - fl) > 0.0f ? 1ull : 0ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(p.sample_counter, n);
+}
+
+hipError_t launch_count_samples(const RayParams& p, hipStream_t s)
+{
+    if (p.tile_w <= 0 || p.tile_h <= 0) return hipSuccess;
+    const dim3 grid((p.tile_w + 15) / 16, (p.tile_h + 15) / 16), block(256);
+    hipLaunchKernelGGL(k_count_samples, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// empty-space-skipping metadata
+
+// Per brick b: min/max of every voxel a sample whose base tap lies in b can touch: [8b, 8b+8] per axis,
+// addressed like the raymarch sampler. NaN voxels poison the range to [-inf, +inf] (never skipped).
+template <int FMT, int MODE>
+__global__ __launch_bounds__(64) void k_brick_minmax(const BrickParams p)
+{
+    const int b = blockIdx.x;
+    const int bx = b % p.bnx, by = (b / p.bnx) % p.bny, bz = b / (p.bnx * p.bny);
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    bool nan = false;
+    for (int t = threadIdx.x; t < 9 * 9 * 9; t += 64) {
+        const int dx = t % 9, dy = (t / 9) % 9, dz = t / 81;
+        int x = bx * kBrick + dx, y = by * kBrick + dy, z = bz * kBrick + dz;
+        // the +8 tap only exists as the "+1" neighbour of an in-range base tap
+        if (x > p.data.nx || y > p.data.ny || z > p.data.nz) continue;
+        x = address<MODE>(x, p.data.nx);
+        y = address<MODE>(y, p.data.ny);
+        z = address<MODE>(z, p.data.nz);
+        const float v = load_voxel<FMT>(p.data.data, ((size_t) z * p.data.ny + y) * (size_t) p.data.nx + x);
+        if (v != v) nan = true;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, o, 64));
+        mx = fmaxf(mx, __shfl_down(mx, o, 64));
+        nan = nan || __shfl_down((int) nan, o, 64);
+    }
+    if (threadIdx.x == 0) p.minmax[b] = nan ? make_float2(-__builtin_inff(), __builtin_inff()) : make_float2(mn, mx);
+}
+
+hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s)
+{
+    const int n = p.bnx * p.bny * p.bnz;
+    if (n == 0) return hipSuccess;
+#define TBRM_BM(F, M) hipLaunchKernelGGL((k_brick_minmax<F, M>), dim3(n), dim3(64), 0, s, p)
+    const bool clamp = p.addr_mode == ADDR_CLAMP;
+    switch (p.data.fmt) {
+        case FMT_U8: if (clamp) TBRM_BM(FMT_U8, ADDR_CLAMP); else TBRM_BM(FMT_U8, ADDR_WRAP); break;
+        case FMT_U16: if (clamp) TBRM_BM(FMT_U16, ADDR_CLAMP); else TBRM_BM(FMT_U16, ADDR_WRAP); break;
+        default: if (clamp) TBRM_BM(FMT_F32, ADDR_CLAMP); else TBRM_BM(FMT_F32, ADDR_WRAP); break;
+    }
+#undef TBRM_BM
+    return hipGetLastError();
+}
+
+// A brick is empty when every value in [min,max] maps to corrected opacity 0: the TF position is monotone in
+// the value (width > 0), so it suffices that the part of [pos(min), pos(max)] that survives the cutoffs only
+// touches TF texels with alpha <= 0.
+__global__ __launch_bounds__(256) void k_brick_empty(const EmptyParams p)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    bool empty = false;
+    if (b < p.n_bricks) {
+        const float2 mm = p.minmax[b];
+        if (p.win.width > 0.0f && mm.x <= mm.y && mm.x > -__builtin_inff() && mm.y < __builtin_inff()) {
+            float lo = tf_position(mm.x, p.win.center, p.win.width);
+            float hi = tf_position(mm.y, p.win.center, p.win.width);
+            if (lo == lo && hi == hi) {
+                bool all_cut = false;
+                if (p.win.low_cutoff > 0.0f) {
+                    if (hi < 0.0f) all_cut = true;
+                    lo = fmaxf(lo, 0.0f);
+                }
+                if (p.win.high_cutoff > 0.0f) {
+                    if (lo > 1.0f) all_cut = true;
+                    hi = fminf(hi, 1.0f);
+                }
+                if (all_cut) empty = true;
+                else {
+                    int i_lo, i_hi;
+                    float f;
+                    texel_split(lo, 256.0f, i_lo, f);
+                    texel_split(hi, 256.0f, i_hi, f);
+                    i_lo = min(max(i_lo, 0), 255);
+                    i_hi = min(max(i_hi + 1, 0), 255);
+                    empty = (p.alpha_prefix[i_hi + 1] - p.alpha_prefix[i_lo]) == 0;
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(empty);
+    const int lane = threadIdx.x & 63;
+    if (b < p.n_bricks || true) {
+        if (lane == 0) p.bits[(blockIdx.x * 256 + threadIdx.x) >> 5] = (uint32_t) m;
+        if (lane == 32) p.bits[(blockIdx.x * 256 + threadIdx.x) >> 5] = (uint32_t) (m >> 32);
+    }
+}
+
+hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s)
+{
+    if (p.n_bricks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_brick_empty, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+} // namespace tbrm
