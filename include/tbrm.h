@@ -230,7 +230,12 @@ TBRM_API int tbrm_count_nominal_samples(tbrm_resources* res, const tbrm_camera* 
 /* readback / sync / interop                                                                          */
 TBRM_API int tbrm_download_light_volume(tbrm_resources* res, void* host_out, size_t n_bytes);
 TBRM_API int tbrm_upload_light_volume(tbrm_resources* res, const void* host_in, size_t n_bytes);
+/* Device address of the light volume in the library's internal 8x8x8-bricked layout (DESIGN.md "Data layout");
+ * meant for element-wise device-side combination across GPUs, not for indexing. */
 TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, size_t* out_bytes);
+/* Kernel launches since creation: out[0] = chunked propagation launches, out[1] = slice-per-launch propagation
+ * launches (fallback path), out[2] = raymarch launches. Lets tests assert which kernel actually ran. */
+TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
 TBRM_API int tbrm_flush(tbrm_resources* res);                 /* FlushRenderingCommands() */
 TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's

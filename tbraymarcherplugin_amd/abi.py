@@ -111,7 +111,7 @@ SYMBOLS = [
     "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
@@ -160,6 +160,7 @@ def load():
     lib.tbrm_download_light_volume.argtypes = [vp, vp, C.c_size_t]
     lib.tbrm_upload_light_volume.argtypes = [vp, vp, C.c_size_t]
     lib.tbrm_light_volume_device_ptr.argtypes = [vp, P(vp), P(C.c_size_t)]
+    lib.tbrm_launch_counters.argtypes = [vp, P(C.c_uint64 * 3)]
     lib.tbrm_flush.argtypes = [vp]
     lib.tbrm_stream.argtypes = [vp, P(vp)]
     lib.tbrm_last_gpu_time_ms.argtypes = [vp, C.c_int, P(C.c_float)]
@@ -336,6 +337,11 @@ class Resources:
         p, n = C.c_void_p(), C.c_size_t()
         check(self.lib.tbrm_light_volume_device_ptr(self.handle, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def launch_counters(self):
+        out = (C.c_uint64 * 3)()
+        check(self.lib.tbrm_launch_counters(self.handle, C.byref(out)))
+        return {"chunk": int(out[0]), "slice": int(out[1]), "raymarch": int(out[2])}
 
     def flush(self):
         check(self.lib.tbrm_flush(self.handle))

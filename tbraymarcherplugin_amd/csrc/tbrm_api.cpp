@@ -20,6 +20,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -68,8 +70,13 @@ struct tbrm_resources {
     tbrm_windowing_params win{0.5f, 1.0f, 1, 1};
 
     void* d_light = nullptr;
-    size_t light_bytes = 0;
-    void* d_buf[3][4]{};
+    size_t light_bytes = 0;        // linear size (what download/upload exchange)
+    size_t light_bricked_bytes = 0;
+    size_t data_bricked_bytes = 0;
+    int dbn[3]{};                  // data volume bricks per axis
+    int lbn[3]{};                  // light volume bricks per axis
+    void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
+    float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
 
     // empty-space-skipping metadata
     int bn[3]{};
@@ -84,6 +91,7 @@ struct tbrm_resources {
 
     hipEvent_t ev[2][2]{};
     bool ev_valid[2]{};
+    uint64_t launches[3]{}; // chunk, slice, raymarch
 };
 
 namespace {
@@ -98,7 +106,7 @@ bool initialized(const tbrm_resources* r) { return r && r->has_volume && r->has_
 
 VolumeDev data_view(const tbrm_resources* r)
 {
-    return VolumeDev{r->d_data, r->desc.dim_x, r->desc.dim_y, r->desc.dim_z, r->desc.data_format};
+    return VolumeDev{r->d_data, r->desc.dim_x, r->desc.dim_y, r->desc.dim_z, r->desc.data_format, r->dbn[0], r->dbn[0] * r->dbn[1]};
 }
 WindowDev window_dev(const tbrm_resources* r)
 {
@@ -145,6 +153,8 @@ PropParams base_prop_params(const tbrm_resources* r, const tbrm_world_params& wo
     p.win = window_dev(r);
     p.light = r->d_light;
     for (int c = 0; c < 3; ++c) p.lv_dims[c] = r->lv_dims[c];
+    p.lv_bnx = r->lbn[0];
+    p.lv_bnxy = r->lbn[0] * r->lbn[1];
     p.lv_fmt = r->lv_fmt;
     host_local_clipping(world, p.cc, p.cd);
     p.clip_mode = propagation_clip_mode(p.cc, p.cd, r->lv_dims);
@@ -163,33 +173,183 @@ int end_timed(tbrm_resources* r, int kind)
     return TBRM_OK;
 }
 
+// ---- chunked propagation (tbrm_light_kernels.hip) --------------------------------------------------------------
+
+bool force_slice_kernel()
+{
+    const char* e = getenv("TBRM_FORCE_SLICE_KERNEL"); // read per call so tests can A/B the two kernels
+    return e && e[0] == '1';
+}
+int chunk_steps_override()
+{
+    const char* e = getenv("TBRM_CHUNK_STEPS");
+    return e ? atoi(e) : 0;
+}
+
+// Range of (tap index - pixel index) of the previous-slice bilinear fetch over one buffer axis, evaluated with the
+// kernel's own fp32 sequence (texel_split of ((c+0.5)/size + offset)); hi includes the +1 tap.
+struct TapRange { int lo = 0, hi = 0; bool ok = false; };
+TapRange prev_tap_range(int size, float off)
+{
+    TapRange t;
+    if (!std::isfinite(off) || size <= 0) return t;
+    t.lo = INT32_MAX; t.hi = INT32_MIN;
+    for (int c = 0; c < size; ++c) {
+        const float u = (((float) (uint32_t) c + 0.5f) / (float) size) + off;
+        float x = u * (float) size - 0.5f;
+        x = std::fmin(std::fmax(x, -0x1p30f), 0x1p30f);
+        const int d = (int) std::floor(x) - c;
+        t.lo = std::min(t.lo, d);
+        t.hi = std::max(t.hi, d + 1);
+    }
+    t.ok = std::abs(t.lo) <= 64 && std::abs(t.hi) <= 64;
+    return t;
+}
+
+inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+inline int ceil_div(int a, int b) { return -floor_div(-a, b); }
+inline int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+float through_light_format(int lv_fmt, float v)
+{
+    if (lv_fmt != FMT_U8) return v;
+    float x = v;
+    if (x != x) return 0.0f;
+    x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+    const uint32_t c = (uint32_t) (x * 255.0f + 0.5f);
+    return (float) c / 255.0f;
+}
+
+void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt)
+{
+    s.border_light = p.border_light;
+    s.off_u = p.prev_pixel_offset[0];
+    s.off_v = p.prev_pixel_offset[1];
+    for (int c = 0; c < 3; ++c) s.uvw_off[c] = p.uvw_offset[c];
+    s.step100 = p.step_size * 100.0f;
+    s.init_value = through_light_format(lv_fmt, p.light_alpha); // Clear2DTexture of the read/write buffers
+}
+
+// Runs one axis pass (Add: stream a only; Change: a = added, r = removed) with the chunk kernel.
+// Returns TBRM_ERR_UNSUPPORTED (nothing enqueued) when the pass has to take the slice-per-launch path.
+int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr,
+                         float b_added)
+{
+    if (force_slice_kernel()) return TBRM_ERR_UNSUPPORTED;
+    const bool change = pr != nullptr;
+    const int W = pa.td[0], H = pa.td[1], D = pa.td[2];
+    TapRange tx = prev_tap_range(W, pa.prev_pixel_offset[0]), ty = prev_tap_range(H, pa.prev_pixel_offset[1]);
+    if (!tx.ok || !ty.ok) return TBRM_ERR_UNSUPPORTED;
+    if (change) {
+        const TapRange rx = prev_tap_range(W, pr->prev_pixel_offset[0]), ry = prev_tap_range(H, pr->prev_pixel_offset[1]);
+        if (!rx.ok || !ry.ok) return TBRM_ERR_UNSUPPORTED;
+        tx.lo = std::min(tx.lo, rx.lo); tx.hi = std::max(tx.hi, rx.hi);
+        ty.lo = std::min(ty.lo, ry.lo); ty.hi = std::max(ty.hi, ry.hi);
+    }
+    const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
+    int M = 0;
+    for (int cand : {16, 8, 4})
+        if (kChunkTile + cand * g <= kChunkMaxHull) { M = cand; break; }
+    if (chunk_steps_override() > 0) M = chunk_steps_override();
+    if (M <= 0) return TBRM_ERR_UNSUPPORTED;
+
+    ChunkParams p{};
+    p.data = base.data;
+    p.data_border = base.data_border;
+    p.tf = base.tf;
+    p.win = base.win;
+    p.light = base.light;
+    for (int c = 0; c < 3; ++c) { p.lv_dims[c] = base.lv_dims[c]; p.cc[c] = base.cc[c]; p.cd[c] = base.cd[c]; }
+    p.lv_bnx = base.lv_bnx; p.lv_bnxy = base.lv_bnxy;
+    p.clip_mode = base.clip_mode;
+    p.axis = pa.axis;
+    p.W = W; p.H = H;
+    p.dir = pa.dir;
+    p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
+    p.cx = clamp_int(0, tx.lo, tx.hi);
+    p.cy = clamp_int(0, ty.lo, ty.hi);
+    p.b_added = b_added;
+    fill_chunk_stream(p.a, pa, r->lv_fmt);
+    if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
+    p.n_steps = std::min(M, D);
+    if (chunk_lds_bytes(p, change) > 150 * 1024) return TBRM_ERR_UNSUPPORTED;
+
+    const int n_chunks = (D + M - 1) / M;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int n = std::min(M, D - c * M);
+        p.n_steps = n;
+        p.j0 = pa.start + c * M * pa.dir;
+        p.first_chunk = c == 0;
+        p.a.plane_in = r->d_plane[c & 1];
+        p.a.plane_out = r->d_plane[(c & 1) ^ 1];
+        p.r.plane_in = r->d_plane[2 + (c & 1)];
+        p.r.plane_out = r->d_plane[2 + ((c & 1) ^ 1)];
+        // tiles whose ownership range [iT + r*cx, (i+1)T + r*cx) meets the plane for some r in [0, n-1]
+        const int sx = (n - 1) * p.cx, sy = (n - 1) * p.cy;
+        p.tile_i0 = floor_div(-std::max(0, sx), kChunkTile);
+        p.tile_j0 = floor_div(-std::max(0, sy), kChunkTile);
+        const int i1 = ceil_div(W - std::min(0, sx), kChunkTile) - 1, j1 = ceil_div(H - std::min(0, sy), kChunkTile) - 1;
+        HIP_TRY(launch_propagate_chunk(p, change, r->lv_fmt, i1 - p.tile_i0 + 1, j1 - p.tile_j0 + 1, r->stream));
+        ++r->launches[0];
+    }
+    return TBRM_OK;
+}
+
+// the reference's structure: one launch per slice (LightingShaders.cpp:132-158 / :289-318)
+int enqueue_pass_sliced(tbrm_resources* r, PropParams p, const tbrm_light_pass& pa, const tbrm_light_pass* pr)
+{
+    const bool change = pr != nullptr;
+    const size_t npx = (size_t) pa.td[0] * pa.td[1];
+    const int ax = pa.axis;
+    if (!change) {
+        HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pa.light_alpha, r->stream));
+    } else {
+        HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pr->light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pr->light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][2], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][3], r->lv_fmt, npx, pa.light_alpha, r->stream));
+    }
+    p.axis = ax;
+    for (int c = 0; c < 3; ++c) p.td[c] = pa.td[c];
+    fill_stream(p.a, pa);
+    if (change) fill_stream(p.r, *pr);
+    for (int j = pa.start; j != pa.stop; j += pa.dir) {
+        p.loop = j;
+        const int e = (j % 2 == 0) ? 0 : 1; // switch read and write buffers each slice
+        if (!change) {
+            p.a.read = r->d_buf[ax][e];
+            p.a.write = r->d_buf[ax][1 - e];
+        } else {
+            p.r.read = r->d_buf[ax][e];
+            p.r.write = r->d_buf[ax][1 - e];
+            p.a.read = r->d_buf[ax][2 + e];
+            p.a.write = r->d_buf[ax][3 - e];
+        }
+        HIP_TRY(launch_propagate_slice(p, change, r->stream));
+        ++r->launches[1];
+    }
+    return TBRM_OK;
+}
+
+int enqueue_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added)
+{
+    const int e = enqueue_pass_chunked(r, base, pa, pr, b_added);
+    if (e != TBRM_ERR_UNSUPPORTED) return e;
+    PropParams p = base;
+    p.b_added = b_added;
+    return enqueue_pass_sliced(r, p, pa, pr);
+}
+
 // AddDirLightToSingleLightVolume_RenderThread (LightingShaders.cpp:35-166)
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world)
 {
     tbrm_light_pass passes[2];
     int n = 0;
-    if (!host_light_passes(light, world, r->lv_dims, r->desc.border_mode, passes, &n)) return TBRM_OK;
-    PropParams p = base_prop_params(r, world);
-    p.b_added = added ? 1.0f : -1.0f;
-    for (int i = 0; i < n; ++i) { // clear the two buffers of each axis first (:62-80)
-        const tbrm_light_pass& lp = passes[i];
-        const size_t npx = (size_t) lp.td[0] * lp.td[1];
-        HIP_TRY(launch_fill(r->d_buf[lp.axis][0], r->lv_fmt, npx, lp.light_alpha, r->stream));
-        HIP_TRY(launch_fill(r->d_buf[lp.axis][1], r->lv_fmt, npx, lp.light_alpha, r->stream));
-    }
-    for (int i = 0; i < n; ++i) {
-        const tbrm_light_pass& lp = passes[i];
-        p.axis = lp.axis;
-        for (int c = 0; c < 3; ++c) p.td[c] = lp.td[c];
-        fill_stream(p.a, lp);
-        for (int j = lp.start; j != lp.stop; j += lp.dir) { // :132-158
-            p.loop = j;
-            const int rd = (j % 2 == 0) ? 0 : 1;
-            p.a.read = r->d_buf[lp.axis][rd];
-            p.a.write = r->d_buf[lp.axis][1 - rd];
-            HIP_TRY(launch_propagate_slice(p, false, r->stream));
-        }
-    }
+    if (!host_light_passes(light, world, r->lv_dims, r->desc.border_mode, passes, &n)) return TBRM_OK; // :41-46
+    const PropParams base = base_prop_params(r, world);
+    for (int i = 0; i < n; ++i) // breaks on weight == 0 (:65,:94)
+        if (int e = enqueue_pass(r, base, passes[i], nullptr, added ? 1.0f : -1.0f)) return e;
     return TBRM_OK;
 }
 
@@ -207,35 +367,20 @@ int enqueue_change(tbrm_resources* r, const tbrm_dir_light_params& removed, cons
         if (e != TBRM_OK) return e;
         return enqueue_add(r, added_light, true, world);
     }
-    PropParams p = base_prop_params(r, world);
-    for (int i = 0; i < 2; ++i) { // :203-223
-        const size_t npx = (size_t) rp[i].td[0] * rp[i].td[1];
-        const int ax = rp[i].axis;
-        HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, rp[i].light_alpha, r->stream));
-        HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, rp[i].light_alpha, r->stream));
-        HIP_TRY(launch_fill(r->d_buf[ax][2], r->lv_fmt, npx, ap[i].light_alpha, r->stream));
-        HIP_TRY(launch_fill(r->d_buf[ax][3], r->lv_fmt, npx, ap[i].light_alpha, r->stream));
-    }
+    const PropParams base = base_prop_params(r, world);
     for (int i = 0; i < 2; ++i) { // no break on weight 0 (:238)
         // Both streams dark (weight 0 on this axis for old and new light): buffers and borders are 0, every
         // propagated value is 0*(1-s) = 0 and |0-0| > 1e-3 never holds: the pass cannot touch the light volume.
         if (rp[i].light_alpha == 0.0f && ap[i].light_alpha == 0.0f && rp[i].border_light == 0.0f && ap[i].border_light == 0.0f)
             continue;
-        p.axis = rp[i].axis;
-        for (int c = 0; c < 3; ++c) p.td[c] = rp[i].td[c];
-        fill_stream(p.r, rp[i]);
-        fill_stream(p.a, ap[i]);
-        for (int j = rp[i].start; j != rp[i].stop; j += rp[i].dir) { // :289-318
-            p.loop = j;
-            const int e = (j % 2 == 0) ? 0 : 1;
-            p.r.read = r->d_buf[p.axis][e];
-            p.r.write = r->d_buf[p.axis][1 - e];
-            p.a.read = r->d_buf[p.axis][2 + e];
-            p.a.write = r->d_buf[p.axis][3 - e];
-            HIP_TRY(launch_propagate_slice(p, true, r->stream));
-        }
+        if (int e = enqueue_pass(r, base, ap[i], &rp[i], 0.0f)) return e;
     }
     return TBRM_OK;
+}
+
+RelayoutParams relayout_params(const void* src, void* dst, const int dims[3], const int bn[3], size_t elem, bool to_bricks)
+{
+    return RelayoutParams{src, dst, dims[0], dims[1], dims[2], bn[0], bn[0] * bn[1], bn[2], (int) elem, to_bricks ? 1 : 0};
 }
 
 int ensure_skipping(tbrm_resources* r)
@@ -277,6 +422,8 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     p.win = window_dev(r);
     p.light = r->d_light;
     for (int c = 0; c < 3; ++c) p.lv_dims[c] = r->lv_dims[c];
+    p.lv_bnx = r->lbn[0];
+    p.lv_bnxy = r->lbn[0] * r->lbn[1];
     p.lv_fmt = r->lv_fmt;
     const tbrm_vec3d* v[4] = {&cam->position, &cam->forward, &cam->right, &cam->up};
     float* dst[4] = {p.cam_pos, p.fwd, p.right, p.up};
@@ -342,8 +489,16 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     r->light_bytes = (size_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] * lv_elem;
     for (int c = 0; c < 3; ++c) {
         const int d = c == 0 ? desc->dim_x : (c == 1 ? desc->dim_y : desc->dim_z);
-        r->bn[c] = (d + kBrick - 1) / kBrick;
+        r->bn[c] = r->dbn[c] = (d + kBrick - 1) / kBrick;
+        r->lbn[c] = (r->lv_dims[c] + kBrick - 1) / kBrick;
     }
+    const size_t data_bricks = (size_t) r->dbn[0] * r->dbn[1] * r->dbn[2], light_bricks = (size_t) r->lbn[0] * r->lbn[1] * r->lbn[2];
+    if (data_bricks * 512 >= (1ull << 32) || light_bricks * 512 >= (1ull << 32)) {
+        delete r;
+        return fail(TBRM_ERR_UNSUPPORTED, "volumes of 2^32 or more (padded) voxels are not supported");
+    }
+    r->data_bricked_bytes = data_bricks * 512 * format_bytes(desc->data_format);
+    r->light_bricked_bytes = light_bricks * 512 * lv_elem;
     const size_t nb = (size_t) r->bn[0] * r->bn[1] * r->bn[2];
     const size_t nb_pad = (nb + 255) / 256 * 256;
 
@@ -360,14 +515,16 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
 
     CREATE_TRY(hipSetDevice(desc->device));
     CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipMalloc(&r->d_data, r->data_bytes));
+    CREATE_TRY(hipMalloc(&r->d_data, r->data_bricked_bytes));
     CREATE_TRY(hipMalloc((void**) &r->d_tf, 256 * sizeof(float4)));
-    CREATE_TRY(hipMalloc(&r->d_light, r->light_bytes));
+    CREATE_TRY(hipMalloc(&r->d_light, r->light_bricked_bytes));
     // XYZReadWriteBuffers: 4 buffers per axis in the light volume's format (RaymarchVolume.cpp:864-866,:889-891)
     const size_t buf_px[3] = {(size_t) r->lv_dims[1] * r->lv_dims[2], (size_t) r->lv_dims[0] * r->lv_dims[2],
         (size_t) r->lv_dims[0] * r->lv_dims[1]};
     for (int a = 0; a < 3; ++a)
         for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc(&r->d_buf[a][k], buf_px[a] * lv_elem));
+    const size_t plane_px = std::max({buf_px[0], buf_px[1], buf_px[2]});
+    for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc((void**) &r->d_plane[k], plane_px * sizeof(float)));
     CREATE_TRY(hipMalloc((void**) &r->d_minmax, nb * sizeof(float2)));
     CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
     CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));
@@ -375,7 +532,7 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     for (int k = 0; k < 2; ++k)
         for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));
     // the light volume render target starts cleared
-    CREATE_TRY(hipMemsetAsync(r->d_light, 0, r->light_bytes, r->stream));
+    CREATE_TRY(hipMemsetAsync(r->d_light, 0, r->light_bricked_bytes, r->stream));
 #undef CREATE_TRY
     *out = r;
     return TBRM_OK;
@@ -391,6 +548,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     (void) hipFree(r->d_light);
     for (auto& axis : r->d_buf)
         for (void* b : axis) (void) hipFree(b);
+    for (float* pl : r->d_plane) (void) hipFree(pl);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     (void) hipFree(r->d_alpha_prefix);
@@ -418,8 +576,14 @@ int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_byte
     if (!r || !host_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
     if (int e = bind(r)) return e;
-    HIP_TRY(hipMemcpyAsync(r->d_data, host_voxels, n_bytes, hipMemcpyHostToDevice, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream)); // the caller may free its buffer on return
+    void* staging = nullptr; // linear copy in HBM, re-laid out into bricks by the GPU
+    HIP_TRY(hipMalloc(&staging, n_bytes));
+    const int dims[3] = {r->desc.dim_x, r->desc.dim_y, r->desc.dim_z};
+    hipError_t e1 = hipMemcpyAsync(staging, host_voxels, n_bytes, hipMemcpyHostToDevice, r->stream);
+    if (e1 == hipSuccess) e1 = launch_relayout(relayout_params(staging, r->d_data, dims, r->dbn, format_bytes(r->desc.data_format), true), r->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream); // the caller may free its buffer on return
+    (void) hipFree(staging);
+    HIP_TRY(e1);
     r->has_volume = true;
     r->minmax_valid = false;
     return TBRM_OK;
@@ -430,7 +594,8 @@ int tbrm_upload_volume_device(tbrm_resources* r, const void* device_voxels, size
     if (!r || !device_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
     if (int e = bind(r)) return e;
-    HIP_TRY(hipMemcpyAsync(r->d_data, device_voxels, n_bytes, hipMemcpyDeviceToDevice, r->stream));
+    const int dims[3] = {r->desc.dim_x, r->desc.dim_y, r->desc.dim_z};
+    HIP_TRY(launch_relayout(relayout_params(device_voxels, r->d_data, dims, r->dbn, format_bytes(r->desc.data_format), true), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->has_volume = true;
     r->minmax_valid = false;
@@ -506,7 +671,7 @@ int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)
     if (!r->d_light) return TBRM_OK; // RaymarchUtils.cpp:106-109
     if (int e = bind(r)) return e;
     if (int e = begin_timed(r, 0)) return e;
-    const size_t n = (size_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2];
+    const size_t n = (size_t) r->lbn[0] * r->lbn[1] * r->lbn[2] * 512; // padding voxels are never sampled
     HIP_TRY(launch_fill(r->d_light, r->lv_fmt, n, clear_value, r->stream));
     return end_timed(r, 0);
 }
@@ -527,6 +692,7 @@ int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tb
     }
     if (int e = begin_timed(r, 1)) return e;
     HIP_TRY(launch_raymarch(p, r->stream));
+    ++r->launches[2];
     return end_timed(r, 1);
 }
 
@@ -574,8 +740,14 @@ int tbrm_download_light_volume(tbrm_resources* r, void* host_out, size_t n_bytes
     if (!r || !host_out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->light_bytes) return fail(TBRM_ERR_INVALID_ARG, "light volume is %zu bytes, got %zu", r->light_bytes, n_bytes);
     if (int e = bind(r)) return e;
-    HIP_TRY(hipMemcpyAsync(host_out, r->d_light, n_bytes, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    void* staging = nullptr;
+    HIP_TRY(hipMalloc(&staging, n_bytes));
+    const int dims[3] = {r->lv_dims[0], r->lv_dims[1], r->lv_dims[2]};
+    hipError_t e1 = launch_relayout(relayout_params(r->d_light, staging, dims, r->lbn, r->lv_fmt == FMT_U8 ? 1 : 4, false), r->stream);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(host_out, staging, n_bytes, hipMemcpyDeviceToHost, r->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
+    (void) hipFree(staging);
+    HIP_TRY(e1);
     return TBRM_OK;
 }
 
@@ -584,16 +756,29 @@ int tbrm_upload_light_volume(tbrm_resources* r, const void* host_in, size_t n_by
     if (!r || !host_in) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->light_bytes) return fail(TBRM_ERR_INVALID_ARG, "light volume is %zu bytes, got %zu", r->light_bytes, n_bytes);
     if (int e = bind(r)) return e;
-    HIP_TRY(hipMemcpyAsync(r->d_light, host_in, n_bytes, hipMemcpyHostToDevice, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
+    void* staging = nullptr;
+    HIP_TRY(hipMalloc(&staging, n_bytes));
+    const int dims[3] = {r->lv_dims[0], r->lv_dims[1], r->lv_dims[2]};
+    hipError_t e1 = hipMemcpyAsync(staging, host_in, n_bytes, hipMemcpyHostToDevice, r->stream);
+    if (e1 == hipSuccess) e1 = launch_relayout(relayout_params(staging, r->d_light, dims, r->lbn, r->lv_fmt == FMT_U8 ? 1 : 4, true), r->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
+    (void) hipFree(staging);
+    HIP_TRY(e1);
     return TBRM_OK;
 }
 
 int tbrm_light_volume_device_ptr(tbrm_resources* r, void** out_ptr, size_t* out_bytes)
 {
     if (!r || !out_ptr) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    *out_ptr = r->d_light;
-    if (out_bytes) *out_bytes = r->light_bytes;
+    *out_ptr = r->d_light; // bricked layout (DESIGN.md "Data layout")
+    if (out_bytes) *out_bytes = r->light_bricked_bytes;
+    return TBRM_OK;
+}
+
+int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
+{
+    if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 3; ++k) out[k] = r->launches[k];
     return TBRM_OK;
 }
 

@@ -14,9 +14,11 @@ constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
 constexpr int kBrickShift = 3;
 
 struct VolumeDev {
-    const void* data;
+    const void* data; // bricked layout (tbrm_device_sampling.h)
     int nx, ny, nz;
     int fmt;
+    int bnx;          // bricks along x
+    int bnxy;         // bricks per z-layer of bricks (bnx * bny)
 };
 
 struct WindowDev { // WindowingParameters float4 (VolumeInfo.h:49-52)
@@ -38,8 +40,9 @@ struct PropParams {
     float data_border; // VolumeSampler border colour
     const float4* tf;  // 256 texels, fp16-rounded values held as fp32
     WindowDev win;
-    void* light;       // ALightVolume
+    void* light;       // ALightVolume (bricked)
     int lv_dims[3];
+    int lv_bnx, lv_bnxy;
     int lv_fmt;        // FMT_U8 or FMT_F32 (buffers share it)
     float cc[3], cd[3];// LocalClippingCenter / LocalClippingDirection
     int clip_mode;     // 0: plane provably leaves every sample weight at exactly 1; 1: general
@@ -51,13 +54,47 @@ struct PropParams {
     PropStream r;      // the removed light (Change only)
 };
 
+// One launch of the chunked propagation kernel: `n_steps` consecutive slices of one axis pass for every tile of
+// the slice plane (tbrm_light_kernels.hip, DESIGN.md "Illumination kernel").
+struct ChunkStream {
+    float border_light;
+    float off_u, off_v;
+    float uvw_off[3];
+    float step100;
+    float init_value;       // what the cleared read/write buffers decode to (first chunk)
+    const float* plane_in;  // propagated light after the previous chunk (W x H floats); unused in the first chunk
+    float* plane_out;       // propagated light after this chunk
+};
+
+struct ChunkParams {
+    VolumeDev data;
+    float data_border;
+    const float4* tf;
+    WindowDev win;
+    void* light;            // bricked
+    int lv_dims[3];
+    int lv_bnx, lv_bnxy;
+    float cc[3], cd[3];
+    int clip_mode;
+    int axis;
+    int W, H;               // TD.X, TD.Y
+    int j0, dir, n_steps;   // first slice of the chunk, +-1, steps in this chunk
+    int first_chunk;
+    int tile_i0, tile_j0;   // index of the first tile (may be negative: sheared passes need lead-in tiles)
+    int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch
+    int cx, cy;             // per-step shift of the ownership frame, within [d*_lo, d*_hi - 1]
+    float b_added;
+    ChunkStream a, r;
+};
+
 struct RayParams {
     VolumeDev data;
     int data_addr_mode; // ADDR_WRAP / ADDR_CLAMP
     const float4* tf;
     WindowDev win;
-    const void* light;
+    const void* light;  // bricked
     int lv_dims[3];
+    int lv_bnx, lv_bnxy;
     int lv_fmt;
     float cam_pos[3], fwd[3], right[3], up[3];
     float thx, thy;
@@ -90,7 +127,23 @@ struct EmptyParams {
     uint32_t* bits;
 };
 
-// launchers (tbrm_kernels.hip)
+struct RelayoutParams {
+    const void* src;
+    void* dst;
+    int nx, ny, nz;
+    int bnx, bnxy, bnz;
+    int elem_bytes;
+    int to_bricks; // 1: linear -> bricked (padding voxels are zeroed); 0: bricked -> linear
+};
+
+constexpr int kChunkTile = 32;      // core tile edge of the chunked propagation kernel (pixels)
+constexpr int kChunkThreads = 1024;
+constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
+
+// launchers (tbrm_kernels.hip, tbrm_light_kernels.hip)
+hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
+size_t chunk_lds_bytes(const ChunkParams& p, bool change);
+hipError_t launch_propagate_chunk(const ChunkParams& p, bool change, int lv_fmt, int tiles_x, int tiles_y, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);

@@ -1,7 +1,6 @@
 // tbrm_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the raymarch + illumination hot path.
 //
-//   k_propagate_slice  : AddDirLightShader.usf:68-128 / ChangeDirLightShader.usf:74-156, one slice per launch
-//                        (the reference's dispatch structure, LightingShaders.cpp:132-158).
+//   (the illumination kernels live in tbrm_light_kernels.hip)
 //   k_raymarch_lit     : PerformRaymarchCubeSetup + PerformWindowedLitRaymarch
 //                        (RaymarchMaterialCommon.usf:23-78, WindowedRaymarchMaterials.usf:21-96).
 //   k_fill             : ClearTextureShader.usf:12-16 / ClearVolumeTextureShader.usf:14-20.
@@ -9,116 +8,9 @@
 //                        exactly the ones whose corrected opacity is 0, so results are unchanged).
 //
 // Compiled with -ffp-contract=off; see tbrm_device_math.h for the arithmetic contract.
-#include "tbrm_device_math.h"
-#include "tbrm_internal.h"
+#include "tbrm_device_sampling.h"
 
 namespace tbrm {
-
-// ------------------------------------------------------------------------------------------------------------
-// voxel access
-
-template <int FMT>
-__device__ __forceinline__ float load_voxel(const void* p, size_t i)
-{
-    if constexpr (FMT == FMT_U8) return decode_u8(((const uint8_t*) p)[i]);
-    else if constexpr (FMT == FMT_U16) return decode_u16(((const uint16_t*) p)[i]);
-    else return ((const float*) p)[i];
-}
-
-template <int FMT>
-__device__ __forceinline__ void store_voxel(void* p, size_t i, float v)
-{
-    if constexpr (FMT == FMT_U8) ((uint8_t*) p)[i] = (uint8_t) encode_u8(v);
-    else ((float*) p)[i] = v;
-}
-
-__device__ __forceinline__ int wrap_fast(int i, int n)
-{
-    if ((unsigned) i >= (unsigned) n) {
-        i = i < 0 ? i + n : i - n;
-        if ((unsigned) i >= (unsigned) n) i = wrap_index(i, n);
-    }
-    return i;
-}
-
-template <int MODE>
-__device__ __forceinline__ int address(int i, int n)
-{
-    if constexpr (MODE == ADDR_WRAP) return wrap_fast(i, n);
-    else return clamp_index(i, n);
-}
-
-// Trilinear fetch, wrap or clamp addressing (the material samplers).
-template <int FMT, int MODE>
-__device__ __forceinline__ float sample_trilinear(const void* data, int nx, int ny, int nz, int ix, int iy, int iz,
-                                                  float fx, float fy, float fz)
-{
-    const int x0 = address<MODE>(ix, nx), x1 = address<MODE>(ix + 1, nx);
-    const int y0 = address<MODE>(iy, ny), y1 = address<MODE>(iy + 1, ny);
-    const int z0 = address<MODE>(iz, nz), z1 = address<MODE>(iz + 1, nz);
-    const size_t r00 = ((size_t) z0 * ny + y0) * (size_t) nx, r10 = ((size_t) z0 * ny + y1) * (size_t) nx;
-    const size_t r01 = ((size_t) z1 * ny + y0) * (size_t) nx, r11 = ((size_t) z1 * ny + y1) * (size_t) nx;
-    const float t000 = load_voxel<FMT>(data, r00 + x0), t001 = load_voxel<FMT>(data, r00 + x1);
-    const float t010 = load_voxel<FMT>(data, r10 + x0), t011 = load_voxel<FMT>(data, r10 + x1);
-    const float t100 = load_voxel<FMT>(data, r01 + x0), t101 = load_voxel<FMT>(data, r01 + x1);
-    const float t110 = load_voxel<FMT>(data, r11 + x0), t111 = load_voxel<FMT>(data, r11 + x1);
-    const float c00 = lerp_(t000, t001, fx), c10 = lerp_(t010, t011, fx);
-    const float c01 = lerp_(t100, t101, fx), c11 = lerp_(t110, t111, fx);
-    const float c0 = lerp_(c00, c10, fy), c1 = lerp_(c01, c11, fy);
-    return lerp_(c0, c1, fz);
-}
-
-// Trilinear fetch with border addressing (the propagation shaders' VolumeSampler, LightingShaders.h:82-89).
-template <int FMT>
-__device__ __forceinline__ float sample_trilinear_border(const VolumeDev& v, float u, float vv, float w, float border)
-{
-    int ix, iy, iz;
-    float fx, fy, fz;
-    texel_split(u, (float) v.nx, ix, fx);
-    texel_split(vv, (float) v.ny, iy, fy);
-    texel_split(w, (float) v.nz, iz, fz);
-    float t[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int x = ix + (k & 1), y = iy + ((k >> 1) & 1), z = iz + (k >> 2);
-        const bool in = (unsigned) x < (unsigned) v.nx && (unsigned) y < (unsigned) v.ny && (unsigned) z < (unsigned) v.nz;
-        t[k] = in ? load_voxel<FMT>(v.data, ((size_t) z * v.ny + y) * (size_t) v.nx + x) : border;
-    }
-    const float c00 = lerp_(t[0], t[1], fx), c10 = lerp_(t[2], t[3], fx);
-    const float c01 = lerp_(t[4], t[5], fx), c11 = lerp_(t[6], t[7], fx);
-    const float c0 = lerp_(c00, c10, fy), c1 = lerp_(c01, c11, fy);
-    return lerp_(c0, c1, fz);
-}
-
-// TF.SampleLevel(clamp-bilinear, (pos, 0.5)) — 1D linear between neighbouring texels of the 256-wide row.
-__device__ __forceinline__ float4 sample_tf(const float4* tf, float pos)
-{
-    int i0;
-    float f;
-    texel_split(pos, 256.0f, i0, f);
-    const int i1 = min(max(i0 + 1, 0), 255);
-    i0 = min(max(i0, 0), 255);
-    const float4 a = tf[i0], b = tf[i1];
-    return make_float4(lerp_(a.x, b.x, f), lerp_(a.y, b.y, f), lerp_(a.z, b.z, f), lerp_(a.w, b.w, f));
-}
-__device__ __forceinline__ float sample_tf_alpha(const float4* tf, float pos)
-{
-    int i0;
-    float f;
-    texel_split(pos, 256.0f, i0, f);
-    const int i1 = min(max(i0 + 1, 0), 255);
-    i0 = min(max(i0, 0), 255);
-    return lerp_(tf[i0].w, tf[i1].w, f);
-}
-
-// SampleWindowedTransferFunction(...).a  (WindowedSampling.usf:20-37)
-__device__ __forceinline__ float windowed_alpha(float value, float step, const float4* tf, const WindowDev& w)
-{
-    const float pos = tf_position(value, w.center, w.width);
-    if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return 0.0f;
-    const float a = saturate_(sample_tf_alpha(tf, pos));
-    return 1.0f - pow_(1.0f - a, step);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // fill
@@ -146,108 +38,6 @@ hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s)
     const int grid = (int) (want < 2048 ? want : 2048);
     hipLaunchKernelGGL(k_fill<FMT_F32>, dim3(grid), dim3(block), 0, s, dst, n, value);
     return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// illumination: one slice of one axis pass
-
-// AlphaWeight (AddDirLightShader.usf:87-105)
-__device__ __forceinline__ float clip_alpha_weight(float u, float v, float w, const float* cc, const float* cd, const int* res)
-{
-    const float dist = ((u - cc[0]) * cd[0] + (v - cc[1]) * cd[1]) + (w - cc[2]) * cd[2];
-    const float ipx = u + cd[0] * dist, ipy = v + cd[1] * dist, ipz = w + cd[2] * dist;
-    const float ox = (u - ipx) * (float) (uint32_t) res[0];
-    const float oy = (v - ipy) * (float) (uint32_t) res[1];
-    const float oz = (w - ipz) * (float) (uint32_t) res[2];
-    const float vd = sqrtf((ox * ox + oy * oy) + oz * oz);
-    const float sg = dist > 0.0f ? 1.0f : (dist < 0.0f ? -1.0f : 0.0f);
-    return fminf(fmaxf(0.5f + ((0.57735026919f * vd) * sg), 0.0f), 1.0f);
-}
-
-template <int LFMT>
-__device__ __forceinline__ float sample_buffer_bilinear(const void* buf, int w, int h, float u, float v, float border)
-{
-    int ix, iy;
-    float fx, fy;
-    texel_split(u, (float) w, ix, fx);
-    texel_split(v, (float) h, iy, fy);
-    float t[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = ix + (k & 1), y = iy + (k >> 1);
-        const bool in = (unsigned) x < (unsigned) w && (unsigned) y < (unsigned) h;
-        t[k] = in ? load_voxel<LFMT>(buf, (size_t) y * w + x) : border;
-    }
-    return lerp_(lerp_(t[0], t[1], fx), lerp_(t[2], t[3], fx), fy);
-}
-
-template <int DFMT, int LFMT, bool GUARD>
-__device__ __forceinline__ float propagate_stream(const PropParams& p, const PropStream& s, int px, int py, const int* pos)
-{
-    const float pu = (((float) (uint32_t) px + 0.5f) / (float) p.td[0]) + s.off_u;
-    const float pv = (((float) (uint32_t) py + 0.5f) / (float) p.td[1]) + s.off_v;
-    const float prev = sample_buffer_bilinear<LFMT>(s.read, p.td[0], p.td[1], pu, pv, s.border_light);
-
-    const float u = (((float) (uint32_t) pos[0] + 0.5f) / (float) (uint32_t) p.lv_dims[0]) + s.uvw_off[0];
-    const float v = (((float) (uint32_t) pos[1] + 0.5f) / (float) (uint32_t) p.lv_dims[1]) + s.uvw_off[1];
-    const float w = (((float) (uint32_t) pos[2] + 0.5f) / (float) (uint32_t) p.lv_dims[2]) + s.uvw_off[2];
-
-    const float aw = p.clip_mode ? clip_alpha_weight(u, v, w, p.cc, p.cd, p.lv_dims) : 1.0f;
-    float cur = 0.0f;
-    bool inside = true;
-    if constexpr (GUARD) inside = (u == saturate_(u)) && (v == saturate_(v)) && (w == saturate_(w));
-    if (aw > 0.0f && inside) {
-        const float val = sample_trilinear_border<DFMT>(p.data, u, v, w, p.data_border);
-        cur = windowed_alpha(val, s.step100, p.tf, p.win) * aw;
-    }
-    return prev * (1 - cur);
-}
-
-template <int DFMT, int LFMT, bool CHANGE>
-__global__ __launch_bounds__(256) void k_propagate_slice(const PropParams p)
-{
-    const int px = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int py = blockIdx.y * 16 + (threadIdx.x >> 4);
-    if (px >= p.td[0] || py >= p.td[1]) return; // D3D drops the overhanging threads' writes
-    int pos[3];
-    if (p.axis == 0) { pos[0] = p.loop; pos[1] = px; pos[2] = py; }
-    else if (p.axis == 1) { pos[0] = px; pos[1] = p.loop; pos[2] = py; }
-    else { pos[0] = px; pos[1] = py; pos[2] = p.loop; }
-    const size_t bi = (size_t) py * p.td[0] + px;
-    const size_t li = ((size_t) pos[2] * p.lv_dims[1] + pos[1]) * (size_t) p.lv_dims[0] + pos[0];
-    if constexpr (!CHANGE) {
-        const float l = propagate_stream<DFMT, LFMT, true>(p, p.a, px, py, pos);
-        store_voxel<LFMT>(p.a.write, bi, l);
-        if (fabsf(l) > 1e-3f) store_voxel<LFMT>(p.light, li, load_voxel<LFMT>(p.light, li) + (l * p.b_added));
-    } else {
-        const float lr = propagate_stream<DFMT, LFMT, false>(p, p.r, px, py, pos);
-        const float la = propagate_stream<DFMT, LFMT, false>(p, p.a, px, py, pos);
-        store_voxel<LFMT>(p.r.write, bi, lr);
-        store_voxel<LFMT>(p.a.write, bi, la);
-        if (fabsf(la - lr) > 1e-3f) store_voxel<LFMT>(p.light, li, load_voxel<LFMT>(p.light, li) + la - lr);
-    }
-}
-
-template <int DFMT, int LFMT>
-static hipError_t launch_prop2(const PropParams& p, bool change, hipStream_t s)
-{
-    const dim3 grid((p.td[0] + 15) / 16, (p.td[1] + 15) / 16), block(256);
-    if (change) hipLaunchKernelGGL((k_propagate_slice<DFMT, LFMT, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_propagate_slice<DFMT, LFMT, false>), grid, block, 0, s, p);
-    return hipGetLastError();
-}
-template <int DFMT>
-static hipError_t launch_prop1(const PropParams& p, bool change, hipStream_t s)
-{
-    return p.lv_fmt == FMT_U8 ? launch_prop2<DFMT, FMT_U8>(p, change, s) : launch_prop2<DFMT, FMT_F32>(p, change, s);
-}
-hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s)
-{
-    switch (p.data.fmt) {
-        case FMT_U8: return launch_prop1<FMT_U8>(p, change, s);
-        case FMT_U16: return launch_prop1<FMT_U16>(p, change, s);
-        default: return launch_prop1<FMT_F32>(p, change, s);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -368,6 +158,7 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
 
     const float nx = (float) p.data.nx, ny = (float) p.data.ny, nz = (float) p.data.nz;
     const float lnx = (float) p.lv_dims[0], lny = (float) p.lv_dims[1], lnz = (float) p.lv_dims[2];
+    const VolumeDev lightv{p.light, p.lv_dims[0], p.lv_dims[1], p.lv_dims[2], LFMT, p.lv_bnx, p.lv_bnxy};
     float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f;
     int cached_brick = -1;
     bool cached_empty = false;
@@ -390,7 +181,7 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
             }
             if (cached_empty) return false; // every tap of this sample maps to opacity 0: exact no-op
         }
-        const float v = sample_trilinear<DFMT, DMODE>(p.data.data, p.data.nx, p.data.ny, p.data.nz, ix, iy, iz, fx, fy, fz);
+        const float v = sample_trilinear<DFMT, DMODE>(p.data, ix, iy, iz, fx, fy, fz);
         // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
         const float tpos = tf_position(v, p.win.center, p.win.width);
         if ((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f)) return false;
@@ -404,7 +195,7 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
         texel_split(saturate_(pos0), lnx, lx, gx);
         texel_split(saturate_(pos1), lny, ly, gy);
         texel_split(saturate_(pos2), lnz, lz, gz);
-        const float l = sample_trilinear<LFMT, ADDR_WRAP>(p.light, p.lv_dims[0], p.lv_dims[1], p.lv_dims[2], lx, ly, lz, gx, gy, gz);
+        const float l = sample_trilinear<LFMT, ADDR_WRAP>(lightv, lx, ly, lz, gx, gy, gz);
         cs.x = cs.x * l; cs.y = cs.y * l; cs.z = cs.z * l;
         // AccumulateLightEnergy (RaymarchMaterialCommon.usf:82-88)
         const float om = 1.0f - le3;
@@ -497,7 +288,7 @@ __global__ __launch_bounds__(64) void k_brick_minmax(const BrickParams p)
         x = address<MODE>(x, p.data.nx);
         y = address<MODE>(y, p.data.ny);
         z = address<MODE>(z, p.data.nz);
-        const float v = load_voxel<FMT>(p.data.data, ((size_t) z * p.data.ny + y) * (size_t) p.data.nx + x);
+        const float v = load_voxel<FMT>(p.data.data, brick_off(x, y, z, p.data.bnx, p.data.bnxy));
         if (v != v) nan = true;
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
@@ -573,6 +364,35 @@ hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s)
 {
     if (p.n_bricks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_empty, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// linear (UVolumeTexture mip, x fastest) <-> bricked. One workgroup per brick; the linear side is read/written as
+// eight-voxel rows, the bricked side as one contiguous 512-voxel run.
+template <typename E>
+__global__ __launch_bounds__(256) void k_relayout(const RelayoutParams p)
+{
+    const int b = blockIdx.x;
+    const int bx = b % p.bnx, by = (b / p.bnx) % (p.bnxy / p.bnx), bz = b / p.bnxy;
+    E* bricked = (E*) (p.to_bricks ? p.dst : const_cast<void*>(p.src)) + (size_t) b * 512;
+    E* linear = (E*) (p.to_bricks ? const_cast<void*>(p.src) : p.dst);
+    for (int t = threadIdx.x; t < 512; t += 256) {
+        const int x = bx * 8 + (t & 7), y = by * 8 + ((t >> 3) & 7), z = bz * 8 + (t >> 6);
+        const bool in = x < p.nx && y < p.ny && z < p.nz;
+        const size_t li = ((size_t) z * p.ny + y) * (size_t) p.nx + x;
+        if (p.to_bricks) bricked[t] = in ? linear[li] : E(0);
+        else if (in) linear[li] = bricked[t];
+    }
+}
+
+hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s)
+{
+    const int n = p.bnxy * p.bnz;
+    if (n == 0) return hipSuccess;
+    if (p.elem_bytes == 1) hipLaunchKernelGGL(k_relayout<uint8_t>, dim3(n), dim3(256), 0, s, p);
+    else if (p.elem_bytes == 2) hipLaunchKernelGGL(k_relayout<uint16_t>, dim3(n), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_relayout<uint32_t>, dim3(n), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

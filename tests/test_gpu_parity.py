@@ -39,13 +39,23 @@ def assert_light_equal(res, orc):
         np.testing.assert_allclose(got, orc.light, rtol=0, atol=TIGHT_TOL)
 
 
+@pytest.fixture(params=["chunk", "slice"])
+def kernel_variant(request, monkeypatch):
+    """Runs a test with the production chunk kernel and with the one-slice-per-launch kernel."""
+    if request.param == "slice":
+        monkeypatch.setenv("TBRM_FORCE_SLICE_KERNEL", "1")
+    else:
+        monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+    return request.param
+
+
 FACE_LIGHTS = [((1, .35, -.5), 0.5), ((-1, .2, .4), 0.6), ((.3, 1, -.2), 0.5), ((.25, -1, .5), 0.7),
                ((.1, .45, 1), 0.5), ((-.35, .2, -1), 0.9), ((1, 0, 0), 0.5), ((0, 0, -1), 0.8), ((1, 1, 0), 0.6)]
 
 
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize("light_32bit", [False, True])
-def test_add_dir_light_all_faces(gpu, oracle_mod, dtype, light_32bit):
+def test_add_dir_light_all_faces(gpu, oracle_mod, dtype, light_32bit, kernel_variant):
     res, orc = make_pair(gpu, oracle_mod, (40, 36, 44), dtype, light_32bit)
     world = S.default_world()
     with res:
@@ -59,10 +69,15 @@ def test_add_dir_light_all_faces(gpu, oracle_mod, dtype, light_32bit):
         res.add_dir_light(light, False, world)
         orc.add_dir_light(light, False, world)
         assert_light_equal(res, orc)
+        counters = res.launch_counters()
+        if kernel_variant == "chunk":  # every one of these passes is within the chunk kernel's envelope
+            assert counters["chunk"] > 0 and counters["slice"] == 0, counters
+        else:
+            assert counters["chunk"] == 0 and counters["slice"] > 0, counters
 
 
 @pytest.mark.parametrize("light_32bit", [False, True])
-def test_change_dir_light_fused_and_fallback(gpu, oracle_mod, light_32bit):
+def test_change_dir_light_fused_and_fallback(gpu, oracle_mod, light_32bit, kernel_variant):
     res, orc = make_pair(gpu, oracle_mod, (48, 48, 48), np.uint16, light_32bit)
     world = S.default_world()
     with res:
@@ -92,7 +107,7 @@ def test_change_dir_light_fused_and_fallback(gpu, oracle_mod, light_32bit):
         assert_light_equal(res, orc)
 
 
-def test_half_resolution_and_clip_plane(gpu, oracle_mod):
+def test_half_resolution_and_clip_plane(gpu, oracle_mod, kernel_variant):
     res, orc = make_pair(gpu, oracle_mod, (45, 40, 37), np.uint16, False, half_res=True)
     # rotated, non-uniformly scaled volume and a clip plane through it
     tr = abi.identity_transform(scale=(100.0, 120.0, 80.0), translation=(10.0, -5.0, 3.0),
