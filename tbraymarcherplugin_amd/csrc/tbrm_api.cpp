@@ -77,6 +77,8 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
+    float* d_occ[4]{};             // chunk kernel: occlusion plane stacks, 2 per stream (allocated on first use)
+    size_t occ_elems = 0;
 
     // empty-space-skipping metadata
     int bn[3]{};
@@ -246,13 +248,6 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         tx.lo = std::min(tx.lo, rx.lo); tx.hi = std::max(tx.hi, rx.hi);
         ty.lo = std::min(ty.lo, ry.lo); ty.hi = std::max(ty.hi, ry.hi);
     }
-    const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
-    int M = 0;
-    for (int cand : {16, 8, 4})
-        if (kChunkTile + cand * g <= kChunkMaxHull) { M = cand; break; }
-    if (chunk_steps_override() > 0) M = chunk_steps_override();
-    if (M <= 0) return TBRM_ERR_UNSUPPORTED;
-
     ChunkParams p{};
     p.data = base.data;
     p.data_border = base.data_border;
@@ -269,28 +264,69 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     p.cx = clamp_int(0, tx.lo, tx.hi);
     p.cy = clamp_int(0, ty.lo, ty.hi);
     p.b_added = b_added;
+    { const char* e = getenv("TBRM_DEBUG"); p.debug = e ? atoi(e) : 0; }
+    static long long* dbg_clock = nullptr;
+    if ((p.debug & 64) && !dbg_clock) HIP_TRY(hipMalloc((void**) &dbg_clock, 64 * sizeof(long long)));
+    p.debug_clock = dbg_clock;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
     if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
-    p.n_steps = std::min(M, D);
-    if (chunk_lds_bytes(p, change) > 150 * 1024) return TBRM_ERR_UNSUPPORTED;
+
+    // chunk length: the longest of 16/8/4 slices whose window (tile + steps*growth) and staged occlusion fit in LDS
+    const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
+    int M = 0;
+    for (int cand : {16, 8, 4}) {
+        if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
+        p.n_steps = std::min(cand, D);
+        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, change) <= 156 * 1024) { M = cand; break; }
+    }
+    if (M <= 0) return TBRM_ERR_UNSUPPORTED;
+
+    // occlusion scratch: 2 (ping-pong over chunks) x 2 (streams) stacks of M planes, allocated on first use
+    const size_t occ_elems = (size_t) 16 * W * H;
+    if (occ_elems > r->occ_elems) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        for (float*& b : r->d_occ) { (void) hipFree(b); b = nullptr; }
+        r->occ_elems = 0;
+        for (float*& b : r->d_occ) HIP_TRY(hipMalloc((void**) &b, occ_elems * sizeof(float)));
+        r->occ_elems = occ_elems;
+    }
 
     const int n_chunks = (D + M - 1) / M;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int n = std::min(M, D - c * M);
-        p.n_steps = n;
+    auto set_chunk = [&](int c) {
+        p.n_steps = std::min(M, D - c * M);
         p.j0 = pa.start + c * M * pa.dir;
         p.first_chunk = c == 0;
-        p.a.plane_in = r->d_plane[c & 1];
-        p.a.plane_out = r->d_plane[(c & 1) ^ 1];
-        p.r.plane_in = r->d_plane[2 + (c & 1)];
-        p.r.plane_out = r->d_plane[2 + ((c & 1) ^ 1)];
+        const int cur = (c & 1), nxt = cur ^ 1;
+        p.a.plane_in = r->d_plane[cur]; p.a.plane_out = r->d_plane[nxt];
+        p.r.plane_in = r->d_plane[2 + cur]; p.r.plane_out = r->d_plane[2 + nxt];
+        p.a.occ_cur = r->d_occ[cur]; p.a.occ_next = r->d_occ[cur]; // the occlusion launch of chunk c fills occ_next
+        p.r.occ_cur = r->d_occ[2 + cur]; p.r.occ_next = r->d_occ[2 + cur];
         // tiles whose ownership range [iT + r*cx, (i+1)T + r*cx) meets the plane for some r in [0, n-1]
-        const int sx = (n - 1) * p.cx, sy = (n - 1) * p.cy;
+        const int sx = (p.n_steps - 1) * p.cx, sy = (p.n_steps - 1) * p.cy;
         p.tile_i0 = floor_div(-std::max(0, sx), kChunkTile);
         p.tile_j0 = floor_div(-std::max(0, sy), kChunkTile);
-        const int i1 = ceil_div(W - std::min(0, sx), kChunkTile) - 1, j1 = ceil_div(H - std::min(0, sy), kChunkTile) - 1;
-        HIP_TRY(launch_propagate_chunk(p, change, r->lv_fmt, i1 - p.tile_i0 + 1, j1 - p.tile_j0 + 1, r->stream));
+        p.tiles_x = ceil_div(W - std::min(0, sx), kChunkTile) - p.tile_i0;
+        p.tiles_y = ceil_div(H - std::min(0, sy), kChunkTile) - p.tile_j0;
+    };
+    // occlusion of chunk c+1 is enqueued ahead of the chain of chunk c: the two do not depend on each other
+    set_chunk(0);
+    HIP_TRY(launch_light_occlusion(p, change, r->stream));
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) {
+            set_chunk(c + 1);
+            HIP_TRY(launch_light_occlusion(p, change, r->stream));
+        }
+        set_chunk(c);
+        HIP_TRY(launch_light_chain(p, change, r->lv_fmt, r->stream));
         ++r->launches[0];
+    }
+    if ((p.debug & 64) && dbg_clock) {
+        long long h[64];
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        HIP_TRY(hipMemcpy(h, dbg_clock, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[tbrm debug] chain block 0 clocks (delta from start):");
+        for (int k = 1; k < 24; ++k) fprintf(stderr, " %lld", h[k] - h[0]);
+        fprintf(stderr, "\n");
     }
     return TBRM_OK;
 }
@@ -549,6 +585,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (auto& axis : r->d_buf)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
+    for (float* oc : r->d_occ) (void) hipFree(oc);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     (void) hipFree(r->d_alpha_prefix);

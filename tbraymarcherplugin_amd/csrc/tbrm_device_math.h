@@ -72,8 +72,16 @@ __device__ __forceinline__ float pow_(float x, float y)
 }
 
 // ---- UNORM conversion (D3D11 functional spec: load c/(2^n-1); store trunc(clamp(x,0,1)*255+0.5), NaN->0)
-__device__ __forceinline__ float decode_u8(uint32_t c) { return (float) c / 255.0f; }
-__device__ __forceinline__ float decode_u16(uint32_t c) { return (float) c / 65535.0f; }
+// c/d through the fma-corrected reciprocal (q = c*r; q += fma(-q, d, c)*r): 3 instructions instead of the ~10 of a
+// correctly rounded v_div sequence, and bit-identical to IEEE c/d for every UNORM8 and UNORM16 code (checked
+// exhaustively: tests/test_gpu_parity.py::test_unorm_decode_is_exact_division).
+__device__ __forceinline__ float div_by_const(float c, float d, float r)
+{
+    const float q = c * r;
+    return fma_(fma_(-q, d, c), r, q);
+}
+__device__ __forceinline__ float decode_u8(uint32_t c) { return div_by_const((float) c, 255.0f, 1.0f / 255.0f); }
+__device__ __forceinline__ float decode_u16(uint32_t c) { return div_by_const((float) c, 65535.0f, 1.0f / 65535.0f); }
 __device__ __forceinline__ uint32_t encode_u8(float x)
 {
     if (x != x) return 0;

@@ -64,8 +64,13 @@ struct ChunkStream {
     float init_value;       // what the cleared read/write buffers decode to (first chunk)
     const float* plane_in;  // propagated light after the previous chunk (W x H floats); unused in the first chunk
     float* plane_out;       // propagated light after this chunk
+    const float* occ_cur;   // occlusion (CurrentSample) of this chunk's slices: [n_steps][H][W], written by the previous launch
+    float* occ_next;        // occlusion of the next chunk's slices: [next_n][H][W]
 };
 
+// One launch of the fused propagation kernel (tbrm_light_kernels.hip, DESIGN.md "Illumination kernel"):
+// "chain" workgroups advance every tile of the slice plane through the `n_steps` slices of the current chunk while
+// "occlusion" workgroups compute the opacity samples of the NEXT chunk's slices.
 struct ChunkParams {
     VolumeDev data;
     float data_border;
@@ -78,12 +83,20 @@ struct ChunkParams {
     int clip_mode;
     int axis;
     int W, H;               // TD.X, TD.Y
-    int j0, dir, n_steps;   // first slice of the chunk, +-1, steps in this chunk
+    int dir;                // +-1
+    // chain part
+    int j0, n_steps;        // first slice of the chunk, steps in this chunk (0: no chain work in this launch)
     int first_chunk;
     int tile_i0, tile_j0;   // index of the first tile (may be negative: sheared passes need lead-in tiles)
+    int tiles_x, tiles_y;
     int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch
-    int cx, cy;             // per-step shift of the ownership frame, within [d*_lo, d*_hi - 1]
+    int cx, cy;             // per-step shift of the ownership frame, within [d*_lo, d*_hi]
     float b_added;
+    // occlusion part
+    int next_j0, next_n;    // first slice and number of slices of the next chunk (0: none)
+    int occ_tiles_x, occ_tiles_y;
+    int debug;              // TBRM_DEBUG bitmask (timing experiments only; results are wrong when set)
+    long long* debug_clock; // bit 64: block 0 writes s_memtime stamps here
     ChunkStream a, r;
 };
 
@@ -143,7 +156,8 @@ constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
 // launchers (tbrm_kernels.hip, tbrm_light_kernels.hip)
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, bool change);
-hipError_t launch_propagate_chunk(const ChunkParams& p, bool change, int lv_fmt, int tiles_x, int tiles_y, hipStream_t s);
+hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s);
+hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
