@@ -260,9 +260,13 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     p.axis = pa.axis;
     p.W = W; p.H = H;
     p.dir = pa.dir;
+    // Unsheared windows: a tile keeps its 32x32 pixels for the whole chunk and its window grows towards the light by
+    // the tap range per remaining slice (the range is widened to contain 0 so the window always covers the tile).
+    tx.lo = std::min(tx.lo, 0); tx.hi = std::max(tx.hi, 0);
+    ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
     p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
-    p.cx = clamp_int(0, tx.lo, tx.hi);
-    p.cy = clamp_int(0, ty.lo, ty.hi);
+    p.cx = 0;
+    p.cy = 0;
     p.b_added = b_added;
     { const char* e = getenv("TBRM_DEBUG"); p.debug = e ? atoi(e) : 0; }
     static long long* dbg_clock = nullptr;
@@ -277,7 +281,8 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     for (int cand : {16, 8, 4}) {
         if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
         p.n_steps = std::min(cand, D);
-        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, change) <= 156 * 1024) { M = cand; break; }
+        p.j0 = pa.start;
+        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, change, r->lv_fmt) <= 156 * 1024) { M = cand; break; }
     }
     if (M <= 0) return TBRM_ERR_UNSUPPORTED;
 
@@ -287,7 +292,7 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         HIP_TRY(hipStreamSynchronize(r->stream));
         for (float*& b : r->d_occ) { (void) hipFree(b); b = nullptr; }
         r->occ_elems = 0;
-        for (float*& b : r->d_occ) HIP_TRY(hipMalloc((void**) &b, occ_elems * sizeof(float)));
+        for (float*& b : r->d_occ) HIP_TRY(hipMalloc((void**) &b, (occ_elems + 2 * kPlaneGuard) * sizeof(float)));
         r->occ_elems = occ_elems;
     }
 
@@ -297,16 +302,13 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         p.j0 = pa.start + c * M * pa.dir;
         p.first_chunk = c == 0;
         const int cur = (c & 1), nxt = cur ^ 1;
-        p.a.plane_in = r->d_plane[cur]; p.a.plane_out = r->d_plane[nxt];
-        p.r.plane_in = r->d_plane[2 + cur]; p.r.plane_out = r->d_plane[2 + nxt];
-        p.a.occ_cur = r->d_occ[cur]; p.a.occ_next = r->d_occ[cur]; // the occlusion launch of chunk c fills occ_next
-        p.r.occ_cur = r->d_occ[2 + cur]; p.r.occ_next = r->d_occ[2 + cur];
-        // tiles whose ownership range [iT + r*cx, (i+1)T + r*cx) meets the plane for some r in [0, n-1]
-        const int sx = (p.n_steps - 1) * p.cx, sy = (p.n_steps - 1) * p.cy;
-        p.tile_i0 = floor_div(-std::max(0, sx), kChunkTile);
-        p.tile_j0 = floor_div(-std::max(0, sy), kChunkTile);
-        p.tiles_x = ceil_div(W - std::min(0, sx), kChunkTile) - p.tile_i0;
-        p.tiles_y = ceil_div(H - std::min(0, sy), kChunkTile) - p.tile_j0;
+        p.a.plane_in = r->d_plane[cur] + kPlaneGuard; p.a.plane_out = r->d_plane[nxt] + kPlaneGuard;
+        p.r.plane_in = r->d_plane[2 + cur] + kPlaneGuard; p.r.plane_out = r->d_plane[2 + nxt] + kPlaneGuard;
+        p.a.occ_cur = p.a.occ_next = r->d_occ[cur] + kPlaneGuard; // the occlusion launch of chunk c fills occ_next
+        p.r.occ_cur = p.r.occ_next = r->d_occ[2 + cur] + kPlaneGuard;
+        p.tile_i0 = p.tile_j0 = 0;
+        p.tiles_x = ceil_div(W, kChunkTile);
+        p.tiles_y = ceil_div(H, kChunkTile);
     };
     // occlusion of chunk c+1 is enqueued ahead of the chain of chunk c: the two do not depend on each other
     set_chunk(0);
@@ -560,7 +562,7 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     for (int a = 0; a < 3; ++a)
         for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc(&r->d_buf[a][k], buf_px[a] * lv_elem));
     const size_t plane_px = std::max({buf_px[0], buf_px[1], buf_px[2]});
-    for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc((void**) &r->d_plane[k], plane_px * sizeof(float)));
+    for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc((void**) &r->d_plane[k], (plane_px + 2 * kPlaneGuard) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**) &r->d_minmax, nb * sizeof(float2)));
     CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
     CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));

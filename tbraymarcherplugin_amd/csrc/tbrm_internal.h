@@ -155,7 +155,8 @@ constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
 
 // launchers (tbrm_kernels.hip, tbrm_light_kernels.hip)
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
-size_t chunk_lds_bytes(const ChunkParams& p, bool change);
+size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
+constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
 hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);

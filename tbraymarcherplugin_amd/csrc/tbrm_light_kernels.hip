@@ -23,6 +23,8 @@
 // (RaymarchVolume.cpp:857-866).
 #include "tbrm_device_sampling.h"
 
+#include <type_traits>
+
 namespace tbrm {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -128,112 +130,217 @@ __device__ __forceinline__ char* carve(char*& cursor, size_t bytes)
     return r;
 }
 
+// Window geometry of one chain workgroup. A tile keeps its 32x32 pixels for the whole chunk; with r slices still to
+// go its window is [r*lox, T + r*hix) x [r*loy, T + r*hiy) in tile coordinates (lox <= 0 <= hix: the range of the
+// previous-slice taps, widened to contain 0), i.e. it grows towards the light by the tap range per remaining slice.
 struct ChunkGeom {
     int n;                  // steps in this chunk
-    int lox, hix, loy, hiy; // tap offsets relative to the ownership frame: [lo, hi]
-    int gx, gy;             // growth of the window per remaining step
-    int HX, HY;             // hull (LDS window) size
-    int padx, pady;         // LDS index of ownership-frame coordinate 0
-    int tabx0, taby0;       // first plane coordinate covered by the previous-tap tables
-    int tablx, tably;       // table lengths
-    int occ_total;          // staged occlusion values per stream: sum over steps of the window size
+    int lox, hix, loy, hiy;
+    int HX, HY;             // hull = window at r = n (the input state)
+    int HXp;                // LDS row stride (HX rounded up to 4 floats: rows are staged with 16-byte copies)
+    int padx, pady;         // LDS index of tile coordinate 0
+    int elems;              // floats per LDS plane (window or staged occlusion)
+    int lv_layers;          // 8-slice brick layers of the light volume the chunk touches
+    int lv_layer0;          // first of them
 };
 
-__host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p, int tile_x, int tile_y)
+__host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
 {
     ChunkGeom g;
     g.n = p.n_steps;
-    g.lox = p.dx_lo - p.cx; g.hix = p.dx_hi - p.cx;
-    g.loy = p.dy_lo - p.cy; g.hiy = p.dy_hi - p.cy;
-    g.gx = g.hix - g.lox; g.gy = g.hiy - g.loy;
-    g.HX = kChunkTile + g.n * g.gx;
-    g.HY = kChunkTile + g.n * g.gy;
+    g.lox = p.dx_lo; g.hix = p.dx_hi; g.loy = p.dy_lo; g.hiy = p.dy_hi;
+    g.HX = kChunkTile + g.n * (g.hix - g.lox);
+    g.HY = kChunkTile + g.n * (g.hiy - g.loy);
+    g.HXp = (g.HX + 3) & ~3;
     g.padx = -g.n * g.lox;
     g.pady = -g.n * g.loy;
-    const int nlo_x = g.n * p.dx_lo, nhi_x = g.n * p.dx_hi, nlo_y = g.n * p.dy_lo, nhi_y = g.n * p.dy_hi;
-    g.tabx0 = tile_x * kChunkTile + (nlo_x < 0 ? nlo_x : 0);
-    g.taby0 = tile_y * kChunkTile + (nlo_y < 0 ? nlo_y : 0);
-    g.tablx = kChunkTile + (nhi_x > 0 ? nhi_x : 0) - (nlo_x < 0 ? nlo_x : 0);
-    g.tably = kChunkTile + (nhi_y > 0 ? nhi_y : 0) - (nlo_y < 0 ? nlo_y : 0);
-    g.occ_total = 0;
-    for (int r = 0; r < g.n; ++r) g.occ_total += ((kChunkTile + r * g.gx) * (kChunkTile + r * g.gy) + 63) & ~63;
+    g.elems = (g.HY * g.HXp + 4 + 3) & ~3; // +4: the last bilinear fetch may touch one float past the last row
+    const int ja = p.j0, jb = p.j0 + (g.n - 1) * p.dir;
+    const int jlo = ja < jb ? ja : jb, jhi = ja < jb ? jb : ja;
+    g.lv_layer0 = jlo >> 3;
+    g.lv_layers = (jhi >> 3) - g.lv_layer0 + 1;
     return g;
 }
 
-size_t chunk_lds_bytes(const ChunkParams& p, bool change)
+constexpr int kOccRing = 3; // slices the occlusion operands are staged ahead of their use
+
+size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt)
 {
-    const ChunkGeom g = chunk_geometry(p, 0, 0);
+    const ChunkGeom g = chunk_geometry(p);
     const int ns = change ? 2 : 1;
-    auto al = [](size_t b) { return (b + 15) & ~(size_t) 15; };
-    size_t total = (size_t) ns * 2 * al(((size_t) g.HX * g.HY + 64) * 4);          // double-buffered plane windows (+ DMA slack)
-    total += (size_t) ns * 2 * (al((size_t) g.tablx * 4) + al((size_t) g.tably * 4)); // previous-tap tables (frac, delta)
+    size_t total = (size_t) ns * (2 + kOccRing) * g.elems * 4;                 // windows + staged occlusion ring
+    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;            // light-volume tile
     return total;
 }
 
-// ---- k_light_occlusion: CurrentSample (AddDirLightShader.usf:85-114) for every voxel of a chunk ------------------
-// grid = (plane tiles of 16x16 pixels, groups of kOccGroup slices); one thread = one pixel x kOccGroup slices, with
-// all 8*kOccGroup taps in flight before the first is used. Addressing is separable in the bricked layout: the two
-// in-plane axes contribute per-thread constants, the slice axis a per-step value read from a small LDS table (which
-// also carries the reference's per-thread (Loop+0.5)/res division out of the kernel).
-constexpr int kOccGroup = 4;
+// asynchronous global -> LDS copies: lane l of the wave lands at lds_wave_base + size*l
+__device__ __forceinline__ void dma_dword(const float* src, float* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
+                                     (__attribute__((address_space(3))) void*) lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ void dma_16(const void* src, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
+                                     (__attribute__((address_space(3))) void*) lds_wave_base, 16, 0, 0);
+}
 
-struct AxisTaps {       // one axis of a trilinear footprint with border addressing
-    uint32_t off0, off1; // brick offsets of the two taps (clamped into range, so always loadable)
+// ---- k_light_occlusion: CurrentSample (AddDirLightShader.usf:85-114) for every voxel of a chunk ------------------
+// One workgroup = 16x16 plane pixels x 8 slices. It first copies every data brick its samples can touch into LDS
+// with coalesced 16-byte global->LDS copies (a few dozen wide vector-memory instructions), then each thread filters
+// its 8 samples out of LDS: the 8 narrow gather loads per sample that bounded the first version (the texture-address
+// path handles ~one 64-lane gather per 20 cycles) become LDS reads. Addressing is separable in the bricked layout:
+// the two in-plane axes contribute per-thread constants, the slice axis a per-step value from a small LDS table
+// (which also carries the reference's per-thread (Loop+0.5)/res division out of the loop).
+constexpr int kOccTile = 16;  // pixels per side
+constexpr int kOccDepth = 8;  // slices per workgroup
+
+struct AxisTaps {        // one axis of a trilinear footprint with border addressing
+    int i0;              // base tap index (unclamped)
     bool ok0, ok1;       // tap inside the volume (else the sampler's border colour applies)
     float f;             // interpolation weight
 };
 
-template <int AXIS>
-__device__ __forceinline__ AxisTaps axis_taps(float coord, int n, int bnx, int bnxy)
+__device__ __forceinline__ AxisTaps axis_taps(float coord, int n)
 {
     AxisTaps t;
-    int i;
-    texel_split(coord, (float) n, i, t.f);
-    t.ok0 = (unsigned) i < (unsigned) n;
-    t.ok1 = (unsigned) (i + 1) < (unsigned) n;
-    const int c0 = min(max(i, 0), n - 1), c1 = min(max(i + 1, 0), n - 1);
-    if constexpr (AXIS == 0) { t.off0 = brick_off_x(c0); t.off1 = brick_off_x(c1); }
-    else if constexpr (AXIS == 1) { t.off0 = brick_off_y(c0, bnx); t.off1 = brick_off_y(c1, bnx); }
-    else { t.off0 = brick_off_z(c0, bnxy); t.off1 = brick_off_z(c1, bnxy); }
+    texel_split(coord, (float) n, t.i0, t.f);
+    t.ok0 = (unsigned) t.i0 < (unsigned) n;
+    t.ok1 = (unsigned) (t.i0 + 1) < (unsigned) n;
     return t;
 }
 
-__device__ __forceinline__ AxisTaps axis_taps_dyn(int axis, float coord, int n, int bnx, int bnxy)
+// offset (in voxels) of coordinate c along `axis` inside the staged brick block: local brick index * 512 + in-brick part
+template <int AXIS>
+__device__ __forceinline__ uint32_t staged_off(int c, const int* b0, const int* nb)
 {
-    return axis == 0 ? axis_taps<0>(coord, n, bnx, bnxy) : (axis == 1 ? axis_taps<1>(coord, n, bnx, bnxy) : axis_taps<2>(coord, n, bnx, bnxy));
+    const int lb = (c >> 3) - b0[AXIS];
+    const uint32_t stride = AXIS == 0 ? 1u : (AXIS == 1 ? (uint32_t) nb[0] : (uint32_t) (nb[0] * nb[1]));
+    const uint32_t inb = (uint32_t) (c & 7) << (3 * AXIS);
+    return (uint32_t) lb * stride * 512u + inb;
 }
 
-template <int DFMT, bool CHANGE>
-__global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p)
+template <int FMT>
+__device__ __forceinline__ float lds_voxel(const void* p, uint32_t i)
 {
-    constexpr int NS = CHANGE ? 2 : 1;
-    __shared__ float s_alpha[256];
-    __shared__ float s_w[2][kOccGroup], s_f[2][kOccGroup];
-    __shared__ uint32_t s_o0[2][kOccGroup], s_o1[2][kOccGroup];
-    __shared__ int s_flags[2][kOccGroup]; // bit0: tap0 in range, bit1: tap1 in range, bit2: w == saturate(w)
+    if constexpr (FMT == FMT_U8) return decode_u8(((const uint8_t*) p)[i]);
+    else if constexpr (FMT == FMT_U16) return decode_u16(((const uint16_t*) p)[i]);
+    else return ((const float*) p)[i];
+}
 
+// LDS bytes for the staged bricks: worst case over workgroups, from the ratio of data to light-volume resolution
+size_t occlusion_lds_bytes(const ChunkParams& p)
+{
     const int dim_u = p.axis == 0 ? 1 : 0, dim_v = p.axis == 2 ? 1 : 2, dim_s = p.axis;
+    const int dd[3] = {p.data.nx, p.data.ny, p.data.nz};
+    auto bricks = [&](int pixels, int dim) {
+        const double ratio = (double) dd[dim] / (double) p.lv_dims[dim];
+        const int texels = (int) ((pixels - 1) * ratio) + 2; // first base tap .. last +1 tap (a workgroup that needs one
+        return (texels - 1 + 7) / 8 + 1;                     // more brick than this reads its taps from global memory)
+    };
+    const size_t n = (size_t) bricks(kOccTile, dim_u) * bricks(kOccTile, dim_v) * bricks(kOccDepth, dim_s);
+    const size_t esz = p.data.fmt == FMT_U8 ? 1 : (p.data.fmt == FMT_U16 ? 2 : 4);
+    return n * 512 * esz;
+}
+
+template <int DFMT, bool CHANGE, int AXIS>
+__global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = CHANGE ? 2 : 1;
+    constexpr int ESZ = DFMT == FMT_U8 ? 1 : (DFMT == FMT_U16 ? 2 : 4);
+    __shared__ float s_alpha[256];
+    __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
+    __shared__ int s_i[2][kOccDepth], s_flags[2][kOccDepth]; // flags: bit0 tap0 in range, bit1 tap1 in range, bit2 w == saturate(w)
+    __shared__ int s_b0[3], s_nb[3], s_staged;
+
+    constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
     const int data_dims[3] = {p.data.nx, p.data.ny, p.data.nz};
-    const int k0 = blockIdx.z * kOccGroup;
+    const int px0 = blockIdx.x * kOccTile, py0 = blockIdx.y * kOccTile, k0 = blockIdx.z * kOccDepth;
+    const int nk = min(kOccDepth, p.n_steps - k0);
 
     s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
-    if (threadIdx.x < NS * kOccGroup) { // slice-axis taps of each step of this group (wave-uniform values)
-        const int si = threadIdx.x / kOccGroup, q = threadIdx.x % kOccGroup;
+    if (threadIdx.x < NS * kOccDepth) { // slice-axis taps of each step of this workgroup (wave-uniform values)
+        const int si = threadIdx.x / kOccDepth, q = threadIdx.x % kOccDepth;
         const ChunkStream& s = si == 0 ? p.a : p.r;
-        const int j = p.j0 + (k0 + q) * p.dir;
+        const int j = p.j0 + min(k0 + q, p.n_steps - 1) * p.dir;
         const float w = (((float) (uint32_t) j + 0.5f) / (float) (uint32_t) p.lv_dims[dim_s]) + s.uvw_off[dim_s];
-        const AxisTaps t = axis_taps_dyn(dim_s, w, data_dims[dim_s], p.data.bnx, p.data.bnxy);
-        s_w[si][q] = w; s_f[si][q] = t.f; s_o0[si][q] = t.off0; s_o1[si][q] = t.off1;
+        const AxisTaps t = axis_taps(w, data_dims[dim_s]);
+        s_w[si][q] = w; s_f[si][q] = t.f; s_i[si][q] = t.i0;
         s_flags[si][q] = (t.ok0 ? 1 : 0) | (t.ok1 ? 2 : 0) | ((w == saturate_(w)) ? 4 : 0);
+    }
+    if (threadIdx.x == 64) { // brick range the workgroup's samples can touch (union over the streams)
+        int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+        const int pxl = min(px0 + kOccTile, p.W) - 1, pyl = min(py0 + kOccTile, p.H) - 1;
+        for (int si = 0; si < NS; ++si) {
+            const ChunkStream& s = si == 0 ? p.a : p.r;
+            const int ends[3][2] = {{px0, pxl}, {py0, pyl}, {p.j0 + k0 * p.dir, p.j0 + (k0 + nk - 1) * p.dir}};
+            constexpr int dims[3] = {dim_u, dim_v, dim_s};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float c = (((float) (uint32_t) ends[a][e] + 0.5f) / (float) (uint32_t) p.lv_dims[dims[a]]) + s.uvw_off[dims[a]];
+                    int i0;
+                    float f;
+                    texel_split(c, (float) data_dims[dims[a]], i0, f);
+                    lo[dims[a]] = min(lo[dims[a]], i0);
+                    hi[dims[a]] = max(hi[dims[a]], i0 + 1);
+                }
+        }
+        const int bn[3] = {p.data.bnx, p.data.bnxy / p.data.bnx, (p.data.nz + 7) >> 3};
+        int count = 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int b_lo = max(lo[a] >> 3, 0), b_hi = min(hi[a] >> 3, bn[a] - 1);
+            s_b0[a] = b_lo;
+            s_nb[a] = max(b_hi - b_lo + 1, 0);
+            count *= s_nb[a];
+        }
+        s_staged = (count > 0 && count * 512 * ESZ <= lds_budget_bytes) ? 1 : 0; // else: read taps from global memory
     }
     __syncthreads();
 
+    const bool staged = s_staged && !(p.debug & 128);
+    const int b0[3] = {s_b0[0], s_b0[1], s_b0[2]}, nb[3] = {s_nb[0], s_nb[1], s_nb[2]};
+    if (staged) { // copy the bricks: 512*ESZ bytes each, 16 bytes per lane
+        constexpr int PIECES = 512 * ESZ / 16;
+        const int total = nb[0] * nb[1] * nb[2] * PIECES;
+        const int wave_base = (threadIdx.x >> 6) * 64, lane = threadIdx.x & 63;
+        for (int cb = wave_base; cb < total; cb += 256) {
+            const int c = cb + lane;
+            const int lb = c / PIECES, piece = c % PIECES;
+            const int lx = lb % nb[0], ly = (lb / nb[0]) % nb[1], lz = lb / (nb[0] * nb[1]);
+            const uint32_t gb = (uint32_t) ((b0[2] + lz) * p.data.bnxy + (b0[1] + ly) * p.data.bnx + (b0[0] + lx));
+            if (c < total) dma_16((const char*) p.data.data + ((size_t) gb * 512 * ESZ + (size_t) piece * 16), smem + (size_t) cb * 16);
+        }
+    }
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (px >= p.W || py >= p.H) return;
-    const size_t plane_elems = (size_t) p.H * p.W;
+    const int px = px0 + (wave & 1) * 8 + (lane & 7);
+    const int py = py0 + (wave >> 1) * 8 + (lane >> 3);
+    const bool pixel_ok = px < p.W && py < p.H;
+    const int plane_elems = p.H * p.W;
     const float border = p.data_border;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!pixel_ok) return;
+
+    // offset of voxel coordinate c along `axis`: in the staged block, or in the bricked global volume
+    auto voff = [&](int c, auto axis_c) -> uint32_t {
+        constexpr int axis = decltype(axis_c)::value;
+        const int n = data_dims[axis];
+        c = min(max(c, 0), n - 1); // clamped: out-of-range taps are replaced by the border colour after the load
+        if (staged) {
+            const int cb = min(max(c >> 3, b0[axis]), b0[axis] + nb[axis] - 1); // stay inside the staged block
+            return staged_off<axis>((cb << 3) | (c & 7), b0, nb);
+        }
+        return axis == 0 ? brick_off_x(c) : (axis == 1 ? brick_off_y(c, p.data.bnx) : brick_off_z(c, p.data.bnxy));
+    };
+    auto tap = [&](uint32_t off) -> float {
+        return staged ? lds_voxel<DFMT>(smem, off) : load_voxel<DFMT>(p.data.data, off);
+    };
 
 #pragma unroll
     for (int si = 0; si < NS; ++si) {
@@ -241,165 +348,133 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p)
         // GetUVW(pos, res) + UVWOffset (AddDirLightShader.usf:85): the two in-plane components
         const float u = (((float) (uint32_t) px + 0.5f) / (float) (uint32_t) p.lv_dims[dim_u]) + s.uvw_off[dim_u];
         const float v = (((float) (uint32_t) py + 0.5f) / (float) (uint32_t) p.lv_dims[dim_v]) + s.uvw_off[dim_v];
-        const AxisTaps tu = axis_taps_dyn(dim_u, u, data_dims[dim_u], p.data.bnx, p.data.bnxy);
-        const AxisTaps tv = axis_taps_dyn(dim_v, v, data_dims[dim_v], p.data.bnx, p.data.bnxy);
+        const AxisTaps tu = axis_taps(u, data_dims[dim_u]), tv = axis_taps(v, data_dims[dim_v]);
         const bool guard_uv = (u == saturate_(u)) && (v == saturate_(v));
-        // in-plane corner offsets and validity (u index is the faster of the two in the lerp order below only when
-        // dim_u < dim_v, which holds for every axis: (1,2), (0,2), (0,1))
-        const uint32_t o00 = tu.off0 + tv.off0, o10 = tu.off1 + tv.off0, o01 = tu.off0 + tv.off1, o11 = tu.off1 + tv.off1;
+        using AU = std::integral_constant<int, dim_u>; using AV = std::integral_constant<int, dim_v>; using AS = std::integral_constant<int, dim_s>;
+        const uint32_t u0 = voff(tu.i0, AU{}), u1 = voff(tu.i0 + 1, AU{}), v0 = voff(tv.i0, AV{}), v1 = voff(tv.i0 + 1, AV{});
+        const uint32_t o00 = u0 + v0, o10 = u1 + v0, o01 = u0 + v1, o11 = u1 + v1;
         const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
+        float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
 
-        float taps[kOccGroup][8], aw[kOccGroup];
-        bool sample[kOccGroup];
-#pragma unroll
-        for (int q = 0; q < kOccGroup; ++q) { // phase 1: issue every tap load of the group
-            sample[q] = false;
-            aw[q] = 0.0f;
-            if (k0 + q >= p.n_steps) continue;
-            const float w = s_w[si][q];
+        for (int q = 0; q < nk; ++q) {
+            const float w = s_w[si][q], fs = s_f[si][q];
             const int fl = s_flags[si][q];
+            float aw = 1.0f;
             if (p.clip_mode) {
                 float c0, c1, c2;
-                if (p.axis == 0) { c0 = w; c1 = u; c2 = v; } else if (p.axis == 1) { c0 = u; c1 = w; c2 = v; } else { c0 = u; c1 = v; c2 = w; }
-                aw[q] = clip_alpha_weight(c0, c1, c2, p.cc, p.cd, p.lv_dims);
-            } else aw[q] = 1.0f;
+                if (AXIS == 0) { c0 = w; c1 = u; c2 = v; } else if (AXIS == 1) { c0 = u; c1 = w; c2 = v; } else { c0 = u; c1 = v; c2 = w; }
+                aw = clip_alpha_weight(c0, c1, c2, p.cc, p.cd, p.lv_dims);
+            }
             bool inside = true;
             if constexpr (!CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
-            sample[q] = aw[q] > 0.0f && inside;
-            if (sample[q] && !(p.debug & 16)) {
-                const uint32_t w0 = s_o0[si][q], w1 = s_o1[si][q];
-                const bool a0 = fl & 1, a1 = fl & 2;
-                // tap t: bit0 = u tap, bit1 = v tap, bit2 = slice tap (re-ordered into x,y,z order in phase 2)
-                taps[q][0] = (k00 && a0) ? load_voxel<DFMT>(p.data.data, o00 + w0) : border;
-                taps[q][1] = (k10 && a0) ? load_voxel<DFMT>(p.data.data, o10 + w0) : border;
-                taps[q][2] = (k01 && a0) ? load_voxel<DFMT>(p.data.data, o01 + w0) : border;
-                taps[q][3] = (k11 && a0) ? load_voxel<DFMT>(p.data.data, o11 + w0) : border;
-                taps[q][4] = (k00 && a1) ? load_voxel<DFMT>(p.data.data, o00 + w1) : border;
-                taps[q][5] = (k10 && a1) ? load_voxel<DFMT>(p.data.data, o10 + w1) : border;
-                taps[q][6] = (k01 && a1) ? load_voxel<DFMT>(p.data.data, o01 + w1) : border;
-                taps[q][7] = (k11 && a1) ? load_voxel<DFMT>(p.data.data, o11 + w1) : border;
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) taps[q][t] = border;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < kOccGroup; ++q) { // phase 2: filter (x, then y, then z), window, transfer function, opacity correction
-            if (k0 + q >= p.n_steps) continue;
             float occ = 0.0f;
-            if (sample[q]) {
-                const float fs = s_f[si][q];
-                const float* t = taps[q];
-                float val;
-                if (p.axis == 2) { // (u,v,s) = (x,y,z)
-                    val = lerp_(lerp_(lerp_(t[0], t[1], tu.f), lerp_(t[2], t[3], tu.f), tv.f),
-                                lerp_(lerp_(t[4], t[5], tu.f), lerp_(t[6], t[7], tu.f), tv.f), fs);
-                } else if (p.axis == 1) { // (u,s,v) = (x,y,z): x = u, y = slice, z = v
-                    val = lerp_(lerp_(lerp_(t[0], t[1], tu.f), lerp_(t[4], t[5], tu.f), fs),
-                                lerp_(lerp_(t[2], t[3], tu.f), lerp_(t[6], t[7], tu.f), fs), tv.f);
-                } else { // (s,u,v) = (x,y,z): x = slice, y = u, z = v
-                    val = lerp_(lerp_(lerp_(t[0], t[4], fs), lerp_(t[1], t[5], fs), tu.f),
-                                lerp_(lerp_(t[2], t[6], fs), lerp_(t[3], t[7], fs), tu.f), tv.f);
+            if (aw > 0.0f && inside && !(p.debug & 16)) {
+                const uint32_t w0 = voff(s_i[si][q], AS{}), w1 = voff(s_i[si][q] + 1, AS{});
+                const bool a0 = fl & 1, a1 = fl & 2;
+                // tap t: bit0 = u tap, bit1 = v tap, bit2 = slice tap
+                const float t0 = (k00 && a0) ? tap(o00 + w0) : border, t1 = (k10 && a0) ? tap(o10 + w0) : border;
+                const float t2 = (k01 && a0) ? tap(o01 + w0) : border, t3 = (k11 && a0) ? tap(o11 + w0) : border;
+                const float t4 = (k00 && a1) ? tap(o00 + w1) : border, t5 = (k10 && a1) ? tap(o10 + w1) : border;
+                const float t6 = (k01 && a1) ? tap(o01 + w1) : border, t7 = (k11 && a1) ? tap(o11 + w1) : border;
+                float val; // filter x, then y, then z
+                if (AXIS == 2) { // (u,v,s) = (x,y,z)
+                    val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t2, t3, tu.f), tv.f), lerp_(lerp_(t4, t5, tu.f), lerp_(t6, t7, tu.f), tv.f), fs);
+                } else if (AXIS == 1) { // x = u, y = slice, z = v
+                    val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t4, t5, tu.f), fs), lerp_(lerp_(t2, t3, tu.f), lerp_(t6, t7, tu.f), fs), tv.f);
+                } else { // x = slice, y = u, z = v
+                    val = lerp_(lerp_(lerp_(t0, t4, fs), lerp_(t1, t5, fs), tu.f), lerp_(lerp_(t2, t6, fs), lerp_(t3, t7, fs), tu.f), tv.f);
                 }
-                occ = (p.debug & 32) ? val : windowed_alpha(val, s.step100, s_alpha, p.win) * aw[q];
+                occ = (p.debug & 32) ? val : windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
             }
-            s.occ_next[(size_t) (k0 + q) * plane_elems + (size_t) py * p.W + px] = occ;
+            out[q * plane_elems] = occ;
         }
     }
 }
 
 // ---- k_light_chain: one tile through the slices of the chunk ---------------------------------------------------
+// Everything a slice needs is in LDS before the slice starts: the propagated-light windows, the occlusion of the
+// window (staged kOccRing slices ahead with asynchronous 16-byte global->LDS copies) and, for UNORM8 light volumes,
+// the tile's light-volume bricks (loaded once, read-modify-written in LDS, stored once). Per slice a workgroup
+// issues a handful of wide vector-memory instructions instead of ~100 narrow ones — the narrow ones, not HBM
+// bandwidth, were what bounded the first versions of this kernel.
 
-// asynchronous global -> LDS copy of one dword per lane: lane l of the wave lands at lds_wave_base + 4*l
-__device__ __forceinline__ void dma_dword(const float* src, float* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
-                                     (__attribute__((address_space(3))) void*) lds_wave_base, 4, 0, 0);
-}
-
-constexpr int kPrefetch = 3; // slices the occlusion / light-volume operands are fetched ahead of their use
-
-template <int LFMT, bool CHANGE>
+template <int LFMT, bool CHANGE, int AXIS>
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = kChunkTile;
     constexpr int NS = CHANGE ? 2 : 1;
+    constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KH = (kChunkMaxHull * kChunkMaxHull - T * T + kChunkThreads - 1) / kChunkThreads; // halo slots per thread
     constexpr int KS = 1 + KH;                                                                     // + the owned pixel
-    const int tile_x = p.tile_i0 + (int) blockIdx.x, tile_y = p.tile_j0 + (int) blockIdx.y;
-    const ChunkGeom g = chunk_geometry(p, tile_x, tile_y);
+    const ChunkGeom g = chunk_geometry(p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_base = wave * 64;
-    const size_t plane_elems = (size_t) p.H * p.W;
-    const int base_x = tile_x * T, base_y = tile_y * T;
-    const int n_slots = g.HX * g.HY;
+    const int plane_elems = p.H * p.W;
+    const int base_x = (int) blockIdx.x * T, base_y = (int) blockIdx.y * T;
 
     int stamp = 0;
     auto tick = [&]() { if ((p.debug & 64) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && stamp < 64) p.debug_clock[stamp++] = (long long) __builtin_amdgcn_s_memtime(); };
     tick();
 
-    char* cursor = smem;
-    float* win0[2]; // win0[si] + cur*win_stride = the window holding the state before the step
-    float* tabx_f[2]; int* tabx_d[2]; float* taby_f[2]; int* taby_d[2];
-    const int win_stride = (int) ((((size_t) n_slots + 64) * 4 + 15) & ~(size_t) 15) / 4;
-#pragma unroll
-    for (int si = 0; si < NS; ++si) {
-        win0[si] = (float*) carve(cursor, ((size_t) n_slots + 64) * 4);
-        (void) carve(cursor, ((size_t) n_slots + 64) * 4);
-        tabx_f[si] = (float*) carve(cursor, g.tablx * 4); tabx_d[si] = (int*) carve(cursor, g.tablx * 4);
-        taby_f[si] = (float*) carve(cursor, g.tably * 4); taby_d[si] = (int*) carve(cursor, g.tably * 4);
-    }
+    // LDS map (floats): stream si: [win 0][win 1][occ ring 0..2]; then the light-volume tile (bytes)
+    float* const lds = (float*) smem;
+    const int stream_stride = (2 + kOccRing) * g.elems;
+    uint8_t* const lv_tile = (uint8_t*) (lds + NS * stream_stride);
 
-    // ---- input window: the plane after the previous chunk (ownership frame of r = n), row-major over the hull -----
-    {
-        const float inv_hx = 1.0f / (float) g.HX;
-        for (int eb = wave_base; eb < n_slots; eb += kChunkThreads) {
-            const int e = eb + lane;
-            const int ly = (int) (((float) e + 0.5f) * inv_hx), lx = e - ly * g.HX; // exact for e < 2^20
-            const int px = base_x + g.n * p.cx + (lx - g.padx), py = base_y + g.n * p.cy + (ly - g.pady);
-            const bool inplane = e < n_slots && (unsigned) px < (unsigned) p.W && (unsigned) py < (unsigned) p.H;
-#pragma unroll
-            for (int si = 0; si < NS; ++si) {
-                const ChunkStream& s = si == 0 ? p.a : p.r;
-                if (inplane && !p.first_chunk) dma_dword(s.plane_in + (size_t) py * p.W + px, win0[si] + eb);
-                else if (e < n_slots) win0[si][e] = inplane ? s.init_value : s.border_light;
-            }
+    // ---- 16-byte staging pattern: thread t copies floats [4t, 4t+4) of an LDS plane = 4 pixels of one hull row ------
+    const int gpr = g.HXp >> 2;                               // copy groups per row
+    const int st_row = (int) (((float) threadIdx.x + 0.5f) * (1.0f / (float) gpr)); // exact: both < 2^11
+    const int st_col = (threadIdx.x - st_row * gpr) * 4;
+    const int st_py = base_y - g.pady + st_row;
+    const int st_src = st_py * p.W + base_x - g.padx + st_col; // may run off the row ends: the planes have guard bands
+    const bool st_ok = st_row < g.HY && (unsigned) st_py < (unsigned) p.H;
+    const int st_dst = wave * 256;                            // this wave's 64 x 4 floats
+    auto stage_occ = [&](int sf) {
+        if (sf < g.n && st_ok && !(p.debug & 4)) {
+            float* dst = lds + 2 * g.elems + (sf % kOccRing) * g.elems + st_dst;
+            dma_16(p.a.occ_cur + sf * plane_elems + st_src, dst);
+            if constexpr (CHANGE) dma_16(p.r.occ_cur + sf * plane_elems + st_src, dst + stream_stride);
+        }
+    };
+
+    // ---- input state: the plane after the previous chunk ------------------------------------------------------------
+    if (!p.first_chunk && st_ok) {
+        dma_16(p.a.plane_in + st_src, lds + st_dst);
+        if constexpr (CHANGE) dma_16(p.r.plane_in + st_src, lds + stream_stride + st_dst);
+    }
+    stage_occ(0);
+    stage_occ(1);
+    stage_occ(2);
+
+    // ---- light-volume tile: the 4x4 brick columns under the tile, every brick layer the chunk touches --------------
+    constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
+    const int lbn[3] = {p.lv_bnx, p.lv_bnxy / p.lv_bnx, (p.lv_dims[2] + 7) >> 3};
+    auto tile_brick_global = [&](int lb, bool& exists) -> uint32_t { // lb = (layer*4 + bv)*4 + bu
+        const int bu = (base_x >> 3) + (lb & 3), bv = (base_y >> 3) + ((lb >> 2) & 3), bl = g.lv_layer0 + (lb >> 4);
+        exists = bu < lbn[dim_u] && bv < lbn[dim_v] && bl < lbn[dim_s];
+        int b3[3];
+        b3[dim_u] = bu; b3[dim_v] = bv; b3[dim_s] = bl;
+        return (uint32_t) ((b3[2] * lbn[1] + b3[1]) * lbn[0] + b3[0]) * 512u;
+    };
+    if constexpr (LV_LDS) {
+        const int chunks = 16 * g.lv_layers * 32; // 16-byte pieces
+        for (int cb = wave * 64; cb < chunks; cb += kChunkThreads) {
+            const int c = cb + lane;
+            bool exists;
+            const uint32_t gofs = tile_brick_global(c >> 5, exists) + (uint32_t) (c & 31) * 16u;
+            if (c < chunks && exists) dma_16((const uint8_t*) p.light + gofs, lv_tile + cb * 16);
         }
     }
-    // previous-slice tap split per plane coordinate: ((c + 0.5)/size + PrevPixelOffset) -> (tap - c, frac)
-    // (AddDirLightShader.usf:81-82); depends only on the coordinate, so one table per axis replaces a division per voxel.
-#pragma unroll
-    for (int si = 0; si < NS; ++si) {
-        const ChunkStream& s = si == 0 ? p.a : p.r;
-        for (int k = threadIdx.x; k < g.tablx + g.tably; k += kChunkThreads) {
-            const bool is_x = k < g.tablx;
-            const int kk = is_x ? k : k - g.tablx;
-            const int c = (is_x ? g.tabx0 : g.taby0) + kk;
-            const int size = is_x ? p.W : p.H;
-            int d = 0;
-            float f = 0.0f;
-            if (c >= 0 && c < size) {
-                const float pu = (((float) (uint32_t) c + 0.5f) / (float) size) + (is_x ? s.off_u : s.off_v);
-                int i0;
-                texel_split(pu, (float) size, i0, f);
-                d = i0 - c;
-            }
-            if (is_x) { tabx_f[si][kk] = f; tabx_d[si][kk] = d; }
-            else { taby_f[si][kk] = f; taby_d[si][kk] = d; }
-        }
-    }
-    tick();
 
-    // ---- this thread's slots: slot 0 = its owned pixel (8x8 patch per wave over the 32x32 core), the rest = its share
-    // of the halo (hull minus core), in ownership-frame coordinates
+    // ---- this thread's slots: slot 0 = its owned pixel (8x8 patch per wave over the 32x32 tile), the rest = its share of
+    // the halo (hull minus tile). A slot's pixel, window index, tap offsets and weights never change during the chunk.
     int sqx[KS], sqy[KS];
     sqx[0] = (wave & 3) * 8 + (lane & 7);
     sqy[0] = (wave >> 2) * 8 + (lane >> 3);
     {
-        // halo slots enumerated as: full rows above the core, the two side strips of the core rows, full rows below
+        // halo slots enumerated as: full rows above the tile, the two side strips of the tile rows, full rows below
         const int top = g.pady * g.HX, side = g.HX - T, mid = T * side;
-        const int n_halo = n_slots - T * T;
+        const int n_halo = g.HX * g.HY - T * T;
         const float inv_hx = 1.0f / (float) g.HX, inv_side = side > 0 ? 1.0f / (float) side : 0.0f;
 #pragma unroll
         for (int k = 0; k < KH; ++k) {
@@ -421,127 +496,191 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             sqy[1 + k] = ly - g.pady;
         }
     }
-
-    // ---- per-slot running state: the pixel of slot k at step s is (base + r*c + q) with r = n-1-s, so from one slice
-    // to the next every per-slot quantity changes by a constant ---------------------------------------------------
-    int pxc[KS], pyc[KS];   // pixel at the step being computed
-    int pxf[KS], pyf[KS];   // pixel at the step being fetched (kPrefetch slices ahead)
-    int idxf[KS];           // its index into the occlusion plane stack
-    int li[KS];             // LDS index of the slot inside a window (constant)
+    int rmin[KS];          // the slot is inside the window while r >= rmin (huge: never / outside the buffer)
+    int li[KS];            // LDS index of the slot inside a plane
+    int tap[NS][KS];       // LDS offset of the first previous-slice tap relative to li
+    float wfx[NS][KS], wfy[NS][KS]; // bilinear weights of the previous-slice fetch
+    bool off_plane[KS];    // inside the hull but outside the buffer: holds the border colour
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
-        pxc[k] = pxf[k] = base_x + (g.n - 1) * p.cx + sqx[k];
-        pyc[k] = pyf[k] = base_y + (g.n - 1) * p.cy + sqy[k];
-        idxf[k] = pyf[k] * p.W + pxf[k];
-        li[k] = (sqy[k] + g.pady) * g.HX + sqx[k] + g.padx;
-    }
-    const int idx_step = (int) plane_elems - p.cy * p.W - p.cx;
-
-    // operands fetched kPrefetch slices ahead: occlusion per slot and stream, the light-volume voxel of the owned pixel
-    float occ_q[kPrefetch][NS][KS];
-    float lv_q[kPrefetch];
-    uint32_t lva_q[kPrefetch]; // voxel offset of that light-volume voxel, reused by the store
-    int sf = 0;                // step being fetched
-    auto fetch = [&](float (&occ)[NS][KS], float& lv, uint32_t& lva) {
-        const int r = g.n - 1 - sf;
-        const int x_lo = r * g.lox, x_hi = T + r * g.hix, y_lo = r * g.loy, y_hi = T + r * g.hiy;
-        const bool live = sf < g.n && !(p.debug & 4);
-        lv = 0.0f;
-        lva = 0;
+        const int qx = sqx[k], qy = sqy[k];
+        const int px = base_x + qx, py = base_y + qy;
+        const bool valid = qx > INT32_MIN / 4;
+        const bool inplane = valid && (unsigned) px < (unsigned) p.W && (unsigned) py < (unsigned) p.H;
+        int need = 0; // smallest r whose window contains the slot
+        if (qx < 0) need = max(need, g.lox < 0 ? (-qx + (-g.lox) - 1) / (-g.lox) : INT32_MAX / 2);
+        if (qx >= T) need = max(need, g.hix > 0 ? (qx - T + g.hix) / g.hix : INT32_MAX / 2);
+        if (qy < 0) need = max(need, g.loy < 0 ? (-qy + (-g.loy) - 1) / (-g.loy) : INT32_MAX / 2);
+        if (qy >= T) need = max(need, g.hiy > 0 ? (qy - T + g.hiy) / g.hiy : INT32_MAX / 2);
+        rmin[k] = inplane ? need : INT32_MAX / 2;
+        off_plane[k] = valid && !inplane;
+        li[k] = valid ? (qy + g.pady) * g.HXp + qx + g.padx : 0;
 #pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            bool active = live && (unsigned) pxf[k] < (unsigned) p.W && (unsigned) pyf[k] < (unsigned) p.H;
-            if (k > 0) active = active && sqx[k] >= x_lo && sqx[k] < x_hi && sqy[k] >= y_lo && sqy[k] < y_hi;
-            occ[0][k] = active ? p.a.occ_cur[idxf[k]] : 0.0f;
-            if constexpr (CHANGE) occ[NS - 1][k] = active ? p.r.occ_cur[idxf[k]] : 0.0f;
-            if (k == 0 && active && !(p.debug & 8)) {
-                const int j = p.j0 + sf * p.dir;
-                int x, y, z;
-                if (p.axis == 0) { x = j; y = pxf[0]; z = pyf[0]; } else if (p.axis == 1) { x = pxf[0]; y = j; z = pyf[0]; } else { x = pxf[0]; y = pyf[0]; z = j; }
-                lva = brick_off(x, y, z, p.lv_bnx, p.lv_bnxy);
-                lv = load_voxel<LFMT>(p.light, lva);
+        for (int si = 0; si < NS; ++si) {
+            // previous-slice tap split: ((c + 0.5)/size + PrevPixelOffset) -> (tap - c, frac) (AddDirLightShader.usf:81-82)
+            const ChunkStream& s = si == 0 ? p.a : p.r;
+            int ix = 0, iy = 0;
+            float fx = 0.0f, fy = 0.0f;
+            if (inplane) {
+                texel_split((((float) (uint32_t) px + 0.5f) / (float) p.W) + s.off_u, (float) p.W, ix, fx);
+                texel_split((((float) (uint32_t) py + 0.5f) / (float) p.H) + s.off_v, (float) p.H, iy, fy);
+                ix -= px;
+                iy -= py;
             }
-            pxf[k] -= p.cx;
-            pyf[k] -= p.cy;
-            idxf[k] += idx_step;
+            tap[si][k] = iy * g.HXp + ix;
+            wfx[si][k] = fx;
+            wfy[si][k] = fy;
         }
-        ++sf;
+    }
+    const int own_idx = (base_y + sqy[0]) * p.W + base_x + sqx[0]; // owned pixel inside a plane
+
+    // the owned pixel's voxel: constant in-plane part + per-slice part, as an offset into the bricked global volume
+    // (float light volumes) or into the LDS tile (UNORM8)
+    uint32_t lv_const = 0;
+    {
+        const int px = base_x + sqx[0], py = base_y + sqy[0];
+        if constexpr (LV_LDS) {
+            const uint32_t lb = (uint32_t) ((sqy[0] >> 3) * 4 + (sqx[0] >> 3)) * 512u;
+            if (AXIS == 0) lv_const = lb + (uint32_t) (py & 7) * 64u + (uint32_t) (px & 7) * 8u;
+            else if (AXIS == 1) lv_const = lb + (uint32_t) (py & 7) * 64u + (uint32_t) (px & 7);
+            else lv_const = lb + (uint32_t) (py & 7) * 8u + (uint32_t) (px & 7);
+        } else {
+            if (AXIS == 0) lv_const = brick_off_y(px, p.lv_bnx) + brick_off_z(py, p.lv_bnxy);
+            else if (AXIS == 1) lv_const = brick_off_x(px) + brick_off_z(py, p.lv_bnxy);
+            else lv_const = brick_off_x(px) + brick_off_y(py, p.lv_bnx);
+        }
+    }
+    auto lv_slice_off = [&](int j) -> uint32_t {
+        if constexpr (LV_LDS) {
+            const uint32_t layer = (uint32_t) ((j >> 3) - g.lv_layer0) * 16u * 512u;
+            return layer + (uint32_t) (j & 7) * (AXIS == 0 ? 1u : (AXIS == 1 ? 8u : 64u));
+        } else {
+            return AXIS == 0 ? brick_off_x(j) : (AXIS == 1 ? brick_off_y(j, p.lv_bnx) : brick_off_z(j, p.lv_bnxy));
+        }
     };
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's global->LDS copies of the input window have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's copies (input window, first occlusion planes, tile) have landed
     __syncthreads();
+    // slots outside the buffer hold the read sampler's border colour in BOTH windows for the whole chunk
+    // (AddDirLightShader.usf:22-25); in the first chunk the buffers were just cleared to the initial light
 #pragma unroll
-    for (int d = 0; d < kPrefetch; ++d) fetch(occ_q[d], lv_q[d], lva_q[d]);
+    for (int k = 0; k < KS; ++k) {
+#pragma unroll
+        for (int si = 0; si < NS; ++si) {
+            const ChunkStream& s = si == 0 ? p.a : p.r;
+            float* w0 = lds + si * stream_stride;
+            if (off_plane[k]) { w0[li[k]] = s.border_light; w0[g.elems + li[k]] = s.border_light; }
+            else if (p.first_chunk && rmin[k] < INT32_MAX / 2) w0[li[k]] = s.init_value;
+        }
+    }
+    __syncthreads();
     tick();
 
-    const int stream_stride = (int) (win0[NS - 1] - win0[0]);
-    int cur = 0; // window holding the state BEFORE the step
-    for (int s = 0; s < g.n; ++s) {
-        const int r = g.n - 1 - s; // steps that remain after this one
-        const int x_lo = r * g.lox, x_hi = T + r * g.hix, y_lo = r * g.loy, y_hi = T + r * g.hiy;
-        const float* wr = win0[0] + cur * win_stride;  // state before the step (stream 0)
-        float* ww = win0[0] + (cur ^ 1) * win_stride;  // state after the step (stream 0)
+    // float light volumes: the owned voxel is fetched kOccRing slices ahead into registers
+    float lvq[kOccRing] = {0.0f, 0.0f, 0.0f};
+    auto fetch_lv = [&](int sf) -> float {
+        if constexpr (LV_LDS) return 0.0f;
+        else return (sf < g.n && rmin[0] == 0) ? load_voxel<LFMT>(p.light, lv_const + lv_slice_off(p.j0 + sf * p.dir)) : 0.0f;
+    };
+    lvq[0] = fetch_lv(0); lvq[1] = fetch_lv(1); lvq[2] = fetch_lv(2);
+
+    // one slice: window `cur` holds the state before it, occlusion ring slot `ring` its opacity samples
+    auto step = [&](int s, int cur, int ring, float lv_reg) {
+        const int r = g.n - 1 - s; // slices that remain after this one
+        const float* wr = lds + cur * g.elems;
+        float* ww = lds + (cur ^ 1) * g.elems;
+        const float* oc = lds + (2 + ring) * g.elems;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const int px = pxc[k], py = pyc[k];
-            pxc[k] -= p.cx;
-            pyc[k] -= p.cy;
-            if (k > 0 && (sqx[k] < x_lo || sqx[k] >= x_hi || sqy[k] < y_lo || sqy[k] >= y_hi || (p.debug & 2))) continue;
-            if ((unsigned) px < (unsigned) p.W && (unsigned) py < (unsigned) p.H) {
-                const int kx = px - g.tabx0, ky = py - g.taby0;
-                float lval[NS];
+            if (r < rmin[k] || (k > 0 && (p.debug & 2))) continue;
+            float lval[NS];
 #pragma unroll
-                for (int si = 0; si < NS; ++si) {
-                    // previous slice, bilinear with border colour (AddDirLightShader.usf:81-82)
-                    const float* pw = wr + si * stream_stride + li[k] + (taby_d[si][ky] - p.cy) * g.HX + (tabx_d[si][kx] - p.cx);
-                    const float fx = tabx_f[si][kx], fy = taby_f[si][ky];
-                    const float prev = lerp_(lerp_(pw[0], pw[1], fx), lerp_(pw[g.HX], pw[g.HX + 1], fx), fy);
-                    const float l = prev * (1 - occ_q[0][si][k]); // :117
-                    lval[si] = l;
-                    ww[si * stream_stride + li[k]] = through_format<LFMT>(l); // WriteBuffer[PixelLoc] = L (:120)
-                }
-                if (k == 0) { // the owned pixel: this workgroup writes its light-volume voxel
-                    if (p.debug & 1) {
-                    } else if constexpr (!CHANGE) {
-                        if (fabsf(lval[0]) > 1e-3f) store_voxel<LFMT>(p.light, lva_q[0], lv_q[0] + (lval[0] * p.b_added)); // :123-126
+            for (int si = 0; si < NS; ++si) {
+                // previous slice, bilinear with border colour (AddDirLightShader.usf:81-82)
+                const float* pw = wr + si * stream_stride + li[k] + tap[si][k];
+                const float prev = lerp_(lerp_(pw[0], pw[1], wfx[si][k]), lerp_(pw[g.HXp], pw[g.HXp + 1], wfx[si][k]), wfy[si][k]);
+                const float l = prev * (1 - oc[si * stream_stride + li[k]]); // :117
+                lval[si] = l;
+                ww[si * stream_stride + li[k]] = through_format<LFMT>(l); // WriteBuffer[PixelLoc] = L (:120)
+            }
+            if (k == 0) { // the owned pixel: this workgroup writes its light-volume voxel
+                const uint32_t vi = lv_const + lv_slice_off(p.j0 + s * p.dir);
+                float delta;
+                bool write;
+                if constexpr (!CHANGE) { delta = lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }      // :123-126
+                else { delta = 0.0f; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }                          // Change :152
+                if (write && !(p.debug & 1)) {
+                    if constexpr (LV_LDS) {
+                        const float old = decode_u8(lv_tile[vi]);
+                        const float nv = CHANGE ? old + lval[0] - lval[NS - 1] : old + delta;                  // :126 / Change :154
+                        lv_tile[vi] = (uint8_t) encode_u8(nv);
                     } else {
-                        const float la = lval[0], lr = lval[NS - 1];
-                        if (fabsf(la - lr) > 1e-3f) store_voxel<LFMT>(p.light, lva_q[0], lv_q[0] + la - lr); // Change :152-154
-                    }
-                    if (r == 0) {
-#pragma unroll
-                        for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[(size_t) py * p.W + px] = through_format<LFMT>(lval[si]);
+                        const float nv = CHANGE ? lv_reg + lval[0] - lval[NS - 1] : lv_reg + delta;
+                        store_voxel<LFMT>(p.light, vi, nv);
                     }
                 }
-            } else { // outside the buffer: later fetches must see the sampler's border colour here
+                if (r == 0) {
 #pragma unroll
-                for (int si = 0; si < NS; ++si) ww[si * stream_stride + li[k]] = (si == 0 ? p.a : p.r).border_light;
+                    for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[own_idx] = through_format<LFMT>(lval[si]);
+                }
             }
         }
-        // rotate the prefetch queue and refill its tail
+    };
+
+    static_assert(kOccRing == 3, "the slice loop below is unrolled for a ring of three");
+    // Per slice: compute, then refill the ring slot just consumed with the slice three ahead. Before the barrier each
+    // wave waits until at most the two youngest refills (2*NS copies) are still in flight, i.e. the next slice's
+    // occlusion has landed (copies complete in issue order).
+    for (int s0 = 0; s0 < g.n; s0 += 6) {
 #pragma unroll
-        for (int d = 0; d + 1 < kPrefetch; ++d) {
-            lv_q[d] = lv_q[d + 1];
-            lva_q[d] = lva_q[d + 1];
-#pragma unroll
-            for (int si = 0; si < NS; ++si)
-#pragma unroll
-                for (int k = 0; k < KS; ++k) occ_q[d][si][k] = occ_q[d + 1][si][k];
+        for (int u = 0; u < 6; ++u) {
+            const int s = s0 + u;
+            if (s < g.n) {
+                step(s, u & 1, u % 3, lvq[u % 3]);
+                lvq[u % 3] = fetch_lv(s + 3);
+            }
+            __syncthreads(); // every wave is done reading ring slot u%3 and window u&1
+            stage_occ(s + 3);
+            // loads (incl. global->LDS copies) complete in issue order: with at most the loads of the two youngest
+            // refills outstanding, the copies for slice s+1 have landed
+            if constexpr (LV_LDS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS + 1)) : "memory");
+            __syncthreads(); // slice s+1's occlusion is visible to every wave
+            tick();
         }
-        fetch(occ_q[kPrefetch - 1], lv_q[kPrefetch - 1], lva_q[kPrefetch - 1]);
-        __syncthreads();
-        cur ^= 1;
-        tick();
+    }
+
+    // ---- write the tile's light-volume bricks back ----------------------------------------------------------------
+    if constexpr (LV_LDS) {
+        const int chunks = 16 * g.lv_layers * 32;
+        for (int c = threadIdx.x; c < chunks; c += kChunkThreads) {
+            bool exists;
+            const uint32_t gofs = tile_brick_global(c >> 5, exists) + (uint32_t) (c & 31) * 16u;
+            if (exists && !(p.debug & 1)) *(uint4*) ((uint8_t*) p.light + gofs) = *(const uint4*) (lv_tile + c * 16);
+        }
     }
 }
 
+template <int DFMT, bool CHANGE, int AXIS>
+static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
+{
+    const dim3 grid((p.W + kOccTile - 1) / kOccTile, (p.H + kOccTile - 1) / kOccTile, (p.n_steps + kOccDepth - 1) / kOccDepth), block(256);
+    size_t lds = occlusion_lds_bytes(p);
+    if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
+    static bool attr = false;
+    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_occlusion<DFMT, CHANGE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_light_occlusion<DFMT, CHANGE, AXIS>), grid, block, lds, s, p, (int) lds);
+    return hipGetLastError();
+}
+template <int DFMT, bool CHANGE>
+static hipError_t launch_occ2(const ChunkParams& p, hipStream_t s)
+{
+    return p.axis == 0 ? launch_occ3<DFMT, CHANGE, 0>(p, s) : (p.axis == 1 ? launch_occ3<DFMT, CHANGE, 1>(p, s) : launch_occ3<DFMT, CHANGE, 2>(p, s));
+}
 template <int DFMT>
 static hipError_t launch_occ1(const ChunkParams& p, bool change, hipStream_t s)
 {
-    const dim3 grid((p.W + 15) / 16, (p.H + 15) / 16, (p.n_steps + kOccGroup - 1) / kOccGroup), block(256);
-    if (change) hipLaunchKernelGGL((k_light_occlusion<DFMT, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_light_occlusion<DFMT, false>), grid, block, 0, s, p);
-    return hipGetLastError();
+    return change ? launch_occ2<DFMT, true>(p, s) : launch_occ2<DFMT, false>(p, s);
 }
 // computes the occlusion of the chunk described by (j0, n_steps) into {a,r}.occ_next
 hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s)
@@ -554,14 +693,19 @@ hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t
     }
 }
 
+template <int LFMT, bool CHANGE, int AXIS>
+static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
+    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
+    return hipGetLastError();
+}
 template <int LFMT, bool CHANGE>
 static hipError_t launch_chain2(const ChunkParams& p, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    const size_t lds = chunk_lds_bytes(p, CHANGE);
-    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
-    return hipGetLastError();
+    return p.axis == 0 ? launch_chain3<LFMT, CHANGE, 0>(p, s) : (p.axis == 1 ? launch_chain3<LFMT, CHANGE, 1>(p, s) : launch_chain3<LFMT, CHANGE, 2>(p, s));
 }
 // advances every tile through the chunk (j0, n_steps), reading {a,r}.occ_cur
 hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s)
