@@ -186,6 +186,8 @@ TBRM_API int tbrm_set_tf_lut(tbrm_resources* res, const float* rgba_256x4);
 TBRM_API int tbrm_color_curve_to_lut(const float* key_times[4], const float* key_values[4],
                                      const int32_t n_keys[4], float* out_rgba_256x4);
 TBRM_API int tbrm_make_default_tf_lut(float* out_rgba_256x4);
+/* What tbrm_set_tf_lut stores: every sample rounded to FFloat16 and widened back (no GPU needed). */
+TBRM_API int tbrm_host_bake_tf_lut(const float* rgba_256x4, float* out_rgba_256x4);
 
 /* FBasicRaymarchRenderingResources::WindowingParameters. */
 TBRM_API int tbrm_set_windowing(tbrm_resources* res, const tbrm_windowing_params* windowing);
@@ -241,6 +243,10 @@ TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's
  * stream; blocks until that work is complete. kind: 0 = add/change/clear (illumination), 1 = raymarch.  */
 TBRM_API int tbrm_last_gpu_time_ms(tbrm_resources* res, int kind, float* out_ms);
+
+/* Self-test of the kernels' UNORM decode: writes decode(c) for every 8-bit code (256 floats) and every 16-bit code
+ * (65536 floats) as evaluated ON THE DEVICE, so a test can compare them with IEEE c/255 and c/65535. */
+TBRM_API int tbrm_selftest_unorm_decode(int device, float* out_u8_256, float* out_u16_65536);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* host parameter math, no GPU needed (LightingShaderUtils.cpp:29-265, LightingShaders.cpp:48-131)     */

@@ -107,11 +107,11 @@ SYMBOLS = [
     "tbrm_version", "tbrm_last_error", "tbrm_device_count",
     "tbrm_resources_create", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
-    "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_set_windowing",
+    "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
     "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_selftest_unorm_decode", "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
@@ -150,6 +150,7 @@ def load():
     lib.tbrm_set_tf_lut.argtypes = [vp, vp]
     lib.tbrm_color_curve_to_lut.argtypes = [P(vp * 4), P(vp * 4), P(C.c_int32 * 4), vp]
     lib.tbrm_make_default_tf_lut.argtypes = [vp]
+    lib.tbrm_host_bake_tf_lut.argtypes = [vp, vp]
     lib.tbrm_set_windowing.argtypes = [vp, P(WindowingParams)]
     lib.tbrm_add_dir_light.argtypes = [vp, P(DirLightParams), C.c_int, P(WorldParams), P(C.c_int), C.c_int]
     lib.tbrm_change_dir_light.argtypes = [vp, P(DirLightParams), P(DirLightParams), P(WorldParams), P(C.c_int)]
@@ -161,6 +162,7 @@ def load():
     lib.tbrm_upload_light_volume.argtypes = [vp, vp, C.c_size_t]
     lib.tbrm_light_volume_device_ptr.argtypes = [vp, P(vp), P(C.c_size_t)]
     lib.tbrm_launch_counters.argtypes = [vp, P(C.c_uint64 * 3)]
+    lib.tbrm_selftest_unorm_decode.argtypes = [C.c_int, vp, vp]
     lib.tbrm_flush.argtypes = [vp]
     lib.tbrm_stream.argtypes = [vp, P(vp)]
     lib.tbrm_last_gpu_time_ms.argtypes = [vp, C.c_int, P(C.c_float)]
@@ -239,6 +241,19 @@ def make_default_tf_lut():
     out = np.empty((256, 4), dtype=np.float32)
     check(load().tbrm_make_default_tf_lut(out.ctypes.data))
     return out
+
+
+def host_bake_tf_lut(lut):
+    lut = np.ascontiguousarray(lut, dtype=np.float32).reshape(256, 4)
+    out = np.empty_like(lut)
+    check(load().tbrm_host_bake_tf_lut(lut.ctypes.data, out.ctypes.data))
+    return out
+
+
+def selftest_unorm_decode(device=0):
+    u8, u16 = np.empty(256, dtype=np.float32), np.empty(65536, dtype=np.float32)
+    check(load().tbrm_selftest_unorm_decode(device, u8.ctypes.data, u16.ctypes.data))
+    return u8, u16
 
 
 def device_count():

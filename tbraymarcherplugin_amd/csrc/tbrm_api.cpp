@@ -669,6 +669,13 @@ int tbrm_make_default_tf_lut(float* out)
     return TBRM_OK;
 }
 
+int tbrm_host_bake_tf_lut(const float* rgba_256x4, float* out)
+{
+    if (!rgba_256x4 || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    host_bake_tf(rgba_256x4, out);
+    return TBRM_OK;
+}
+
 int tbrm_set_windowing(tbrm_resources* r, const tbrm_windowing_params* w)
 {
     if (!r || !w) return fail(TBRM_ERR_INVALID_ARG, "null argument");
@@ -811,6 +818,20 @@ int tbrm_light_volume_device_ptr(tbrm_resources* r, void** out_ptr, size_t* out_
     if (!r || !out_ptr) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     *out_ptr = r->d_light; // bricked layout (DESIGN.md "Data layout")
     if (out_bytes) *out_bytes = r->light_bricked_bytes;
+    return TBRM_OK;
+}
+
+int tbrm_selftest_unorm_decode(int device, float* out_u8_256, float* out_u16_65536)
+{
+    if (!out_u8_256 || !out_u16_65536) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**) &d, (256 + 65536) * sizeof(float)));
+    hipError_t e = launch_selftest_decode(d, d + 256, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_u8_256, d, 256 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_u16_65536, d + 256, 65536 * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    HIP_TRY(e);
     return TBRM_OK;
 }
 

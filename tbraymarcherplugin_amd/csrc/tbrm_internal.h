@@ -154,6 +154,7 @@ constexpr int kChunkThreads = 1024;
 constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
 
 // launchers (tbrm_kernels.hip, tbrm_light_kernels.hip)
+hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)

@@ -367,6 +367,18 @@ hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
+__global__ void k_selftest_decode(float* u8, float* u16)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < 256) u8[c] = decode_u8(c);
+    if (c < 65536) u16[c] = decode_u16(c);
+}
+hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_decode, dim3(256), dim3(256), 0, s, d_u8, d_u16);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // linear (UVolumeTexture mip, x fastest) <-> bricked. One workgroup per brick; the linear side is read/written as
 // eight-voxel rows, the bricked side as one contiguous 512-voxel run.

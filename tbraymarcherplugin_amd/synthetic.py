@@ -127,8 +127,10 @@ def _keys(rows):
 # TF-A "dense": low opacity, most rays traverse the whole cube
 TF_A_KEYS = _keys([(0.0, 0, 0, 0, 0), (0.25, .8, .4, .3, 0), (0.45, .9, .6, .5, .02), (0.70, 1, 1, .9, .15), (1.0, 1, 1, 1, .40)])
 # TF-B "bone": keys of the reference's Content/Curves/TF_CT-Bone.uasset
-TF_B_KEYS = _keys([(0.0, 0, 0, 0, 0), (0.4934, 0.7294, 0.2549, 0.3020, 0), (0.6014, 0.9059, 0.8157, 0.5529, 0.7157),
-                   (1.0, 1, 1, 1, 0.7059)])
+TF_B_KEYS = _keys([(0.0, 0, 0, 0, 0),
+                   (0.49344614148139954, 0.7294120192527771, 0.2549020051956177, 0.3019610047340393, 0),
+                   (0.6013756990432739, 0.9058820009231567, 0.8156859874725342, 0.5529410243034363, 0.715686023235321),
+                   (1.0, 1, 1, 1, 0.7058820128440857)])
 
 # (world direction, intensity) L0..L7
 LIGHTS = [((1, .35, -.5), 0.5), ((-.4, 1, -.3), 0.4), ((.2, -.3, -1), 0.4), ((-1, -.6, .4), 0.3),

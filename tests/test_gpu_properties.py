@@ -1,0 +1,95 @@
+"""Size-independent properties of the HIP path at sizes the oracle would take too long for."""
+import numpy as np
+import pytest
+
+from tbraymarcherplugin_amd import abi, sharding, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make(gpu, n, dtype=np.uint16, light_32bit=False, tf="A", window=(0.5, 0.9, True, False), seed=3):
+    import torch
+
+    vol = S.make_volume_torch((n, n, n), dtype, S.seed_for_config(seed), torch.device("cuda", 0))
+    res = abi.Resources((n, n, n), abi.DTYPE_FMT[np.dtype(dtype)], light_32bit)
+    res.upload_volume_device(vol.data_ptr(), vol.numel() * vol.element_size())
+    res.set_tf_lut(abi.color_curve_to_lut(S.tf_keys(tf)))
+    res.set_windowing(abi.WindowingParams(*window))
+    return res
+
+
+def test_chunk_kernels_equal_slice_kernel_at_256(gpu, monkeypatch):
+    """The production kernels (16 slices per launch pair) and the reference-structured kernel (one slice per launch)
+    produce the same UNORM8 light volume, bit for bit, on a 256^3 volume with 4 lights and two selective updates."""
+    world = S.default_world()
+    results = []
+    for variant in ("chunk", "slice"):
+        if variant == "slice":
+            monkeypatch.setenv("TBRM_FORCE_SLICE_KERNEL", "1")
+        else:
+            monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+        with make(gpu, 256) as res:
+            for i in range(4):
+                res.add_dir_light(S.light(i), True, world)
+            res.change_dir_light(S.light(1), abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1]), world)
+            res.change_dir_light(S.light(2), abi.DirLightParams(S.rotate_z(S.LIGHTS[2][0], 60.0), S.LIGHTS[2][1]), world)
+            results.append(res.download_light_volume())
+            c = res.launch_counters()
+            assert (c["chunk"] > 0 and c["slice"] == 0) if variant == "chunk" else (c["slice"] > 0 and c["chunk"] == 0)
+    assert np.array_equal(results[0], results[1]), f"{np.count_nonzero(results[0] != results[1])} voxels differ"
+    assert results[0].max() == 255 and results[0].min() < 60
+
+
+def test_add_then_remove_restores_float_light_volume(gpu):
+    world = S.default_world()
+    with make(gpu, 192, light_32bit=True) as res:
+        res.add_dir_light(S.light(0), True, world)
+        base = res.download_light_volume()
+        res.add_dir_light(S.light(3), True, world)
+        assert np.abs(res.download_light_volume() - base).max() > 0.1
+        res.add_dir_light(S.light(3), False, world)
+        assert np.abs(res.download_light_volume() - base).max() < 1e-6
+        res.clear_light_volume(0.0)
+        assert not res.download_light_volume().any()
+
+
+def test_transparent_volume_saturates(gpu):
+    world = S.default_world()
+    with make(gpu, 160) as res:
+        lut = np.zeros((256, 4), dtype=np.float32)
+        lut[:, :3] = 1.0
+        res.set_tf_lut(lut)
+        for d, inten, want in [((1, 0, 0), 0.5, 128), ((0, -1, 0), 0.4, 230), ((0, 0, 1), 0.3, 255)]:
+            res.add_dir_light(abi.DirLightParams(d, inten), True, world)
+            lv = res.download_light_volume()
+            assert (lv[8:-8, 8:-8, 8:-8] == want).all()  # interior: away from the sRGB-quantised border colour
+        img = res.raymarch_lit(S.default_camera(256, 256), abi.Tile(0, 0, 256, 256), abi.RaymarchParams(128.0, -1, True), world)
+        assert not img.any()
+
+
+def test_skipping_and_tiling_do_not_change_the_image_at_config2_size(gpu):
+    world = S.default_world()
+    cam = S.default_camera(512, 512)
+    full_tile = abi.Tile(0, 0, 512, 512)
+    for tf, window in (("A", (0.5, 0.9, True, False)), ("B", (0.5, 0.8, True, True))):
+        with make(gpu, 256, tf=tf, window=window) as res:
+            for i in range(2):
+                res.add_dir_light(S.light(i), True, world)
+            a = res.raymarch_lit(cam, full_tile, abi.RaymarchParams(256.0, -1, False), world)
+            b = res.raymarch_lit(cam, full_tile, abi.RaymarchParams(256.0, -1, True), world)
+            assert np.array_equal(a, b), "empty-space skipping changed pixels"
+            assert a[..., 3].max() > 0.9 and np.isfinite(a).all()
+            # 4-way interleaved tiles reassemble to the same frame
+            parts = np.stack([res.raymarch_lit(cam, sharding.rank_tile(512, 512, r, 4), abi.RaymarchParams(256.0, -1, True), world) for r in range(4)])
+            assert np.array_equal(sharding.assemble(parts, 512, 4), a)
+            n = res.count_nominal_samples(cam, full_tile, abi.RaymarchParams(256.0, -1, True), world)
+            n_parts = sum(res.count_nominal_samples(cam, sharding.rank_tile(512, 512, r, 4), abi.RaymarchParams(256.0, -1, True), world) for r in range(4))
+            assert n == n_parts and n > 10_000_000
+
+
+def test_unorm_decode_is_exact_division(gpu):
+    """The 3-instruction UNORM decode of the kernels (c*r corrected by one fma residual) equals IEEE c/255 and c/65535
+    for every code."""
+    u8, u16 = abi.selftest_unorm_decode(0)
+    assert np.array_equal(u8, np.arange(256, dtype=np.float32) / np.float32(255))
+    assert np.array_equal(u16, np.arange(65536, dtype=np.float32) / np.float32(65535))

@@ -1,0 +1,75 @@
+"""N>1 path: image-tile sharding + all-gather, exercised with 2 gloo processes on CPU. The oracle stands in for the
+renderer (tests may use it); on GPUs bench.py runs the same sharding code over RCCL with the HIP renderer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tbraymarcherplugin_amd import abi, sharding, synthetic as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tile_rows_partition_the_framebuffer():
+    for world in (1, 2, 4, 8):
+        h = 8 * world * 3
+        rows = np.concatenate([sharding.rank_rows(h, r, world) for r in range(world)])
+        assert sorted(rows.tolist()) == list(range(h))
+        t = sharding.rank_tile(40, h, world - 1, world)
+        assert (t.x0, t.y0, t.w, t.h, t.row_group_step) == (0, 8 * (world - 1), 40, h // world, world)
+    with pytest.raises(ValueError):
+        sharding.rows_per_rank(100, 8)
+    # assemble() inverts the interleave
+    world, h, w = 4, 64, 5
+    full = np.arange(h * w * 4, dtype=np.float32).reshape(h, w, 4)
+    gathered = np.stack([full[sharding.rank_rows(h, r, world)] for r in range(world)])
+    assert np.array_equal(sharding.assemble(gathered, h, world), full)
+
+
+def _worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    vol = S.make_volume_numpy((24, 24, 24), np.uint16, 0x5EED0002)
+    orc = oracle.OracleScene(vol)
+    orc.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
+    orc.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+    world = S.default_world()
+    orc.add_dir_light(S.light(0), True, world)
+    W, H = 40, 48
+    cam = S.default_camera(W, H)
+    rp = abi.RaymarchParams(32.0, -1, False)
+
+    def render(tile):
+        img, _ = orc.raymarch_lit(cam, tile, rp, world)
+        return torch.from_numpy(img)
+
+    def all_gather(local):
+        parts = [torch.empty_like(local) for _ in range(world_size)]  # gloo: list form of all_gather
+        dist.all_gather(parts, local.contiguous())
+        return torch.stack(parts)
+
+    frame = sharding.render_sharded(render, W, H, rank, world_size, all_gather)
+    full, _ = orc.raymarch_lit(cam, abi.Tile(0, 0, W, H), rp, world)
+    ok = np.array_equal(frame.numpy(), full)
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_render_matches_single_process(tmp_path, oracle_mod):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
