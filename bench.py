@@ -170,14 +170,26 @@ def main():
     if ray_ms >= illum_ms:
         dom = dict(kernel="k_raymarch_lit", achieved=ray_bytes / (ray_ms * 1e-3) / 1e9, launch_ms=ray_ms, alg_bytes=ray_bytes)
     else:
-        dom = dict(kernel="change_dir_light (2 axis passes)", achieved=illum_bytes / (illum_ms * 1e-3) / 1e9,
-                   launch_ms=illum_ms, alg_bytes=illum_bytes)
+        dom = dict(kernel="k_light_occlusion+k_light_chain (one ChangeDirLight = 2 axis passes)",
+                   achieved=illum_bytes / (illum_ms * 1e-3) / 1e9, launch_ms=illum_ms, alg_bytes=illum_bytes)
+    # HBM traffic from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+    # summarised by tools/pmc_traffic.py into profiles/): per launch of the raymarch kernel, or summed over the launches
+    # one ChangeDirLight makes
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.config == 3 and n_gpus == 1:
         try:
             with open(pmc_path) as f:
-                traffic = json.load(f).get(dom["kernel"].split(" ")[0])
+                pmc = json.load(f)
+            if dom["kernel"].startswith("k_raymarch"):
+                traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if "k_raymarch_lit" in k)
+            else:
+                chain = [v for k, v in pmc.items() if "k_light_chain" in k and ", true," in k]
+                occ = [v for k, v in pmc.items() if "k_light_occlusion" in k and ", true," in k]
+                per_pair = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in chain) / sum(v["launches"] for v in chain)
+                            + sum(v["hbm_bytes_per_launch"] * v["launches"] for v in occ) / sum(v["launches"] for v in occ))
+                traffic = per_pair * 2 * math.ceil(n / 16)  # launch pairs of one Change: 2 axis passes x chunks of 16 slices
+            traffic = int(traffic)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,

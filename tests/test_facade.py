@@ -1,0 +1,36 @@
+"""The C++ host side (include/tbrm_plugin.hpp: ARaymarchVolume / URaymarchUtils mirror) builds against the C-ABI with
+plain g++, and on a GPU box reproduces the reference's Tick policy (RaymarchVolume.cpp:327-416)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "facade_test.cpp")
+LIB_DIR = os.path.join(ROOT, "tbraymarcherplugin_amd", "lib")
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "facade_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe,
+                    "-L", LIB_DIR, "-ltbrm", f"-Wl,-rpath,{LIB_DIR}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_facade_compiles_and_links_with_gxx(tmp_path, abi_mod):
+    assert os.path.exists(build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_facade_tick_policy_on_gpu(tmp_path, gpu):
+    out = subprocess.run([build(tmp_path), "32"], check=True, capture_output=True, text=True).stdout
+    lines = dict(l.split(" ", 1) for l in out.strip().splitlines() if " " in l)
+    assert out.strip().endswith("OK"), out
+    assert lines["after_first_tick"] == "resets=1 adds=3 changes=0"      # recompute requested -> ResetAllLights
+    assert lines["after_idle_tick"] == "resets=1 adds=3 changes=0"       # nothing moved: no work
+    assert lines["after_one_moved"] == "resets=1 adds=3 changes=1"       # 1 of 3 lights -> ChangeDirLightInSingleVolume
+    assert lines["after_two_moved"] == "resets=2 adds=6 changes=1"       # >1 and >= half -> full reset is quicker
+    assert lines["after_window_change"] == "resets=3 adds=9 changes=1"   # windowing change -> bRequestedRecompute
+    mean_a = float(lines["render"].split("mean_alpha=")[1].split()[0])
+    assert 0.01 < mean_a < 0.9
+    assert "slice=0" in lines["launches"] and "raymarch=1" in lines["launches"]
