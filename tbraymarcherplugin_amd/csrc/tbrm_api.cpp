@@ -81,6 +81,9 @@ struct tbrm_resources {
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
     float* d_occ[4]{};             // chunk kernel: occlusion plane stacks, 2 per stream (allocated on first use)
     size_t occ_elems = 0;
+    uint8_t* d_occ_zero[2]{};      // empty-block flags of the two occlusion buffers
+    float* d_zero_page = nullptr;  // 4 KiB of zeros
+    size_t occ_zero_bytes = 0;
 
     // empty-space-skipping metadata
     int bn[3]{};
@@ -176,6 +179,8 @@ int end_timed(tbrm_resources* r, int kind)
     r->ev_valid[kind] = true;
     return TBRM_OK;
 }
+
+int ensure_skipping(tbrm_resources* r);
 
 // ---- chunked propagation (tbrm_light_kernels.hip) --------------------------------------------------------------
 
@@ -298,6 +303,24 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         r->occ_elems = occ_elems;
     }
 
+    // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window)
+    const bool sparse = !getenv("TBRM_NO_SPARSE_OCC");
+    p.occ_blocks_x = ceil_div(W, 16);
+    p.occ_blocks_y = ceil_div(H, 16);
+    if (sparse) {
+        if (int e = ensure_skipping(r)) return e;
+        const size_t zbytes = (size_t) p.occ_blocks_x * p.occ_blocks_y * 2;
+        if (zbytes > r->occ_zero_bytes) {
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            for (uint8_t*& z : r->d_occ_zero) { (void) hipFree(z); z = nullptr; }
+            r->occ_zero_bytes = 0;
+            for (uint8_t*& z : r->d_occ_zero) HIP_TRY(hipMalloc((void**) &z, zbytes));
+            r->occ_zero_bytes = zbytes;
+        }
+        p.empty_bits = r->d_empty;
+        p.zero_page = r->d_zero_page;
+    }
+
     const int n_chunks = (D + M - 1) / M;
     auto set_chunk = [&](int c) {
         p.n_steps = std::min(M, D - c * M);
@@ -308,6 +331,10 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         p.r.plane_in = r->d_plane[2 + cur] + kPlaneGuard; p.r.plane_out = r->d_plane[2 + nxt] + kPlaneGuard;
         p.a.occ_cur = p.a.occ_next = r->d_occ[cur] + kPlaneGuard; // the occlusion launch of chunk c fills occ_next
         p.r.occ_cur = p.r.occ_next = r->d_occ[2 + cur] + kPlaneGuard;
+        // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple
+        // of 4 does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
+        const bool sp = sparse && ((p.n_steps * -p.dx_lo) % 4 == 0);
+        p.occ_zero_cur = p.occ_zero_next = sp ? r->d_occ_zero[cur] : nullptr;
         p.tile_i0 = p.tile_j0 = 0;
         p.tiles_x = ceil_div(W, kChunkTile);
         p.tiles_y = ceil_div(H, kChunkTile);
@@ -589,6 +616,8 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
     CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**) &r->d_counter, sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc((void**) &r->d_zero_page, 4096));
+    CREATE_TRY(hipMemsetAsync(r->d_zero_page, 0, 4096, r->stream));
     for (int k = 0; k < 2; ++k)
         for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));
     // the light volume render target starts cleared
@@ -615,6 +644,8 @@ int tbrm_resources_destroy(tbrm_resources* r)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
     for (float* oc : r->d_occ) (void) hipFree(oc);
+    for (uint8_t* z : r->d_occ_zero) (void) hipFree(z);
+    (void) hipFree(r->d_zero_page);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     (void) hipFree(r->d_alpha_prefix);

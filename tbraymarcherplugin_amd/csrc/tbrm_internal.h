@@ -95,6 +95,13 @@ struct ChunkParams {
     // occlusion part
     int next_j0, next_n;    // first slice and number of slices of the next chunk (0: none)
     int occ_tiles_x, occ_tiles_y;
+    // empty-block hand-off: an occlusion workgroup whose bricks all map to opacity 0 writes one flag instead of its
+    // 16x16x8 zeros; the chain stages zeros for flagged blocks without touching the plane stack
+    const uint32_t* empty_bits;   // per data brick (k_brick_empty), null: feature off
+    uint8_t* occ_zero_next;       // flags written by the occlusion launch: [slice group][block y][block x]
+    const uint8_t* occ_zero_cur;  // flags read by the chain launch
+    const float* zero_page;       // 4 KiB of zeros: the copy source for flagged blocks (keeps the copies per wave uniform)
+    int occ_blocks_x, occ_blocks_y;
     int debug;              // TBRM_DEBUG bitmask (timing experiments only; results are wrong when set)
     long long* debug_clock; // bit 64: block 0 writes s_memtime stamps here
     ChunkStream a, r;

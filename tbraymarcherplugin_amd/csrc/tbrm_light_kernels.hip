@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     __shared__ float s_alpha[256];
     __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
     __shared__ int s_i[2][kOccDepth], s_flags[2][kOccDepth]; // flags: bit0 tap0 in range, bit1 tap1 in range, bit2 w == saturate(w)
-    __shared__ int s_b0[3], s_nb[3], s_staged;
+    __shared__ int s_b0[3], s_nb[3], s_staged, s_maybe_empty, s_block_empty;
+    __shared__ int s_ends[12], s_end_dim[12];
 
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
     const int data_dims[3] = {p.data.nx, p.data.ny, p.data.nz};
@@ -269,37 +270,83 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
         s_w[si][q] = w; s_f[si][q] = t.f; s_i[si][q] = t.i0;
         s_flags[si][q] = (t.ok0 ? 1 : 0) | (t.ok1 ? 2 : 0) | ((w == saturate_(w)) ? 4 : 0);
     }
-    if (threadIdx.x == 64) { // brick range the workgroup's samples can touch (union over the streams)
-        int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + NS * 6) { // tap range of the first / last pixel and slice, one lane each
+        const int t = threadIdx.x - 64, si = t / 6, a = (t % 6) >> 1, e = t & 1;
+        const ChunkStream& s = si == 0 ? p.a : p.r;
         const int pxl = min(px0 + kOccTile, p.W) - 1, pyl = min(py0 + kOccTile, p.H) - 1;
-        for (int si = 0; si < NS; ++si) {
-            const ChunkStream& s = si == 0 ? p.a : p.r;
-            const int ends[3][2] = {{px0, pxl}, {py0, pyl}, {p.j0 + k0 * p.dir, p.j0 + (k0 + nk - 1) * p.dir}};
-            constexpr int dims[3] = {dim_u, dim_v, dim_s};
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float c = (((float) (uint32_t) ends[a][e] + 0.5f) / (float) (uint32_t) p.lv_dims[dims[a]]) + s.uvw_off[dims[a]];
-                    int i0;
-                    float f;
-                    texel_split(c, (float) data_dims[dims[a]], i0, f);
-                    lo[dims[a]] = min(lo[dims[a]], i0);
-                    hi[dims[a]] = max(hi[dims[a]], i0 + 1);
-                }
+        const int end = a == 0 ? (e ? pxl : px0) : (a == 1 ? (e ? pyl : py0) : p.j0 + (e ? k0 + nk - 1 : k0) * p.dir);
+        const int dim = a == 0 ? dim_u : (a == 1 ? dim_v : dim_s);
+        const int lvd = dim == 0 ? p.lv_dims[0] : (dim == 1 ? p.lv_dims[1] : p.lv_dims[2]);
+        const float off = dim == 0 ? s.uvw_off[0] : (dim == 1 ? s.uvw_off[1] : s.uvw_off[2]);
+        const int dd = dim == 0 ? p.data.nx : (dim == 1 ? p.data.ny : p.data.nz);
+        const float c = (((float) (uint32_t) end + 0.5f) / (float) (uint32_t) lvd) + off;
+        int i0;
+        float f;
+        texel_split(c, (float) dd, i0, f);
+        s_ends[t] = i0;
+        s_end_dim[t] = dim;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // brick range the workgroup's samples can touch (union over the streams)
+        int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+        for (int t = 0; t < NS * 6; ++t) {
+            const int d = s_end_dim[t], i0 = s_ends[t];
+            if (d == 0) { lo[0] = min(lo[0], i0); hi[0] = max(hi[0], i0 + 1); }
+            else if (d == 1) { lo[1] = min(lo[1], i0); hi[1] = max(hi[1], i0 + 1); }
+            else { lo[2] = min(lo[2], i0); hi[2] = max(hi[2], i0 + 1); }
         }
         const int bn[3] = {p.data.bnx, p.data.bnxy / p.data.bnx, (p.data.nz + 7) >> 3};
+        const int dn[3] = {p.data.nx, p.data.ny, p.data.nz};
         int count = 1;
+        bool touches_border = false;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const int b_lo = max(lo[a] >> 3, 0), b_hi = min(hi[a] >> 3, bn[a] - 1);
             s_b0[a] = b_lo;
             s_nb[a] = max(b_hi - b_lo + 1, 0);
             count *= s_nb[a];
+            touches_border = touches_border || lo[a] < 0 || hi[a] >= dn[a];
         }
         s_staged = (count > 0 && count * 512 * ESZ <= lds_budget_bytes) ? 1 : 0; // else: read taps from global memory
+        // workgroups with taps outside the volume are never skipped: a blend of the border colour with in-volume taps can
+        // leave both value ranges (k_brick_empty's bit only vouches for a sample whose 8 taps lie in the brick's apron)
+        s_maybe_empty = (p.empty_bits && count > 0 && count <= 64 && !touches_border) ? 1 : 0;
     }
     __syncthreads();
+
+    // Empty block: the brick of every sample's base tap has its k_brick_empty bit set, i.e. every value the sample's 8
+    // taps can take (the brick plus its +1 apron) maps to opacity 0, so every CurrentSample is exactly 0. One flag
+    // replaces the 16x16x8 zeros; the chain stages zeros for it.
+    if (p.occ_zero_next) {
+        bool empty = false;
+        if (s_maybe_empty) {
+            if (threadIdx.x < 64) {
+                const int count = s_nb[0] * s_nb[1] * s_nb[2];
+                bool mine = true;
+                if ((int) threadIdx.x < count) {
+                    const int lx = threadIdx.x % s_nb[0], ly = (threadIdx.x / s_nb[0]) % s_nb[1], lz = threadIdx.x / (s_nb[0] * s_nb[1]);
+                    const int b = (s_b0[2] + lz) * p.data.bnxy + (s_b0[1] + ly) * p.data.bnx + (s_b0[0] + lx);
+                    mine = (p.empty_bits[b >> 5] >> (b & 31)) & 1u;
+                }
+                const bool all_empty = __all(mine);
+                if (threadIdx.x == 0) s_block_empty = all_empty ? 1 : 0;
+            }
+            __syncthreads();
+            empty = s_block_empty != 0;
+        }
+        if (threadIdx.x == 0)
+            p.occ_zero_next[(blockIdx.z * p.occ_blocks_y + blockIdx.y) * p.occ_blocks_x + blockIdx.x] = empty ? 1 : 0;
+        if (empty && (p.debug & 1024)) { // diagnostic: write the zeros explicitly
+            const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+            const int px_ = px0 + (wave_ & 1) * 8 + (lane_ & 7), py_ = py0 + (wave_ >> 1) * 8 + (lane_ >> 3);
+            if (px_ < p.W && py_ < p.H)
+                for (int q = 0; q < nk; ++q) {
+                    p.a.occ_next[(k0 + q) * p.H * p.W + py_ * p.W + px_] = 0.0f;
+                    if constexpr (CHANGE) p.r.occ_next[(k0 + q) * p.H * p.W + py_ * p.W + px_] = 0.0f;
+                }
+        }
+        if (empty && !(p.debug & 256)) return;
+    }
 
     const bool staged = s_staged && !(p.debug & 128);
     const int b0[3] = {s_b0[0], s_b0[1], s_b0[2]}, nb[3] = {s_nb[0], s_nb[1], s_nb[2]};
@@ -429,11 +476,30 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int st_src = st_py * p.W + base_x - g.padx + st_col; // may run off the row ends: the planes have guard bands
     const bool st_ok = st_row < g.HY && (unsigned) st_py < (unsigned) p.H;
     const int st_dst = wave * 256;                            // this wave's 64 x 4 floats
+    // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: zeros are staged without a copy
+    bool st_zero[2] = {false, false}; // this thread's 4 pixels lie in empty blocks, slices [0,8) / [8,16) of the chunk
+    if (p.occ_zero_cur && st_ok && !(p.debug & 512)) {
+        const int x_first = base_x - g.padx + st_col, x_last = x_first + 3;
+        const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = st_py >> 4;
+#pragma unroll
+        for (int z = 0; z < 2; ++z) {
+            bool zero = x_last >= 0 && x_first < p.W && z * kOccDepth < g.n;
+            if (zero) {
+                const uint8_t* row = p.occ_zero_cur + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
+                zero = row[bx0] != 0 && row[bx1] != 0;
+            }
+            st_zero[z] = zero;
+        }
+    }
     auto stage_occ = [&](int sf) {
         if (sf < g.n && st_ok && !(p.debug & 4)) {
             float* dst = lds + 2 * g.elems + (sf % kOccRing) * g.elems + st_dst;
-            dma_16(p.a.occ_cur + sf * plane_elems + st_src, dst);
-            if constexpr (CHANGE) dma_16(p.r.occ_cur + sf * plane_elems + st_src, dst + stream_stride);
+            // flagged-empty lanes copy from a page of zeros (L2-resident) instead of the plane stack: same number of copy
+            // instructions per wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on
+            const bool zero = st_zero[sf >> 3];
+            const float* zsrc = p.zero_page + (threadIdx.x & 63) * 4;
+            dma_16(zero ? zsrc : p.a.occ_cur + sf * plane_elems + st_src, dst);
+            if constexpr (CHANGE) dma_16(zero ? zsrc : p.r.occ_cur + sf * plane_elems + st_src, dst + stream_stride);
         }
     };
 
