@@ -445,15 +445,14 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
 // issues a handful of wide vector-memory instructions instead of ~100 narrow ones — the narrow ones, not HBM
 // bandwidth, were what bounded the first versions of this kernel.
 
-template <int LFMT, bool CHANGE, int AXIS>
+template <int LFMT, bool CHANGE, int AXIS, int KH> // KH = halo pixels per thread: ceil((hull area - tile area) / threads)
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = kChunkTile;
     constexpr int NS = CHANGE ? 2 : 1;
     constexpr bool LV_LDS = LFMT == FMT_U8;
-    constexpr int KH = (kChunkMaxHull * kChunkMaxHull - T * T + kChunkThreads - 1) / kChunkThreads; // halo slots per thread
-    constexpr int KS = 1 + KH;                                                                     // + the owned pixel
+    constexpr int KS = 1 + KH; // + the owned pixel
     const ChunkGeom g = chunk_geometry(p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int plane_elems = p.H * p.W;
@@ -759,14 +758,26 @@ hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t
     }
 }
 
+template <int LFMT, bool CHANGE, int AXIS, int KH>
+static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
+{
+    static bool attr = false;
+    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
+    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
+    return hipGetLastError();
+}
 template <int LFMT, bool CHANGE, int AXIS>
 static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
-    return hipGetLastError();
+    const ChunkGeom g = chunk_geometry(p);
+    const int halo = g.HX * g.HY - kChunkTile * kChunkTile;
+    const int kh = (halo + kChunkThreads - 1) / kChunkThreads;
+    if constexpr (CHANGE) { // two streams double the per-pixel state: the exact count keeps the kernel out of scratch
+        if (kh <= 1) return launch_chain4<LFMT, CHANGE, AXIS, 1>(p, s);
+        if (kh == 2) return launch_chain4<LFMT, CHANGE, AXIS, 2>(p, s);
+    }
+    return launch_chain4<LFMT, CHANGE, AXIS, 3>(p, s); // measured: the single-stream kernel is fastest fully unrolled
 }
 template <int LFMT, bool CHANGE>
 static hipError_t launch_chain2(const ChunkParams& p, hipStream_t s)
