@@ -67,12 +67,20 @@ def main():
     if world_size != n_gpus and not (n_gpus == 1 and world_size == 1):
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world_size}: launch with torch.distributed.run --nproc-per-node {n_gpus}")
     dist = None
+    # Dry run of the N>1 code path on a box with ONE GPU (every rank on device 0, gloo instead of RCCL): only for checking
+    # the sharding / gather / reporting logic where no multi-GPU node is available; never used by the driver.
+    one_gpu_dry_run = os.environ.get("TBRM_BENCH_ONE_GPU_DRY_RUN") == "1"
+    if one_gpu_dry_run:
+        local_rank = 0
     if n_gpus > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu_dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     abi.load()
@@ -88,6 +96,7 @@ def main():
     # ---- setup (untimed): inputs resident in HBM ---------------------------------------------------------
     vol_dev = S.make_volume_torch(dims, cfg["dtype"], seed, device)
     res = abi.Resources(dims, abi.DTYPE_FMT[np.dtype(cfg["dtype"])], cfg["light_32bit"], False, local_rank)
+    torch.cuda.synchronize()  # the library reads the tensor on its own stream: torch's generator kernels must be done
     res.upload_volume_device(vol_dev.data_ptr(), vol_dev.numel() * vol_dev.element_size())
     lut = abi.color_curve_to_lut(S.tf_keys(cfg["tf"]))
     res.set_tf_lut(lut)
@@ -112,8 +121,9 @@ def main():
     gathered = torch.empty((n_gpus, rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) if n_gpus > 1 else None
     my_samples = res.count_nominal_samples(cam, tile, rp, world)
     total_samples = my_samples
+    red_device = torch.device("cpu") if one_gpu_dry_run else device
     if dist is not None:
-        t = torch.tensor([my_samples], dtype=torch.int64, device=device)
+        t = torch.tensor([my_samples], dtype=torch.int64, device=red_device)
         dist.all_reduce(t)
         total_samples = int(t.item())
 
@@ -130,7 +140,12 @@ def main():
         res.raymarch_lit_device(cam, tile, rp, world, out.data_ptr())
         if dist is not None:
             res.flush()  # the tile must be complete before RCCL reads it on torch's stream
-            dist.all_gather_into_tensor(gathered, out)
+            if one_gpu_dry_run:
+                parts = [torch.empty(out.shape, dtype=out.dtype) for _ in range(n_gpus)]
+                dist.all_gather(parts, out.cpu())
+                gathered.copy_(torch.stack(parts))
+            else:
+                dist.all_gather_into_tensor(gathered, out)
         if record:
             if not args.raymarch_only:
                 ms_illum.append(res.last_gpu_time_ms(0))
@@ -149,9 +164,24 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- N>1: the assembled frame must equal this rank's own render of the whole framebuffer (untimed check) ----
+    gather_ok = None
+    if dist is not None:
+        from tbraymarcherplugin_amd import sharding
+
+        frame = sharding.assemble(gathered, fb_h, n_gpus)
+        full = torch.empty((fb_h, fb_w, 4), dtype=torch.float32, device=device)
+        res.raymarch_lit_device(cam, abi.Tile(0, 0, fb_w, fb_h, 1), rp, world, full.data_ptr())
+        res.flush()
+        gather_ok = bool(torch.equal(frame, full))
+        if not gather_ok and os.environ.get("TBRM_BENCH_DEBUG"):
+            rows = torch.from_numpy(sharding.rank_rows(fb_h, rank, n_gpus)).to(device)
+            print(f"[rank {rank}] frame-full max|d| = {float((frame - full).abs().max())}, own tile vs own full: "
+                  f"{bool(torch.equal(out, full[rows]))}, gathered[rank] vs out: {bool(torch.equal(gathered[rank], out))}", flush=True)
 
     # ---- per-kernel GPU time with HIP events on the library's stream (separate, untimed pass) -------------
     for k in range(max(3, min(args.steps, 10))):
@@ -217,6 +247,7 @@ def main():
                                       if n_gpus > 1 else "single GPU",
                        "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only)},
             "nominal_samples_per_step": total_samples,
+            "gathered_frame_equals_single_gpu_render": gather_ok,
             "gpu_ms": {"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4), "reset_all_lights_setup": round(reset_ms, 2)},
             "raymarch_only_msamples_per_s": round(my_samples / (ray_ms * 1e-3) / 1e6, 2),
             "roofline": roofline,

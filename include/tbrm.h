@@ -176,6 +176,8 @@ TBRM_API int tbrm_resources_is_initialized(const tbrm_resources* res); /* bIsIni
 /* UVolumeTexture-shaped input: dense x-fastest array in desc.data_format (CreateVolumeTextureMip memcpy,
  * TextureUtilities.cpp:43-78). Host pointer variant copies over PCIe; device variant reads HBM.        */
 TBRM_API int tbrm_upload_volume(tbrm_resources* res, const void* host_voxels, size_t n_bytes);
+/* device variant: the voxels must be complete in HBM before the call (the library reads them on its own stream: sync
+ * the producing stream first); the buffer may be released when the call returns. */
 TBRM_API int tbrm_upload_volume_device(tbrm_resources* res, const void* device_voxels, size_t n_bytes);
 
 /* Transfer function. tbrm_set_tf_lut takes the 256 x RGBA float samples ColorCurveToTexture would take from

@@ -12,6 +12,7 @@ def make(gpu, n, dtype=np.uint16, light_32bit=False, tf="A", window=(0.5, 0.9, T
 
     vol = S.make_volume_torch((n, n, n), dtype, S.seed_for_config(seed), torch.device("cuda", 0))
     res = abi.Resources((n, n, n), abi.DTYPE_FMT[np.dtype(dtype)], light_32bit)
+    torch.cuda.synchronize()  # the library reads the tensor on its own stream
     res.upload_volume_device(vol.data_ptr(), vol.numel() * vol.element_size())
     res.set_tf_lut(abi.color_curve_to_lut(S.tf_keys(tf)))
     res.set_windowing(abi.WindowingParams(*window))

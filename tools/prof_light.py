@@ -17,7 +17,7 @@ def main():
     dev = torch.device("cuda", 0)
     vol = S.make_volume_torch((n, n, n), cfg["dtype"], S.seed_for_config(3), dev)
     res = abi.Resources((n, n, n), abi.FMT_G16)
-    res.upload_volume_device(vol.data_ptr(), vol.numel() * 2)
+    torch.cuda.synchronize(); res.upload_volume_device(vol.data_ptr(), vol.numel() * 2)
     res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
     res.set_windowing(abi.WindowingParams(*cfg["window"]))
     world = S.default_world()
