@@ -369,8 +369,8 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         long long h[64];
         HIP_TRY(hipStreamSynchronize(r->stream));
         HIP_TRY(hipMemcpy(h, dbg_clock, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[tbrm debug] chain block 0 clocks (delta from start):");
-        for (int k = 1; k < 24; ++k) fprintf(stderr, " %lld", h[k] - h[0]);
+        fprintf(stderr, "[tbrm debug] chain block 0 clock deltas:");
+        for (int k = 1; k < 48; ++k) fprintf(stderr, " %lld", h[k] - h[k - 1]);
         fprintf(stderr, "\n");
     }
     return TBRM_OK;

@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     __shared__ float s_alpha[256];
     __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
     __shared__ int s_i[2][kOccDepth], s_flags[2][kOccDepth]; // flags: bit0 tap0 in range, bit1 tap1 in range, bit2 w == saturate(w)
-    __shared__ int s_b0[3], s_nb[3], s_staged, s_maybe_empty, s_block_empty;
+    __shared__ int s_b0[3], s_nb[3], s_staged, s_maybe_empty, s_block_empty, s_interior;
+    __shared__ uint32_t s_o0[2][kOccDepth], s_o1[2][kOccDepth];
     __shared__ int s_ends[12], s_end_dim[12];
 
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
             touches_border = touches_border || lo[a] < 0 || hi[a] >= dn[a];
         }
         s_staged = (count > 0 && count * 512 * ESZ <= lds_budget_bytes) ? 1 : 0; // else: read taps from global memory
+        s_interior = touches_border ? 0 : 1;
         // workgroups with taps outside the volume are never skipped: a blend of the border colour with in-volume taps can
         // leave both value ranges (k_brick_empty's bit only vouches for a sample whose 8 taps lie in the brick's apron)
         s_maybe_empty = (p.empty_bits && count > 0 && count <= 64 && !touches_border) ? 1 : 0;
@@ -363,18 +365,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
         }
     }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = px0 + (wave & 1) * 8 + (lane & 7);
-    const int py = py0 + (wave >> 1) * 8 + (lane >> 3);
-    const bool pixel_ok = px < p.W && py < p.H;
-    const int plane_elems = p.H * p.W;
-    const float border = p.data_border;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (!pixel_ok) return;
-
-    // offset of voxel coordinate c along `axis`: in the staged block, or in the bricked global volume
+    // offset of voxel coordinate c along axis A: in the staged block, or in the bricked global volume
     auto voff = [&](int c, auto axis_c) -> uint32_t {
         constexpr int axis = decltype(axis_c)::value;
         const int n = data_dims[axis];
@@ -385,57 +376,88 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
         }
         return axis == 0 ? brick_off_x(c) : (axis == 1 ? brick_off_y(c, p.data.bnx) : brick_off_z(c, p.data.bnxy));
     };
-    auto tap = [&](uint32_t off) -> float {
-        return staged ? lds_voxel<DFMT>(smem, off) : load_voxel<DFMT>(p.data.data, off);
-    };
-
-#pragma unroll
-    for (int si = 0; si < NS; ++si) {
-        const ChunkStream& s = si == 0 ? p.a : p.r;
-        // GetUVW(pos, res) + UVWOffset (AddDirLightShader.usf:85): the two in-plane components
-        const float u = (((float) (uint32_t) px + 0.5f) / (float) (uint32_t) p.lv_dims[dim_u]) + s.uvw_off[dim_u];
-        const float v = (((float) (uint32_t) py + 0.5f) / (float) (uint32_t) p.lv_dims[dim_v]) + s.uvw_off[dim_v];
-        const AxisTaps tu = axis_taps(u, data_dims[dim_u]), tv = axis_taps(v, data_dims[dim_v]);
-        const bool guard_uv = (u == saturate_(u)) && (v == saturate_(v));
-        using AU = std::integral_constant<int, dim_u>; using AV = std::integral_constant<int, dim_v>; using AS = std::integral_constant<int, dim_s>;
-        const uint32_t u0 = voff(tu.i0, AU{}), u1 = voff(tu.i0 + 1, AU{}), v0 = voff(tv.i0, AV{}), v1 = voff(tv.i0 + 1, AV{});
-        const uint32_t o00 = u0 + v0, o10 = u1 + v0, o01 = u0 + v1, o11 = u1 + v1;
-        const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
-        float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
-
-        for (int q = 0; q < nk; ++q) {
-            const float w = s_w[si][q], fs = s_f[si][q];
-            const int fl = s_flags[si][q];
-            float aw = 1.0f;
-            if (p.clip_mode) {
-                float c0, c1, c2;
-                if (AXIS == 0) { c0 = w; c1 = u; c2 = v; } else if (AXIS == 1) { c0 = u; c1 = w; c2 = v; } else { c0 = u; c1 = v; c2 = w; }
-                aw = clip_alpha_weight(c0, c1, c2, p.cc, p.cd, p.lv_dims);
-            }
-            bool inside = true;
-            if constexpr (!CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
-            float occ = 0.0f;
-            if (aw > 0.0f && inside && !(p.debug & 16)) {
-                const uint32_t w0 = voff(s_i[si][q], AS{}), w1 = voff(s_i[si][q] + 1, AS{});
-                const bool a0 = fl & 1, a1 = fl & 2;
-                // tap t: bit0 = u tap, bit1 = v tap, bit2 = slice tap
-                const float t0 = (k00 && a0) ? tap(o00 + w0) : border, t1 = (k10 && a0) ? tap(o10 + w0) : border;
-                const float t2 = (k01 && a0) ? tap(o01 + w0) : border, t3 = (k11 && a0) ? tap(o11 + w0) : border;
-                const float t4 = (k00 && a1) ? tap(o00 + w1) : border, t5 = (k10 && a1) ? tap(o10 + w1) : border;
-                const float t6 = (k01 && a1) ? tap(o01 + w1) : border, t7 = (k11 && a1) ? tap(o11 + w1) : border;
-                float val; // filter x, then y, then z
-                if (AXIS == 2) { // (u,v,s) = (x,y,z)
-                    val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t2, t3, tu.f), tv.f), lerp_(lerp_(t4, t5, tu.f), lerp_(t6, t7, tu.f), tv.f), fs);
-                } else if (AXIS == 1) { // x = u, y = slice, z = v
-                    val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t4, t5, tu.f), fs), lerp_(lerp_(t2, t3, tu.f), lerp_(t6, t7, tu.f), fs), tv.f);
-                } else { // x = slice, y = u, z = v
-                    val = lerp_(lerp_(lerp_(t0, t4, fs), lerp_(t1, t5, fs), tu.f), lerp_(lerp_(t2, t6, fs), lerp_(t3, t7, fs), tu.f), tv.f);
-                }
-                occ = (p.debug & 32) ? val : windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
-            }
-            out[q * plane_elems] = occ;
-        }
+    using AU = std::integral_constant<int, dim_u>; using AV = std::integral_constant<int, dim_v>; using AS = std::integral_constant<int, dim_s>;
+    if (threadIdx.x < NS * kOccDepth) { // slice-axis tap offsets of each step (wave-uniform), in the layout just chosen
+        const int si = threadIdx.x / kOccDepth, q = threadIdx.x % kOccDepth;
+        s_o0[si][q] = voff(s_i[si][q], AS{});
+        s_o1[si][q] = voff(s_i[si][q] + 1, AS{});
     }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = px0 + (wave & 1) * 8 + (lane & 7);
+    const int py = py0 + (wave >> 1) * 8 + (lane >> 3);
+    const bool pixel_ok = px < p.W && py < p.H;
+    const int plane_elems = p.H * p.W;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!pixel_ok) return;
+
+    // the sample loop, specialised on workgroup-uniform facts so the common case carries no dead branches:
+    //   STAGED   taps come from LDS (else from global memory: a workgroup whose bricks did not fit)
+    //   INTERIOR every tap of every sample lies inside the volume (no border-colour selects)
+    //   CLIP     the clip plane can change a sample's weight (else AlphaWeight is exactly 1)
+    auto run = [&](auto staged_c, auto interior_c, auto clip_c) {
+        constexpr bool STAGED = decltype(staged_c)::value, INTERIOR = decltype(interior_c)::value, CLIP = decltype(clip_c)::value;
+        const float border = p.data_border;
+        auto tap = [&](uint32_t off, bool ok) -> float {
+            if constexpr (INTERIOR) return STAGED ? lds_voxel<DFMT>(smem, off) : load_voxel<DFMT>(p.data.data, off);
+            else return ok ? (STAGED ? lds_voxel<DFMT>(smem, off) : load_voxel<DFMT>(p.data.data, off)) : border;
+        };
+#pragma unroll
+        for (int si = 0; si < NS; ++si) {
+            const ChunkStream& s = si == 0 ? p.a : p.r;
+            // GetUVW(pos, res) + UVWOffset (AddDirLightShader.usf:85): the two in-plane components
+            const float u = (((float) (uint32_t) px + 0.5f) / (float) (uint32_t) p.lv_dims[dim_u]) + s.uvw_off[dim_u];
+            const float v = (((float) (uint32_t) py + 0.5f) / (float) (uint32_t) p.lv_dims[dim_v]) + s.uvw_off[dim_v];
+            const AxisTaps tu = axis_taps(u, data_dims[dim_u]), tv = axis_taps(v, data_dims[dim_v]);
+            const bool guard_uv = (u == saturate_(u)) && (v == saturate_(v));
+            const uint32_t u0 = voff(tu.i0, AU{}), u1 = voff(tu.i0 + 1, AU{}), v0 = voff(tv.i0, AV{}), v1 = voff(tv.i0 + 1, AV{});
+            const uint32_t o00 = u0 + v0, o10 = u1 + v0, o01 = u0 + v1, o11 = u1 + v1;
+            const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
+            float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
+
+            for (int q = 0; q < nk; ++q) {
+                const float fs = s_f[si][q];
+                const int fl = s_flags[si][q];
+                float aw = 1.0f;
+                if constexpr (CLIP) {
+                    const float w = s_w[si][q];
+                    float c0, c1, c2;
+                    if (AXIS == 0) { c0 = w; c1 = u; c2 = v; } else if (AXIS == 1) { c0 = u; c1 = w; c2 = v; } else { c0 = u; c1 = v; c2 = w; }
+                    aw = clip_alpha_weight(c0, c1, c2, p.cc, p.cd, p.lv_dims);
+                }
+                bool inside = true;
+                if constexpr (!CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
+                float occ = 0.0f;
+                if (aw > 0.0f && inside && !(p.debug & 16)) {
+                    const uint32_t w0 = s_o0[si][q], w1 = s_o1[si][q];
+                    const bool a0 = fl & 1, a1 = fl & 2;
+                    // tap t: bit0 = u tap, bit1 = v tap, bit2 = slice tap
+                    const float t0 = tap(o00 + w0, k00 && a0), t1 = tap(o10 + w0, k10 && a0);
+                    const float t2 = tap(o01 + w0, k01 && a0), t3 = tap(o11 + w0, k11 && a0);
+                    const float t4 = tap(o00 + w1, k00 && a1), t5 = tap(o10 + w1, k10 && a1);
+                    const float t6 = tap(o01 + w1, k01 && a1), t7 = tap(o11 + w1, k11 && a1);
+                    float val; // filter x, then y, then z
+                    if (AXIS == 2) { // (u,v,s) = (x,y,z)
+                        val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t2, t3, tu.f), tv.f), lerp_(lerp_(t4, t5, tu.f), lerp_(t6, t7, tu.f), tv.f), fs);
+                    } else if (AXIS == 1) { // x = u, y = slice, z = v
+                        val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t4, t5, tu.f), fs), lerp_(lerp_(t2, t3, tu.f), lerp_(t6, t7, tu.f), fs), tv.f);
+                    } else { // x = slice, y = u, z = v
+                        val = lerp_(lerp_(lerp_(t0, t4, fs), lerp_(t1, t5, fs), tu.f), lerp_(lerp_(t2, t6, fs), lerp_(t3, t7, fs), tu.f), tv.f);
+                    }
+                    occ = (p.debug & 32) ? val : windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
+                }
+                out[q * plane_elems] = occ;
+            }
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    const bool interior = s_interior != 0;
+    if (staged && interior && !p.clip_mode) run(T_{}, T_{}, F_{});       // the common case
+    else if (staged && !p.clip_mode) run(T_{}, F_{}, F_{});               // shell of the volume
+    else if (staged) run(T_{}, F_{}, T_{});                               // clip plane active
+    else run(F_{}, F_{}, T_{});                                           // bricks did not fit in LDS
 }
 
 // ---- k_light_chain: one tile through the slices of the chunk ---------------------------------------------------
@@ -704,12 +726,16 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 step(s, u & 1, u % 3, lvq[u % 3]);
                 lvq[u % 3] = fetch_lv(s + 3);
             }
+            if (p.debug & 2048) tick();
             __syncthreads(); // every wave is done reading ring slot u%3 and window u&1
+            if (p.debug & 2048) tick();
             stage_occ(s + 3);
+            if (p.debug & 2048) tick();
             // loads (incl. global->LDS copies) complete in issue order: with at most the loads of the two youngest
             // refills outstanding, the copies for slice s+1 have landed
             if constexpr (LV_LDS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS + 1)) : "memory");
+            if (p.debug & 2048) tick();
             __syncthreads(); // slice s+1's occlusion is visible to every wave
             tick();
         }

@@ -11,7 +11,7 @@ res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS)); res.set_windowing(abi.Windo
 world = S.default_world()
 light = abi.DirLightParams((0.2, 0.3, 1), 0.3)   # single-axis? no: two passes Z then Y
 light = abi.DirLightParams((0.05, 0.04, 1), 0.3)  # w0 > 0.99 -> one Z pass, generic fractional offsets (g = 1)
-for dbg in [0, 64, 64+2, 64+15, 16, 48]:
+for dbg in [0, 2112]:
     os.environ["TBRM_DEBUG"] = str(dbg)
     for rep in range(2):
         res.add_dir_light(light, True, world); ms = res.last_gpu_time_ms(0)
