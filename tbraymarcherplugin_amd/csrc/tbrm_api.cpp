@@ -303,22 +303,32 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         r->occ_elems = occ_elems;
     }
 
-    // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window)
+    // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
+    // workgroup of the whole pass, computed up front
     const bool sparse = !getenv("TBRM_NO_SPARSE_OCC");
+    const int n_chunks_ = (D + M - 1) / M;
     p.occ_blocks_x = ceil_div(W, 16);
     p.occ_blocks_y = ceil_div(H, 16);
+    p.occ_groups = ceil_div(M, kOccSlices);
+    const size_t flags_per_chunk = (size_t) p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
     if (sparse) {
         if (int e = ensure_skipping(r)) return e;
-        const size_t zbytes = (size_t) p.occ_blocks_x * p.occ_blocks_y * 2;
+        const size_t zbytes = flags_per_chunk * n_chunks_;
         if (zbytes > r->occ_zero_bytes) {
             HIP_TRY(hipStreamSynchronize(r->stream));
-            for (uint8_t*& z : r->d_occ_zero) { (void) hipFree(z); z = nullptr; }
+            (void) hipFree(r->d_occ_zero[0]);
+            r->d_occ_zero[0] = nullptr;
             r->occ_zero_bytes = 0;
-            for (uint8_t*& z : r->d_occ_zero) HIP_TRY(hipMalloc((void**) &z, zbytes));
+            HIP_TRY(hipMalloc((void**) &r->d_occ_zero[0], zbytes));
             r->occ_zero_bytes = zbytes;
         }
         p.empty_bits = r->d_empty;
         p.zero_page = r->d_zero_page;
+        p.occ_flags_out = r->d_occ_zero[0];
+        p.pass_start = pa.start;
+        p.pass_slices = D;
+        p.chunk_slices = M;
+        HIP_TRY(launch_occ_flags(p, change, n_chunks_, r->stream));
     }
 
     const int n_chunks = (D + M - 1) / M;
@@ -334,7 +344,7 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple
         // of 4 does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
         const bool sp = sparse && ((p.n_steps * -p.dx_lo) % 4 == 0);
-        p.occ_zero_cur = p.occ_zero_next = sp ? r->d_occ_zero[cur] : nullptr;
+        p.occ_flags = sp ? r->d_occ_zero[0] + (size_t) c * flags_per_chunk : nullptr;
         p.tile_i0 = p.tile_j0 = 0;
         p.tiles_x = ceil_div(W, kChunkTile);
         p.tiles_y = ceil_div(H, kChunkTile);

@@ -95,13 +95,15 @@ struct ChunkParams {
     // occlusion part
     int next_j0, next_n;    // first slice and number of slices of the next chunk (0: none)
     int occ_tiles_x, occ_tiles_y;
-    // empty-block hand-off: an occlusion workgroup whose bricks all map to opacity 0 writes one flag instead of its
-    // 16x16x8 zeros; the chain stages zeros for flagged blocks without touching the plane stack
-    const uint32_t* empty_bits;   // per data brick (k_brick_empty), null: feature off
-    uint8_t* occ_zero_next;       // flags written by the occlusion launch: [slice group][block y][block x]
-    const uint8_t* occ_zero_cur;  // flags read by the chain launch
+    // empty-block hand-off: k_occ_flags marks, once per pass, every occlusion workgroup (16x16 pixels x 8 slices) whose
+    // samples can only touch data bricks that map every value to opacity 0. Such a workgroup exits at once and the chain
+    // stages zeros for its pixels from a page of zeros instead of the plane stack.
+    const uint32_t* empty_bits;   // per data brick (k_brick_empty); used by k_occ_flags only
+    const uint8_t* occ_flags;     // this chunk's flags: [slice group][block y][block x]; null: feature off for this chunk
+    uint8_t* occ_flags_out;       // k_occ_flags: the whole pass, [chunk][slice group][block y][block x]
+    int occ_blocks_x, occ_blocks_y, occ_groups; // blocks per plane row / column, slice groups per chunk
+    int pass_start, pass_slices, chunk_slices;  // k_occ_flags: first slice, slices in the pass, slices per chunk
     const float* zero_page;       // 4 KiB of zeros: the copy source for flagged blocks (keeps the copies per wave uniform)
-    int occ_blocks_x, occ_blocks_y;
     int debug;              // TBRM_DEBUG bitmask (timing experiments only; results are wrong when set)
     long long* debug_clock; // bit 64: block 0 writes s_memtime stamps here
     ChunkStream a, r;
@@ -156,6 +158,7 @@ struct RelayoutParams {
     int to_bricks; // 1: linear -> bricked (padding voxels are zeroed); 0: bricked -> linear
 };
 
+constexpr int kOccSlices = 8;      // slices per occlusion workgroup (kOccDepth in tbrm_light_kernels.hip)
 constexpr int kChunkTile = 32;      // core tile edge of the chunked propagation kernel (pixels)
 constexpr int kChunkThreads = 1024;
 constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
@@ -165,6 +168,7 @@ hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
+hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s);
 hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);

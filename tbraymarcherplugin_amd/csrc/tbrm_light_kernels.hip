@@ -193,7 +193,8 @@ __device__ __forceinline__ void dma_16(const void* src, void* lds_wave_base)
 // the two in-plane axes contribute per-thread constants, the slice axis a per-step value from a small LDS table
 // (which also carries the reference's per-thread (Loop+0.5)/res division out of the loop).
 constexpr int kOccTile = 16;  // pixels per side
-constexpr int kOccDepth = 8;  // slices per workgroup
+constexpr int kOccDepth = 8;  // slices per workgroup (16 was measured: fewer halo bricks per sample, but no faster)
+static_assert(kOccDepth == kOccSlices, "host and kernel disagree on the occlusion workgroup depth");
 
 struct AxisTaps {        // one axis of a trilinear footprint with border addressing
     int i0;              // base tap index (unclamped)
@@ -243,6 +244,85 @@ size_t occlusion_lds_bytes(const ChunkParams& p)
     return n * 512 * esz;
 }
 
+// ---- k_occ_flags: once per pass, which occlusion workgroups are empty ---------------------------------------------
+// One thread per occlusion workgroup (16x16 pixels x 8 slices of one chunk). The workgroup is empty when the brick of
+// every sample's base tap has its k_brick_empty bit set: the bit vouches for every value the 8 taps of a sample based
+// in that brick can take (the brick plus its +1 apron), so every CurrentSample is exactly 0. Workgroups with taps
+// outside the volume are never flagged (a blend with the sampler's border colour can leave both value ranges).
+template <bool CHANGE, int AXIS>
+__global__ __launch_bounds__(256) void k_occ_flags(const ChunkParams p, int n_chunks)
+{
+    constexpr int NS = CHANGE ? 2 : 1;
+    constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS;
+    const int per_chunk = p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_chunks * per_chunk) return;
+    const int c = id / per_chunk, rem = id % per_chunk;
+    const int bx = rem % p.occ_blocks_x, by = (rem / p.occ_blocks_x) % p.occ_blocks_y, zg = rem / (p.occ_blocks_x * p.occ_blocks_y);
+    const int n = min(p.chunk_slices, p.pass_slices - c * p.chunk_slices);
+    const int k0 = zg * kOccDepth;
+    uint8_t flag = 0;
+    if (k0 < n) {
+        const int nk = min(kOccDepth, n - k0);
+        const int j0 = p.pass_start + (c * p.chunk_slices + k0) * p.dir, j1 = j0 + (nk - 1) * p.dir;
+        const int px0 = bx * kOccTile, py0 = by * kOccTile;
+        const int pxl = min(px0 + kOccTile, p.W) - 1, pyl = min(py0 + kOccTile, p.H) - 1;
+        const int dn[3] = {p.data.nx, p.data.ny, p.data.nz};
+        const int bn[3] = {p.data.bnx, p.data.bnxy / p.data.bnx, (p.data.nz + 7) >> 3};
+        int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+#pragma unroll
+        for (int si = 0; si < NS; ++si) {
+            const ChunkStream& s = si == 0 ? p.a : p.r;
+            const int ends[3][2] = {{px0, pxl}, {py0, pyl}, {j0, j1}};
+            constexpr int dims[3] = {dim_u, dim_v, dim_s};
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float cc = (((float) (uint32_t) ends[a][e] + 0.5f) / (float) (uint32_t) p.lv_dims[dims[a]]) + s.uvw_off[dims[a]];
+                    int i0;
+                    float f;
+                    texel_split(cc, (float) dn[dims[a]], i0, f);
+                    lo[dims[a]] = min(lo[dims[a]], i0);
+                    hi[dims[a]] = max(hi[dims[a]], i0 + 1);
+                }
+        }
+        bool ok = true;
+        int b_lo[3], b_hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ok = ok && lo[a] >= 0 && hi[a] < dn[a]; // every tap inside the volume
+            b_lo[a] = max(lo[a] >> 3, 0);
+            b_hi[a] = min(hi[a] >> 3, bn[a] - 1);
+        }
+        if (ok) {
+            for (int z = b_lo[2]; z <= b_hi[2] && ok; ++z)
+                for (int y = b_lo[1]; y <= b_hi[1] && ok; ++y)
+                    for (int x = b_lo[0]; x <= b_hi[0]; ++x) {
+                        const int b = z * p.data.bnxy + y * p.data.bnx + x;
+                        if (!((p.empty_bits[b >> 5] >> (b & 31)) & 1u)) { ok = false; break; }
+                    }
+            flag = ok ? 1 : 0;
+        }
+    }
+    p.occ_flags_out[id] = flag;
+}
+
+template <bool CHANGE>
+static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t s)
+{
+    const int total = n_chunks * p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
+    const dim3 grid((total + 255) / 256), block(256);
+    if (p.axis == 0) hipLaunchKernelGGL((k_occ_flags<CHANGE, 0>), grid, block, 0, s, p, n_chunks);
+    else if (p.axis == 1) hipLaunchKernelGGL((k_occ_flags<CHANGE, 1>), grid, block, 0, s, p, n_chunks);
+    else hipLaunchKernelGGL((k_occ_flags<CHANGE, 2>), grid, block, 0, s, p, n_chunks);
+    return hipGetLastError();
+}
+hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s)
+{
+    return change ? launch_flags2<true>(p, n_chunks, s) : launch_flags2<false>(p, n_chunks, s);
+}
+
 template <int DFMT, bool CHANGE, int AXIS>
 __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
 {
@@ -252,7 +332,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     __shared__ float s_alpha[256];
     __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
     __shared__ int s_i[2][kOccDepth], s_flags[2][kOccDepth]; // flags: bit0 tap0 in range, bit1 tap1 in range, bit2 w == saturate(w)
-    __shared__ int s_b0[3], s_nb[3], s_staged, s_maybe_empty, s_block_empty, s_interior;
+    __shared__ int s_b0[3], s_nb[3], s_staged, s_interior;
     __shared__ uint32_t s_o0[2][kOccDepth], s_o1[2][kOccDepth];
     __shared__ int s_ends[12], s_end_dim[12];
 
@@ -260,6 +340,9 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     const int data_dims[3] = {p.data.nx, p.data.ny, p.data.nz};
     const int px0 = blockIdx.x * kOccTile, py0 = blockIdx.y * kOccTile, k0 = blockIdx.z * kOccDepth;
     const int nk = min(kOccDepth, p.n_steps - k0);
+
+    // flagged empty by k_occ_flags: every CurrentSample of this workgroup is exactly 0 and the chain knows it
+    if (p.occ_flags && p.occ_flags[(blockIdx.z * p.occ_blocks_y + blockIdx.y) * p.occ_blocks_x + blockIdx.x] && !(p.debug & 256)) return;
 
     s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
     if (threadIdx.x < NS * kOccDepth) { // slice-axis taps of each step of this workgroup (wave-uniform values)
@@ -310,45 +393,8 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
         }
         s_staged = (count > 0 && count * 512 * ESZ <= lds_budget_bytes) ? 1 : 0; // else: read taps from global memory
         s_interior = touches_border ? 0 : 1;
-        // workgroups with taps outside the volume are never skipped: a blend of the border colour with in-volume taps can
-        // leave both value ranges (k_brick_empty's bit only vouches for a sample whose 8 taps lie in the brick's apron)
-        s_maybe_empty = (p.empty_bits && count > 0 && count <= 64 && !touches_border) ? 1 : 0;
     }
     __syncthreads();
-
-    // Empty block: the brick of every sample's base tap has its k_brick_empty bit set, i.e. every value the sample's 8
-    // taps can take (the brick plus its +1 apron) maps to opacity 0, so every CurrentSample is exactly 0. One flag
-    // replaces the 16x16x8 zeros; the chain stages zeros for it.
-    if (p.occ_zero_next) {
-        bool empty = false;
-        if (s_maybe_empty) {
-            if (threadIdx.x < 64) {
-                const int count = s_nb[0] * s_nb[1] * s_nb[2];
-                bool mine = true;
-                if ((int) threadIdx.x < count) {
-                    const int lx = threadIdx.x % s_nb[0], ly = (threadIdx.x / s_nb[0]) % s_nb[1], lz = threadIdx.x / (s_nb[0] * s_nb[1]);
-                    const int b = (s_b0[2] + lz) * p.data.bnxy + (s_b0[1] + ly) * p.data.bnx + (s_b0[0] + lx);
-                    mine = (p.empty_bits[b >> 5] >> (b & 31)) & 1u;
-                }
-                const bool all_empty = __all(mine);
-                if (threadIdx.x == 0) s_block_empty = all_empty ? 1 : 0;
-            }
-            __syncthreads();
-            empty = s_block_empty != 0;
-        }
-        if (threadIdx.x == 0)
-            p.occ_zero_next[(blockIdx.z * p.occ_blocks_y + blockIdx.y) * p.occ_blocks_x + blockIdx.x] = empty ? 1 : 0;
-        if (empty && (p.debug & 1024)) { // diagnostic: write the zeros explicitly
-            const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-            const int px_ = px0 + (wave_ & 1) * 8 + (lane_ & 7), py_ = py0 + (wave_ >> 1) * 8 + (lane_ >> 3);
-            if (px_ < p.W && py_ < p.H)
-                for (int q = 0; q < nk; ++q) {
-                    p.a.occ_next[(k0 + q) * p.H * p.W + py_ * p.W + px_] = 0.0f;
-                    if constexpr (CHANGE) p.r.occ_next[(k0 + q) * p.H * p.W + py_ * p.W + px_] = 0.0f;
-                }
-        }
-        if (empty && !(p.debug & 256)) return;
-    }
 
     const bool staged = s_staged && !(p.debug & 128);
     const int b0[3] = {s_b0[0], s_b0[1], s_b0[2]}, nb[3] = {s_nb[0], s_nb[1], s_nb[2]};
@@ -417,6 +463,9 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
             const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
             float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
 
+            // the 8 samples of a thread are independent dependency chains (LDS taps -> filter -> TF -> pow): unrolled so the
+            // scheduler interleaves them; with only a few waves per SIMD a rolled loop runs at one chain's latency
+#pragma unroll 4
             for (int q = 0; q < nk; ++q) {
                 const float fs = s_f[si][q];
                 const int fl = s_flags[si][q];
@@ -498,15 +547,15 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const bool st_ok = st_row < g.HY && (unsigned) st_py < (unsigned) p.H;
     const int st_dst = wave * 256;                            // this wave's 64 x 4 floats
     // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: zeros are staged without a copy
-    bool st_zero[2] = {false, false}; // this thread's 4 pixels lie in empty blocks, slices [0,8) / [8,16) of the chunk
-    if (p.occ_zero_cur && st_ok && !(p.debug & 512)) {
+    bool st_zero[2] = {false, false}; // this thread's 4 pixels lie in empty blocks of slice group 0 / 1 of the chunk
+    if (p.occ_flags && st_ok && !(p.debug & 512)) {
         const int x_first = base_x - g.padx + st_col, x_last = x_first + 3;
         const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = st_py >> 4;
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
             bool zero = x_last >= 0 && x_first < p.W && z * kOccDepth < g.n;
             if (zero) {
-                const uint8_t* row = p.occ_zero_cur + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
+                const uint8_t* row = p.occ_flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
                 zero = row[bx0] != 0 && row[bx1] != 0;
             }
             st_zero[z] = zero;
@@ -517,7 +566,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             float* dst = lds + 2 * g.elems + (sf % kOccRing) * g.elems + st_dst;
             // flagged-empty lanes copy from a page of zeros (L2-resident) instead of the plane stack: same number of copy
             // instructions per wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on
-            const bool zero = st_zero[sf >> 3];
+            const bool zero = st_zero[sf / kOccDepth];
             const float* zsrc = p.zero_page + (threadIdx.x & 63) * 4;
             dma_16(zero ? zsrc : p.a.occ_cur + sf * plane_elems + st_src, dst);
             if constexpr (CHANGE) dma_16(zero ? zsrc : p.r.occ_cur + sf * plane_elems + st_src, dst + stream_stride);
