@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtbrm.so")
+LIB_PATH = os.environ.get("TBRM_LIB_PATH") or os.path.join(HERE, "lib", "libtbrm.so")  # override: A/B a second build
 
 # enums (include/tbrm.h)
 OK, ERR_INVALID_ARG, ERR_NOT_INITIALIZED, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED = range(6)

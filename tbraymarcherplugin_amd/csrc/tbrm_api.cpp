@@ -353,7 +353,7 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     // Measured on MI355X (round 1): the cross-stream event waits cost more than the overlap gains (fused Change 7.8 ms
     // vs 6.1 ms in-order), so it is off unless TBRM_OVERLAP=1. Dependencies when on: chain(c) needs occlusion(c);
     // occlusion(c+2) overwrites the buffer chain(c) reads.
-    const bool overlap = getenv("TBRM_OVERLAP") != nullptr;
+    const bool overlap = r->stream_occ != nullptr;
     hipStream_t so = overlap ? r->stream_occ : r->stream;
     if (overlap) {
         HIP_TRY(hipEventRecord(r->ev_pass, r->stream)); // everything enqueued so far (earlier passes use the same buffers)
@@ -528,6 +528,8 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     host_world_to_local(world->volume_transform, p.m);
     host_local_clipping(*world, p.cc, p.cd);
     p.clip_mode = raymarch_clip_mode(p.cc, p.cd);
+    p.share_grid = (r->lv_dims[0] == r->desc.dim_x && r->lv_dims[1] == r->desc.dim_y && r->lv_dims[2] == r->desc.dim_z &&
+                    !getenv("TBRM_NO_SHARE_GRID")) ? 1 : 0;
     p.tile_x0 = tile->x0; p.tile_y0 = tile->y0; p.tile_w = tile->w; p.tile_h = tile->h;
     p.row_group_step = tile->row_group_step > 0 ? tile->row_group_step : 1;
     p.steps = rp->steps;
@@ -606,7 +608,9 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
 
     CREATE_TRY(hipSetDevice(desc->device));
     CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipStreamCreateWithFlags(&r->stream_occ, hipStreamNonBlocking));
+    // A second HIP stream is only created when the (off-by-default) occlusion/chain overlap is requested: merely owning
+    // a second hardware queue slowed the raymarch kernel from 0.96 to 1.46 ms on MI355X (measured, round 1).
+    if (getenv("TBRM_OVERLAP")) CREATE_TRY(hipStreamCreateWithFlags(&r->stream_occ, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
         CREATE_TRY(hipEventCreateWithFlags(&r->ev_occ[k], hipEventDisableTiming));
         CREATE_TRY(hipEventCreateWithFlags(&r->ev_chain[k], hipEventDisableTiming));

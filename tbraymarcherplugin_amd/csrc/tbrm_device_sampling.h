@@ -76,6 +76,44 @@ __device__ __forceinline__ float sample_trilinear(const VolumeDev& v, int ix, in
     return lerp_(c0, c1, fz);
 }
 
+// The eight brick offsets of a trilinear footprint (wrap or clamp addressing): computed once per sample and shared by
+// every volume with the same dimensions.
+struct TapOffsets {
+    uint32_t x0, x1, y0, y1, z0, z1;
+};
+
+template <int MODE>
+__device__ __forceinline__ TapOffsets tap_offsets(const VolumeDev& v, int ix, int iy, int iz)
+{
+    // the +1 tap of an in-range base tap needs no general wrap: it is either base+1 or the first/last texel
+    const int x0 = address<MODE>(ix, v.nx), y0 = address<MODE>(iy, v.ny), z0 = address<MODE>(iz, v.nz);
+    int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
+    if constexpr (MODE == ADDR_WRAP) { x1 = x1 == v.nx ? 0 : x1; y1 = y1 == v.ny ? 0 : y1; z1 = z1 == v.nz ? 0 : z1; }
+    else {
+        x1 = ix + 1 < 0 ? 0 : (x1 >= v.nx ? v.nx - 1 : x1);
+        y1 = iy + 1 < 0 ? 0 : (y1 >= v.ny ? v.ny - 1 : y1);
+        z1 = iz + 1 < 0 ? 0 : (z1 >= v.nz ? v.nz - 1 : z1);
+    }
+    TapOffsets t;
+    t.x0 = brick_off_x(x0); t.x1 = brick_off_x(x1);
+    t.y0 = brick_off_y(y0, v.bnx); t.y1 = brick_off_y(y1, v.bnx);
+    t.z0 = brick_off_z(z0, v.bnxy); t.z1 = brick_off_z(z1, v.bnxy);
+    return t;
+}
+
+template <int FMT>
+__device__ __forceinline__ float sample_trilinear_at(const void* data, const TapOffsets& t, float fx, float fy, float fz)
+{
+    const float t000 = load_voxel<FMT>(data, t.z0 + t.y0 + t.x0), t001 = load_voxel<FMT>(data, t.z0 + t.y0 + t.x1);
+    const float t010 = load_voxel<FMT>(data, t.z0 + t.y1 + t.x0), t011 = load_voxel<FMT>(data, t.z0 + t.y1 + t.x1);
+    const float t100 = load_voxel<FMT>(data, t.z1 + t.y0 + t.x0), t101 = load_voxel<FMT>(data, t.z1 + t.y0 + t.x1);
+    const float t110 = load_voxel<FMT>(data, t.z1 + t.y1 + t.x0), t111 = load_voxel<FMT>(data, t.z1 + t.y1 + t.x1);
+    const float c00 = lerp_(t000, t001, fx), c10 = lerp_(t010, t011, fx);
+    const float c01 = lerp_(t100, t101, fx), c11 = lerp_(t110, t111, fx);
+    const float c0 = lerp_(c00, c10, fy), c1 = lerp_(c01, c11, fy);
+    return lerp_(c0, c1, fz);
+}
+
 // Trilinear fetch with border addressing from pre-split texel coordinates (the propagation shaders'
 // VolumeSampler, LightingShaders.h:82-89).
 template <int FMT>

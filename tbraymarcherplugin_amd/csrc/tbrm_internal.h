@@ -124,6 +124,7 @@ struct RayParams {
     float m[12];        // WorldToLocal rows (3x3 + translation)
     float cc[3], cd[3];
     int clip_mode;      // 0: clip plane provably never clips a sample position; 1: general
+    int share_grid;     // light volume has the data volume's size and wrap addressing: taps share their offsets
     int tile_x0, tile_y0, tile_w, tile_h, row_group_step;
     float steps;
     int jitter_frame;

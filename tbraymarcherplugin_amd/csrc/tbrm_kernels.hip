@@ -163,6 +163,10 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
     int cached_brick = -1;
     bool cached_empty = false;
 
+    // the light volume shares the data volume's footprint when it has the same size and the position is inside the
+    // cube (saturate(CurPos) == CurPos): same texel split, same wrapped indices, same brick offsets
+    const bool same_grid = DMODE == ADDR_WRAP && p.share_grid;
+
     // one sample; returns true when the early-exit threshold was crossed
     auto sample = [&](float step) -> bool {
         int ix, iy, iz;
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
             }
             if (cached_empty) return false; // every tap of this sample maps to opacity 0: exact no-op
         }
-        const float v = sample_trilinear<DFMT, DMODE>(p.data, ix, iy, iz, fx, fy, fz);
+        const TapOffsets dt = tap_offsets<DMODE>(p.data, ix, iy, iz);
+        const float v = sample_trilinear_at<DFMT>(p.data.data, dt, fx, fy, fz);
         // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
         const float tpos = tf_position(v, p.win.center, p.win.width);
         if ((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f)) return false;
@@ -190,12 +195,18 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
         if (a_sat == 0.0f) return false; // 1 - pow(1, s) = 0: the sample contributes exactly nothing
         const float a = 1.0f - pow_(1.0f - a_sat, step);
         // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
-        int lx, ly, lz;
-        float gx, gy, gz;
-        texel_split(saturate_(pos0), lnx, lx, gx);
-        texel_split(saturate_(pos1), lny, ly, gy);
-        texel_split(saturate_(pos2), lnz, lz, gz);
-        const float l = sample_trilinear<LFMT, ADDR_WRAP>(lightv, lx, ly, lz, gx, gy, gz);
+        float l;
+        const float sp0 = saturate_(pos0), sp1 = saturate_(pos1), sp2 = saturate_(pos2);
+        if (same_grid && sp0 == pos0 && sp1 == pos1 && sp2 == pos2) {
+            l = sample_trilinear_at<LFMT>(p.light, dt, fx, fy, fz);
+        } else {
+            int lx, ly, lz;
+            float gx, gy, gz;
+            texel_split(sp0, lnx, lx, gx);
+            texel_split(sp1, lny, ly, gy);
+            texel_split(sp2, lnz, lz, gz);
+            l = sample_trilinear_at<LFMT>(p.light, tap_offsets<ADDR_WRAP>(lightv, lx, ly, lz), gx, gy, gz);
+        }
         cs.x = cs.x * l; cs.y = cs.y * l; cs.z = cs.z * l;
         // AccumulateLightEnergy (RaymarchMaterialCommon.usf:82-88)
         const float om = 1.0f - le3;
