@@ -114,6 +114,44 @@ __device__ __forceinline__ float sample_trilinear_at(const void* data, const Tap
     return lerp_(c0, c1, fz);
 }
 
+// Raw (undecoded) taps of a trilinear footprint: issuing the 8 loads and using them are separate steps, so a sample's
+// loads can be in flight while the previous sample is being shaded.
+template <int FMT> struct RawVoxel { using type = uint32_t; };
+template <> struct RawVoxel<FMT_F32> { using type = float; };
+
+template <int FMT>
+__device__ __forceinline__ typename RawVoxel<FMT>::type load_raw(const void* p, uint32_t i)
+{
+    if constexpr (FMT == FMT_U8) return ((const uint8_t*) p)[i];
+    else if constexpr (FMT == FMT_U16) return ((const uint16_t*) p)[i];
+    else return ((const float*) p)[i];
+}
+template <int FMT>
+__device__ __forceinline__ float decode_raw(typename RawVoxel<FMT>::type r)
+{
+    if constexpr (FMT == FMT_U8) return decode_u8(r);
+    else if constexpr (FMT == FMT_U16) return decode_u16(r);
+    else return r;
+}
+
+template <int FMT>
+struct RawTaps {
+    typename RawVoxel<FMT>::type t[8];
+    __device__ __forceinline__ void issue(const void* data, const TapOffsets& o)
+    {
+        t[0] = load_raw<FMT>(data, o.z0 + o.y0 + o.x0); t[1] = load_raw<FMT>(data, o.z0 + o.y0 + o.x1);
+        t[2] = load_raw<FMT>(data, o.z0 + o.y1 + o.x0); t[3] = load_raw<FMT>(data, o.z0 + o.y1 + o.x1);
+        t[4] = load_raw<FMT>(data, o.z1 + o.y0 + o.x0); t[5] = load_raw<FMT>(data, o.z1 + o.y0 + o.x1);
+        t[6] = load_raw<FMT>(data, o.z1 + o.y1 + o.x0); t[7] = load_raw<FMT>(data, o.z1 + o.y1 + o.x1);
+    }
+    __device__ __forceinline__ float filter(float fx, float fy, float fz) const
+    {
+        const float c00 = lerp_(decode_raw<FMT>(t[0]), decode_raw<FMT>(t[1]), fx), c10 = lerp_(decode_raw<FMT>(t[2]), decode_raw<FMT>(t[3]), fx);
+        const float c01 = lerp_(decode_raw<FMT>(t[4]), decode_raw<FMT>(t[5]), fx), c11 = lerp_(decode_raw<FMT>(t[6]), decode_raw<FMT>(t[7]), fx);
+        return lerp_(lerp_(c00, c10, fy), lerp_(c01, c11, fy), fz);
+    }
+};
+
 // Trilinear fetch with border addressing from pre-split texel coordinates (the propagation shaders'
 // VolumeSampler, LightingShaders.h:82-89).
 template <int FMT>

@@ -167,13 +167,28 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
     // cube (saturate(CurPos) == CurPos): same texel split, same wrapped indices, same brick offsets
     const bool same_grid = DMODE == ADDR_WRAP && p.share_grid;
 
-    // one sample; returns true when the early-exit threshold was crossed
-    auto sample = [&](float step) -> bool {
+    // A sample is split into "issue" (position -> clip / empty-space test -> 16 tap loads) and "shade" (filter, window,
+    // transfer function, opacity correction, light, accumulate). Positions do not depend on shading, so the loads of
+    // sample k+1 are issued before sample k is shaded: the two dependent memory round trips of the reference's loop body
+    // (data fetch, then light fetch) disappear behind the previous sample's arithmetic.
+    struct Pending {
+        bool valid;        // there is a sample
+        bool skip;         // clipped, or inside a brick that maps to opacity 0: exact no-op
+        float step;        // StepSize for the opacity correction
+        float fx, fy, fz;  // data-volume filter weights
+        float gx, gy, gz;  // light-volume filter weights
+        RawTaps<DFMT> d;
+        RawTaps<LFMT> l;
+    };
+    auto issue = [&](float step, Pending& n) {
+        n.valid = true;
+        n.skip = true;
+        n.step = step;
+        if (p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd)) return;
         int ix, iy, iz;
-        float fx, fy, fz;
-        texel_split(pos0, nx, ix, fx);
-        texel_split(pos1, ny, iy, fy);
-        texel_split(pos2, nz, iz, fz);
+        texel_split(pos0, nx, ix, n.fx);
+        texel_split(pos1, ny, iy, n.fy);
+        texel_split(pos2, nz, iz, n.fz);
         if (p.empty_bits) {
             const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
             const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
@@ -183,30 +198,36 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
                 cached_brick = b;
                 cached_empty = (p.empty_bits[b >> 5] >> (b & 31)) & 1u;
             }
-            if (cached_empty) return false; // every tap of this sample maps to opacity 0: exact no-op
+            if (cached_empty) return; // every tap of this sample maps to opacity 0
         }
+        n.skip = false;
         const TapOffsets dt = tap_offsets<DMODE>(p.data, ix, iy, iz);
-        const float v = sample_trilinear_at<DFMT>(p.data.data, dt, fx, fy, fz);
+        n.d.issue(p.data.data, dt);
+        // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
+        const float sp0 = saturate_(pos0), sp1 = saturate_(pos1), sp2 = saturate_(pos2);
+        if (same_grid && sp0 == pos0 && sp1 == pos1 && sp2 == pos2) {
+            n.gx = n.fx; n.gy = n.fy; n.gz = n.fz;
+            n.l.issue(p.light, dt);
+        } else {
+            int lx, ly, lz;
+            texel_split(sp0, lnx, lx, n.gx);
+            texel_split(sp1, lny, ly, n.gy);
+            texel_split(sp2, lnz, lz, n.gz);
+            n.l.issue(p.light, tap_offsets<ADDR_WRAP>(lightv, lx, ly, lz));
+        }
+    };
+    // returns true when the early-exit threshold was crossed
+    auto shade = [&](const Pending& c) -> bool {
+        if (c.skip) return false;
+        const float v = c.d.filter(c.fx, c.fy, c.fz);
         // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
         const float tpos = tf_position(v, p.win.center, p.win.width);
         if ((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f)) return false;
         float4 cs = sample_tf(s_tf, tpos);
         const float a_sat = saturate_(cs.w);
         if (a_sat == 0.0f) return false; // 1 - pow(1, s) = 0: the sample contributes exactly nothing
-        const float a = 1.0f - pow_(1.0f - a_sat, step);
-        // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
-        float l;
-        const float sp0 = saturate_(pos0), sp1 = saturate_(pos1), sp2 = saturate_(pos2);
-        if (same_grid && sp0 == pos0 && sp1 == pos1 && sp2 == pos2) {
-            l = sample_trilinear_at<LFMT>(p.light, dt, fx, fy, fz);
-        } else {
-            int lx, ly, lz;
-            float gx, gy, gz;
-            texel_split(sp0, lnx, lx, gx);
-            texel_split(sp1, lny, ly, gy);
-            texel_split(sp2, lnz, lz, gz);
-            l = sample_trilinear_at<LFMT>(p.light, tap_offsets<ADDR_WRAP>(lightv, lx, ly, lz), gx, gy, gz);
-        }
+        const float a = 1.0f - pow_(1.0f - a_sat, c.step);
+        const float l = c.l.filter(c.gx, c.gy, c.gz);
         cs.x = cs.x * l; cs.y = cs.y * l; cs.z = cs.z * l;
         // AccumulateLightEnergy (RaymarchMaterialCommon.usf:82-88)
         const float om = 1.0f - le3;
@@ -216,16 +237,29 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
         le3 = le3 + (a * om);
         return le3 > 0.95f;
     };
+    // sample idx of the ray: the max_steps full steps (CurPos += LocalCamVec before sampling, :67), then the fractional one
+    auto advance_and_issue = [&](int idx, Pending& n) {
+        if (idx < max_steps) {
+            pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2;
+            issue(step_world, n);
+        } else if (idx == max_steps && final_step > 0.0f) { // :84-93
+            pos0 = pos0 + (sv0 * final_step); pos1 = pos1 + (sv1 * final_step); pos2 = pos2 + (sv2 * final_step);
+            issue(100.0f * final_step, n);
+        } else n.valid = false;
+    };
 
+    Pending pa, pb;
     int k = 0;
-    for (k = 0; k < max_steps; k++) {
-        pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2;
-        if (p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd)) continue;
-        if (sample(step_world)) { le3 = 1.0f; break; }
-    }
-    if (k == max_steps && final_step > 0.0f) {
-        pos0 = pos0 + (sv0 * final_step); pos1 = pos1 + (sv1 * final_step); pos2 = pos2 + (sv2 * final_step);
-        if (!(p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd))) sample(100.0f * final_step);
+    advance_and_issue(0, pa);
+    for (;;) { // two samples per trip so the pending buffers swap roles without copies
+        if (!pa.valid) break;
+        advance_and_issue(k + 1, pb);
+        if (shade(pa) && k < max_steps) { le3 = 1.0f; break; } // early exit belongs to the full steps only (:75-79)
+        ++k;
+        if (!pb.valid) break;
+        advance_and_issue(k + 1, pa);
+        if (shade(pb) && k < max_steps) { le3 = 1.0f; break; }
+        ++k;
     }
     reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
 }
