@@ -58,8 +58,6 @@ struct tbrm_resources {
     int32_t lv_dims[3]{};
     int lv_fmt = FMT_U8;
     hipStream_t stream = nullptr;
-    hipStream_t stream_occ = nullptr;   // occlusion kernels of chunk c+1 run here, beside the chain of chunk c
-    hipEvent_t ev_occ[2]{}, ev_chain[2]{}, ev_pass = nullptr;
 
     void* d_data = nullptr;
     size_t data_bytes = 0;
@@ -79,9 +77,10 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
-    float* d_occ[4]{};             // chunk kernel: occlusion plane stacks, 2 per stream (allocated on first use)
+    float* d_occ[2]{};             // chunk kernel: occlusion plane stack of a span, one per stream (allocated on first use)
     size_t occ_elems = 0;
     uint8_t* d_occ_zero[2]{};      // empty-block flags of the two occlusion buffers
+    uint32_t* d_occ_list = nullptr; // work lists of the pass (one uint32 per flag) followed by 4096 per-chunk counts
     float* d_zero_page = nullptr;  // 4 KiB of zeros
     size_t occ_zero_bytes = 0;
 
@@ -293,87 +292,98 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     }
     if (M <= 0) return TBRM_ERR_UNSUPPORTED;
 
-    // occlusion scratch: 2 (ping-pong over chunks) x 2 (streams) stacks of M planes, allocated on first use
-    const size_t occ_elems = (size_t) 16 * W * H;
+    // The occlusion launches are decoupled from the chain's chunk length: one launch covers a "span" of S slices (several
+    // chunks), so that it has enough workgroups to fill 256 CUs even when the chain has to run short chunks (a strongly
+    // slanted pass runs M = 8) and the live-workgroup list of a span deals an even share to every CU.
+    int S = 64; // measured on MI355X, fused Change at 512^3: S = 16 3.87 ms, 32 3.46, 64 3.30, 128 3.29
+    if (const char* e = getenv("TBRM_OCC_SLICES")) S = atoi(e);
+    S = std::max(M, (S / M) * M);
+    const int n_spans = ceil_div(D, S);
+
+    // occlusion scratch: 2 (streams) stacks of S planes, allocated on first use
+    const size_t occ_elems = (size_t) S * W * H;
     if (occ_elems > r->occ_elems) {
         HIP_TRY(hipStreamSynchronize(r->stream));
         for (float*& b : r->d_occ) { (void) hipFree(b); b = nullptr; }
         r->occ_elems = 0;
-        for (float*& b : r->d_occ) HIP_TRY(hipMalloc((void**) &b, (occ_elems + 2 * kPlaneGuard) * sizeof(float)));
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**) &r->d_occ[k], (occ_elems + 2 * kPlaneGuard) * sizeof(float)));
         r->occ_elems = occ_elems;
     }
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
-    // workgroup of the whole pass, computed up front
+    // workgroup of the whole pass, computed up front, and per span the ascending list of the workgroups with work
     const bool sparse = !getenv("TBRM_NO_SPARSE_OCC");
-    const int n_chunks_ = (D + M - 1) / M;
+    const bool work_list = sparse && !getenv("TBRM_NO_OCC_LIST");
     p.occ_blocks_x = ceil_div(W, 16);
     p.occ_blocks_y = ceil_div(H, 16);
-    p.occ_groups = ceil_div(M, kOccSlices);
-    const size_t flags_per_chunk = (size_t) p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
+    p.occ_groups = ceil_div(S, kOccSlices);
+    const size_t flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
+    const size_t flags_per_span = (size_t) p.occ_groups * flags_per_group;
     if (sparse) {
+        if (n_spans > 4096) return TBRM_ERR_UNSUPPORTED;
         if (int e = ensure_skipping(r)) return e;
-        const size_t zbytes = flags_per_chunk * n_chunks_;
+        const size_t zbytes = flags_per_span * n_spans;
         if (zbytes > r->occ_zero_bytes) {
             HIP_TRY(hipStreamSynchronize(r->stream));
             (void) hipFree(r->d_occ_zero[0]);
+            (void) hipFree(r->d_occ_list);
             r->d_occ_zero[0] = nullptr;
+            r->d_occ_list = nullptr;
             r->occ_zero_bytes = 0;
             HIP_TRY(hipMalloc((void**) &r->d_occ_zero[0], zbytes));
+            HIP_TRY(hipMalloc((void**) &r->d_occ_list, zbytes * sizeof(uint32_t) + 4096 * sizeof(int))); // lists + counts
             r->occ_zero_bytes = zbytes;
         }
         p.empty_bits = r->d_empty;
         p.zero_page = r->d_zero_page;
         p.occ_flags_out = r->d_occ_zero[0];
+        p.occ_list_out = work_list ? r->d_occ_list : nullptr;
+        p.occ_count_out = (int*) (r->d_occ_list + r->occ_zero_bytes);
         p.pass_start = pa.start;
         p.pass_slices = D;
-        p.chunk_slices = M;
-        HIP_TRY(launch_occ_flags(p, change, n_chunks_, r->stream));
+        p.chunk_slices = S;
+        HIP_TRY(launch_occ_flags(p, change, n_spans, r->stream));
     }
 
-    const int n_chunks = (D + M - 1) / M;
-    auto set_chunk = [&](int c) {
-        p.n_steps = std::min(M, D - c * M);
-        p.j0 = pa.start + c * M * pa.dir;
-        p.first_chunk = c == 0;
-        const int cur = (c & 1), nxt = cur ^ 1;
-        p.a.plane_in = r->d_plane[cur] + kPlaneGuard; p.a.plane_out = r->d_plane[nxt] + kPlaneGuard;
-        p.r.plane_in = r->d_plane[2 + cur] + kPlaneGuard; p.r.plane_out = r->d_plane[2 + nxt] + kPlaneGuard;
-        p.a.occ_cur = p.a.occ_next = r->d_occ[cur] + kPlaneGuard; // the occlusion launch of chunk c fills occ_next
-        p.r.occ_cur = p.r.occ_next = r->d_occ[2 + cur] + kPlaneGuard;
-        // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple
-        // of 4 does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
-        const bool sp = sparse && ((p.n_steps * -p.dx_lo) % 4 == 0);
-        p.occ_flags = sp ? r->d_occ_zero[0] + (size_t) c * flags_per_chunk : nullptr;
-        p.tile_i0 = p.tile_j0 = 0;
-        p.tiles_x = ceil_div(W, kChunkTile);
-        p.tiles_y = ceil_div(H, kChunkTile);
-    };
-    // The occlusion of chunk c+1 does not depend on the chain of chunk c, so it can run on a second stream beside it.
-    // Measured on MI355X (round 1): the cross-stream event waits cost more than the overlap gains (fused Change 7.8 ms
-    // vs 6.1 ms in-order), so it is off unless TBRM_OVERLAP=1. Dependencies when on: chain(c) needs occlusion(c);
-    // occlusion(c+2) overwrites the buffer chain(c) reads.
-    const bool overlap = r->stream_occ != nullptr;
-    hipStream_t so = overlap ? r->stream_occ : r->stream;
-    if (overlap) {
-        HIP_TRY(hipEventRecord(r->ev_pass, r->stream)); // everything enqueued so far (earlier passes use the same buffers)
-        HIP_TRY(hipStreamWaitEvent(so, r->ev_pass, 0));
-    }
-    set_chunk(0);
-    HIP_TRY(launch_light_occlusion(p, change, so));
-    if (overlap) HIP_TRY(hipEventRecord(r->ev_occ[0], so));
-    for (int c = 0; c < n_chunks; ++c) {
-        if (c + 1 < n_chunks) {
-            set_chunk(c + 1);
-            if (overlap && c >= 1) HIP_TRY(hipStreamWaitEvent(so, r->ev_chain[(c - 1) & 1], 0)); // buffer (c+1)&1 is free again
-            HIP_TRY(launch_light_occlusion(p, change, so));
-            if (overlap) HIP_TRY(hipEventRecord(r->ev_occ[(c + 1) & 1], so));
+    p.tile_i0 = p.tile_j0 = 0;
+    p.tiles_x = ceil_div(W, kChunkTile);
+    p.tiles_y = ceil_div(H, kChunkTile);
+    p.a.occ_next = r->d_occ[0] + kPlaneGuard;
+    p.r.occ_next = r->d_occ[1] + kPlaneGuard;
+    // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple of 4
+    // does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
+    auto chunk_sparse_ok = [&](int c) { return (std::min(M, D - c * M) * -p.dx_lo) % 4 == 0; };
+    for (int sp = 0; sp < n_spans; ++sp) {
+        const int s0 = sp * S, sn = std::min(S, D - s0);
+        const int c0 = s0 / M, c1 = ceil_div(s0 + sn, M);
+        bool span_sparse = sparse;
+        for (int c = c0; c < c1; ++c) span_sparse = span_sparse && chunk_sparse_ok(c); // else the whole span runs dense
+
+        // occlusion of the span: fills {a,r}.occ_next with sn planes
+        p.j0 = pa.start + s0 * pa.dir;
+        p.n_steps = sn;
+        p.occ_flags = nullptr;
+        p.occ_list = span_sparse && work_list ? r->d_occ_list + (size_t) sp * flags_per_span : nullptr;
+        p.occ_count = span_sparse && work_list ? (const int*) (r->d_occ_list + r->occ_zero_bytes) + sp : nullptr;
+        if (span_sparse && !work_list) p.occ_flags = r->d_occ_zero[0] + (size_t) sp * flags_per_span;
+        HIP_TRY(launch_light_occlusion(p, change, r->stream));
+
+        // the chain, chunk by chunk
+        for (int c = c0; c < c1; ++c) {
+            const int k0 = c * M - s0; // first slice of the chunk within the span
+            p.n_steps = std::min(M, D - c * M);
+            p.j0 = pa.start + c * M * pa.dir;
+            p.first_chunk = c == 0;
+            const int cur = (c & 1), nxt = cur ^ 1;
+            p.a.plane_in = r->d_plane[cur] + kPlaneGuard; p.a.plane_out = r->d_plane[nxt] + kPlaneGuard;
+            p.r.plane_in = r->d_plane[2 + cur] + kPlaneGuard; p.r.plane_out = r->d_plane[2 + nxt] + kPlaneGuard;
+            p.a.occ_cur = p.a.occ_next + (size_t) k0 * W * H;
+            p.r.occ_cur = p.r.occ_next + (size_t) k0 * W * H;
+            p.occ_phase = k0 % kOccSlices;
+            p.occ_flags = span_sparse ? r->d_occ_zero[0] + (size_t) sp * flags_per_span + (size_t) (k0 / kOccSlices) * flags_per_group : nullptr;
+            HIP_TRY(launch_light_chain(p, change, r->lv_fmt, r->stream));
+            ++r->launches[0];
         }
-        set_chunk(c);
-        if (overlap) HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_occ[c & 1], 0));
-        HIP_TRY(launch_light_chain(p, change, r->lv_fmt, r->stream));
-        if (overlap) HIP_TRY(hipEventRecord(r->ev_chain[c & 1], r->stream));
-        ++r->launches[0];
     }
     if ((p.debug & 64) && dbg_clock) {
         long long h[64];
@@ -608,14 +618,6 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
 
     CREATE_TRY(hipSetDevice(desc->device));
     CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    // A second HIP stream is only created when the (off-by-default) occlusion/chain overlap is requested: merely owning
-    // a second hardware queue slowed the raymarch kernel from 0.96 to 1.46 ms on MI355X (measured, round 1).
-    if (getenv("TBRM_OVERLAP")) CREATE_TRY(hipStreamCreateWithFlags(&r->stream_occ, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) {
-        CREATE_TRY(hipEventCreateWithFlags(&r->ev_occ[k], hipEventDisableTiming));
-        CREATE_TRY(hipEventCreateWithFlags(&r->ev_chain[k], hipEventDisableTiming));
-    }
-    CREATE_TRY(hipEventCreateWithFlags(&r->ev_pass, hipEventDisableTiming));
     CREATE_TRY(hipMalloc(&r->d_data, r->data_bricked_bytes));
     CREATE_TRY(hipMalloc((void**) &r->d_tf, 256 * sizeof(float4)));
     CREATE_TRY(hipMalloc(&r->d_light, r->light_bricked_bytes));
@@ -646,11 +648,6 @@ int tbrm_resources_destroy(tbrm_resources* r)
     if (!r) return TBRM_OK;
     (void) hipSetDevice(r->desc.device);
     if (r->stream) (void) hipStreamSynchronize(r->stream);
-    if (r->stream_occ) (void) hipStreamSynchronize(r->stream_occ);
-    for (hipEvent_t e : r->ev_occ) if (e) (void) hipEventDestroy(e);
-    for (hipEvent_t e : r->ev_chain) if (e) (void) hipEventDestroy(e);
-    if (r->ev_pass) (void) hipEventDestroy(r->ev_pass);
-    if (r->stream_occ) (void) hipStreamDestroy(r->stream_occ);
     (void) hipFree(r->d_data);
     (void) hipFree(r->d_tf);
     (void) hipFree(r->d_light);
@@ -659,6 +656,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (float* pl : r->d_plane) (void) hipFree(pl);
     for (float* oc : r->d_occ) (void) hipFree(oc);
     for (uint8_t* z : r->d_occ_zero) (void) hipFree(z);
+    (void) hipFree(r->d_occ_list);
     (void) hipFree(r->d_zero_page);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);

@@ -99,11 +99,20 @@ struct ChunkParams {
     // samples can only touch data bricks that map every value to opacity 0. Such a workgroup exits at once and the chain
     // stages zeros for its pixels from a page of zeros instead of the plane stack.
     const uint32_t* empty_bits;   // per data brick (k_brick_empty); used by k_occ_flags only
-    const uint8_t* occ_flags;     // this chunk's flags: [slice group][block y][block x]; null: feature off for this chunk
+    const uint8_t* occ_flags;     // flags from the slice group holding the chunk's first slice on: [slice group][block y][block x];
+                                  // null: feature off for this chunk
+    int occ_phase;                // index of the chunk's first slice within that slice group
     uint8_t* occ_flags_out;       // k_occ_flags: the whole pass, [chunk][slice group][block y][block x]
     int occ_blocks_x, occ_blocks_y, occ_groups; // blocks per plane row / column, slice groups per chunk
     int pass_start, pass_slices, chunk_slices;  // k_occ_flags: first slice, slices in the pass, slices per chunk
     const float* zero_page;       // 4 KiB of zeros: the copy source for flagged blocks (keeps the copies per wave uniform)
+    // work list: the non-empty workgroups of each chunk in ascending order (k_occ_compact). The occlusion launch keeps its
+    // full grid; workgroup i takes entry i of the list or exits, so the live ones are dealt evenly over the CUs instead
+    // of landing wherever the dense part of the volume happens to map.
+    const uint32_t* occ_list;     // this chunk's list; null: every workgroup takes its own grid position
+    const int* occ_count;         // this chunk's number of list entries
+    uint32_t* occ_list_out;       // k_occ_compact: the whole pass, [chunk][per-chunk capacity]
+    int* occ_count_out;           // k_occ_compact: [chunk]
     int debug;              // TBRM_DEBUG bitmask (timing experiments only; results are wrong when set)
     long long* debug_clock; // bit 64: block 0 writes s_memtime stamps here
     ChunkStream a, r;
@@ -169,7 +178,7 @@ hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
-hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s);
+hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s); // + the work lists
 hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);

@@ -308,6 +308,37 @@ __global__ __launch_bounds__(256) void k_occ_flags(const ChunkParams p, int n_ch
     p.occ_flags_out[id] = flag;
 }
 
+// ---- k_occ_compact: per chunk, the ascending list of workgroups that are NOT flagged -----------------------------
+// One workgroup per chunk; thread t owns a contiguous run of the chunk's flags, a block-wide exclusive scan of the
+// per-thread counts gives every live workgroup its list position (deterministic, ascending).
+__global__ __launch_bounds__(256) void k_occ_compact(const ChunkParams p)
+{
+    __shared__ int s_scan[256];
+    const int per_chunk = p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
+    const int c = blockIdx.x;
+    const uint8_t* flags = p.occ_flags_out + (size_t) c * per_chunk;
+    uint32_t* list = p.occ_list_out + (size_t) c * per_chunk;
+    const int n = min(p.chunk_slices, p.pass_slices - c * p.chunk_slices);
+    const int live_groups = (n + kOccDepth - 1) / kOccDepth;       // slice groups past the chunk's last slice have no work
+    const int live = live_groups * p.occ_blocks_y * p.occ_blocks_x;
+    const int run = (per_chunk + 255) / 256;
+    const int i0 = min((int) threadIdx.x * run, live), i1 = min(i0 + run, live);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) mine += flags[i] ? 0 : 1;
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele scan
+        const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[threadIdx.x] - mine;
+    for (int i = i0; i < i1; ++i)
+        if (!flags[i]) list[pos++] = (uint32_t) i;
+    if (threadIdx.x == 255) p.occ_count_out[c] = s_scan[255];
+}
+
 template <bool CHANGE>
 static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t s)
 {
@@ -316,6 +347,7 @@ static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t 
     if (p.axis == 0) hipLaunchKernelGGL((k_occ_flags<CHANGE, 0>), grid, block, 0, s, p, n_chunks);
     else if (p.axis == 1) hipLaunchKernelGGL((k_occ_flags<CHANGE, 1>), grid, block, 0, s, p, n_chunks);
     else hipLaunchKernelGGL((k_occ_flags<CHANGE, 2>), grid, block, 0, s, p, n_chunks);
+    if (p.occ_list_out) hipLaunchKernelGGL(k_occ_compact, dim3(n_chunks), block, 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s)
@@ -338,11 +370,19 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
 
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
     const int data_dims[3] = {p.data.nx, p.data.ny, p.data.nz};
-    const int px0 = blockIdx.x * kOccTile, py0 = blockIdx.y * kOccTile, k0 = blockIdx.z * kOccDepth;
+    // which block of the chunk: its own grid position, or (sparse chunks) entry `linear id` of the chunk's work list —
+    // workgroups flagged empty by k_occ_flags (every CurrentSample exactly 0, and the chain knows it) are not on the list
+    int gx = blockIdx.x, gy = blockIdx.y, gz = blockIdx.z;
+    if (p.occ_list) {
+        const int slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (slot >= *p.occ_count) return;
+        const int id = (int) p.occ_list[slot];
+        gx = id % p.occ_blocks_x;
+        gy = (id / p.occ_blocks_x) % p.occ_blocks_y;
+        gz = id / (p.occ_blocks_x * p.occ_blocks_y);
+    } else if (p.occ_flags && p.occ_flags[(gz * p.occ_blocks_y + gy) * p.occ_blocks_x + gx]) return; // list off (A/B runs)
+    const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
     const int nk = min(kOccDepth, p.n_steps - k0);
-
-    // flagged empty by k_occ_flags: every CurrentSample of this workgroup is exactly 0 and the chain knows it
-    if (p.occ_flags && p.occ_flags[(blockIdx.z * p.occ_blocks_y + blockIdx.y) * p.occ_blocks_x + blockIdx.x] && !(p.debug & 256)) return;
 
     s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
     if (threadIdx.x < NS * kOccDepth) { // slice-axis taps of each step of this workgroup (wave-uniform values)
@@ -553,7 +593,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = st_py >> 4;
 #pragma unroll
         for (int z = 0; z < 2; ++z) {
-            bool zero = x_last >= 0 && x_first < p.W && z * kOccDepth < g.n;
+            bool zero = x_last >= 0 && x_first < p.W && z * kOccDepth < p.occ_phase + g.n;
             if (zero) {
                 const uint8_t* row = p.occ_flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
                 zero = row[bx0] != 0 && row[bx1] != 0;
@@ -566,7 +606,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             float* dst = lds + 2 * g.elems + (sf % kOccRing) * g.elems + st_dst;
             // flagged-empty lanes copy from a page of zeros (L2-resident) instead of the plane stack: same number of copy
             // instructions per wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on
-            const bool zero = st_zero[sf / kOccDepth];
+            const bool zero = st_zero[(p.occ_phase + sf) / kOccDepth];
             const float* zsrc = p.zero_page + (threadIdx.x & 63) * 4;
             dma_16(zero ? zsrc : p.a.occ_cur + sf * plane_elems + st_src, dst);
             if constexpr (CHANGE) dma_16(zero ? zsrc : p.r.occ_cur + sf * plane_elems + st_src, dst + stream_stride);
