@@ -274,10 +274,6 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     p.cx = 0;
     p.cy = 0;
     p.b_added = b_added;
-    { const char* e = getenv("TBRM_DEBUG"); p.debug = e ? atoi(e) : 0; }
-    static long long* dbg_clock = nullptr;
-    if ((p.debug & 64) && !dbg_clock) HIP_TRY(hipMalloc((void**) &dbg_clock, 64 * sizeof(long long)));
-    p.debug_clock = dbg_clock;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
     if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
 
@@ -384,14 +380,6 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
             HIP_TRY(launch_light_chain(p, change, r->lv_fmt, r->stream));
             ++r->launches[0];
         }
-    }
-    if ((p.debug & 64) && dbg_clock) {
-        long long h[64];
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        HIP_TRY(hipMemcpy(h, dbg_clock, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[tbrm debug] chain block 0 clock deltas:");
-        for (int k = 1; k < 48; ++k) fprintf(stderr, " %lld", h[k] - h[k - 1]);
-        fprintf(stderr, "\n");
     }
     return TBRM_OK;
 }

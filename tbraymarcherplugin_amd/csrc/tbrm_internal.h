@@ -113,8 +113,6 @@ struct ChunkParams {
     const int* occ_count;         // this chunk's number of list entries
     uint32_t* occ_list_out;       // k_occ_compact: the whole pass, [chunk][per-chunk capacity]
     int* occ_count_out;           // k_occ_compact: [chunk]
-    int debug;              // TBRM_DEBUG bitmask (timing experiments only; results are wrong when set)
-    long long* debug_clock; // bit 64: block 0 writes s_memtime stamps here
     ChunkStream a, r;
 };
 

@@ -164,6 +164,15 @@ __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
 
 constexpr int kOccRing = 3; // slices the occlusion operands are staged ahead of their use
 
+// Workgroup barrier for LDS traffic only. __syncthreads() carries a workgroup-scope fence, which the compiler has to
+// lower to s_waitcnt vmcnt(0): inside the chain's slice loop that would drain the asynchronous global->LDS copies
+// issued for the slices AHEAD at every barrier and expose their full latency once per slice. Here only this wave's LDS
+// operations are waited for; copy completion is tracked explicitly with s_waitcnt vmcnt(N) by the caller.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     }
     __syncthreads();
 
-    const bool staged = s_staged && !(p.debug & 128);
+    const bool staged = s_staged != 0;
     const int b0[3] = {s_b0[0], s_b0[1], s_b0[2]}, nb[3] = {s_nb[0], s_nb[1], s_nb[2]};
     if (staged) { // copy the bricks: 512*ESZ bytes each, 16 bytes per lane
         constexpr int PIECES = 512 * ESZ / 16;
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                 bool inside = true;
                 if constexpr (!CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
                 float occ = 0.0f;
-                if (aw > 0.0f && inside && !(p.debug & 16)) {
+                if (aw > 0.0f && inside) {
                     const uint32_t w0 = s_o0[si][q], w1 = s_o1[si][q];
                     const bool a0 = fl & 1, a1 = fl & 2;
                     // tap t: bit0 = u tap, bit1 = v tap, bit2 = slice tap
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                     } else { // x = slice, y = u, z = v
                         val = lerp_(lerp_(lerp_(t0, t4, fs), lerp_(t1, t5, fs), tu.f), lerp_(lerp_(t2, t6, fs), lerp_(t3, t7, fs), tu.f), tv.f);
                     }
-                    occ = (p.debug & 32) ? val : windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
+                    occ = windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
                 }
                 out[q * plane_elems] = occ;
             }
@@ -569,9 +578,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int plane_elems = p.H * p.W;
     const int base_x = (int) blockIdx.x * T, base_y = (int) blockIdx.y * T;
 
-    int stamp = 0;
-    auto tick = [&]() { if ((p.debug & 64) && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && stamp < 64) p.debug_clock[stamp++] = (long long) __builtin_amdgcn_s_memtime(); };
-    tick();
 
     // LDS map (floats): stream si: [win 0][win 1][occ ring 0..2]; then the light-volume tile (bytes)
     float* const lds = (float*) smem;
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int st_dst = wave * 256;                            // this wave's 64 x 4 floats
     // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: zeros are staged without a copy
     bool st_zero[2] = {false, false}; // this thread's 4 pixels lie in empty blocks of slice group 0 / 1 of the chunk
-    if (p.occ_flags && st_ok && !(p.debug & 512)) {
+    if (p.occ_flags && st_ok) {
         const int x_first = base_x - g.padx + st_col, x_last = x_first + 3;
         const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = st_py >> 4;
 #pragma unroll
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         }
     }
     auto stage_occ = [&](int sf) {
-        if (sf < g.n && st_ok && !(p.debug & 4)) {
+        if (sf < g.n && st_ok) {
             float* dst = lds + 2 * g.elems + (sf % kOccRing) * g.elems + st_dst;
             // flagged-empty lanes copy from a page of zeros (L2-resident) instead of the plane stack: same number of copy
             // instructions per wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on
@@ -750,7 +756,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         }
     }
     __syncthreads();
-    tick();
 
     // float light volumes: the owned voxel is fetched kOccRing slices ahead into registers
     float lvq[kOccRing] = {0.0f, 0.0f, 0.0f};
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         const float* oc = lds + (2 + ring) * g.elems;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            if (r < rmin[k] || (k > 0 && (p.debug & 2))) continue;
+            if (r < rmin[k]) continue;
             float lval[NS];
 #pragma unroll
             for (int si = 0; si < NS; ++si) {
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 bool write;
                 if constexpr (!CHANGE) { delta = lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }      // :123-126
                 else { delta = 0.0f; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }                          // Change :152
-                if (write && !(p.debug & 1)) {
+                if (write) {
                     if constexpr (LV_LDS) {
                         const float old = decode_u8(lv_tile[vi]);
                         const float nv = CHANGE ? old + lval[0] - lval[NS - 1] : old + delta;                  // :126 / Change :154
@@ -815,18 +820,19 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 step(s, u & 1, u % 3, lvq[u % 3]);
                 lvq[u % 3] = fetch_lv(s + 3);
             }
-            if (p.debug & 2048) tick();
-            __syncthreads(); // every wave is done reading ring slot u%3 and window u&1
-            if (p.debug & 2048) tick();
+            lds_barrier(); // every wave is done reading ring slot u%3 and window u&1, and its window writes are visible
             stage_occ(s + 3);
-            if (p.debug & 2048) tick();
-            // loads (incl. global->LDS copies) complete in issue order: with at most the loads of the two youngest
-            // refills outstanding, the copies for slice s+1 have landed
-            if constexpr (LV_LDS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS + 1)) : "memory");
-            if (p.debug & 2048) tick();
-            __syncthreads(); // slice s+1's occlusion is visible to every wave
-            tick();
+            // The copies complete in issue order and, with a UNORM8 light volume, they are the only vector-memory
+            // operations of the loop: once at most the copies of the slices after s+1 (NS per slice, those that exist)
+            // are outstanding, the ones for slice s+1 have landed. A float light volume adds per-lane loads and
+            // conditional stores of the owned voxel to the count, so that variant drains everything.
+            if constexpr (LV_LDS) {
+                const int younger = min(g.n - 2 - s, 2); // slices s+2, s+3 if inside the chunk
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier(); // slice s+1's occlusion is visible to every wave
         }
     }
 
@@ -836,7 +842,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         for (int c = threadIdx.x; c < chunks; c += kChunkThreads) {
             bool exists;
             const uint32_t gofs = tile_brick_global(c >> 5, exists) + (uint32_t) (c & 31) * 16u;
-            if (exists && !(p.debug & 1)) *(uint4*) ((uint8_t*) p.light + gofs) = *(const uint4*) (lv_tile + c * 16);
+            if (exists) *(uint4*) ((uint8_t*) p.light + gofs) = *(const uint4*) (lv_tile + c * 16);
         }
     }
 }
