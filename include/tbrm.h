@@ -250,6 +250,11 @@ TBRM_API int tbrm_last_gpu_time_ms(tbrm_resources* res, int kind, float* out_ms)
  * (65536 floats) as evaluated ON THE DEVICE, so a test can compare them with IEEE c/255 and c/65535. */
 TBRM_API int tbrm_selftest_unorm_decode(int device, float* out_u8_256, float* out_u16_65536);
 
+/* Self-test of the kernels' UNORM8 store: out[i] = what in[i] reads back as after a round trip through a UNORM8
+ * render target (D3D11: NaN -> 0, clamp to [0,1], trunc(x*255 + 0.5), load code/255), evaluated ON THE DEVICE with the
+ * routine the propagation kernels use for WriteBuffer / the light volume (RaymarchVolume.cpp:857-866 picks PF_G8). */
+TBRM_API int tbrm_selftest_unorm8_roundtrip(int device, const float* in, size_t n, float* out);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* host parameter math, no GPU needed (LightingShaderUtils.cpp:29-265, LightingShaders.cpp:48-131)     */
 /* Fills out[0..1]; *n_passes = number of axis passes an Add would run (it breaks on weight == 0).      */

@@ -111,7 +111,7 @@ SYMBOLS = [
     "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_selftest_unorm_decode", "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
@@ -163,6 +163,7 @@ def load():
     lib.tbrm_light_volume_device_ptr.argtypes = [vp, P(vp), P(C.c_size_t)]
     lib.tbrm_launch_counters.argtypes = [vp, P(C.c_uint64 * 3)]
     lib.tbrm_selftest_unorm_decode.argtypes = [C.c_int, vp, vp]
+    lib.tbrm_selftest_unorm8_roundtrip.argtypes = [C.c_int, vp, C.c_size_t, vp]
     lib.tbrm_flush.argtypes = [vp]
     lib.tbrm_stream.argtypes = [vp, P(vp)]
     lib.tbrm_last_gpu_time_ms.argtypes = [vp, C.c_int, P(C.c_float)]
@@ -254,6 +255,13 @@ def selftest_unorm_decode(device=0):
     u8, u16 = np.empty(256, dtype=np.float32), np.empty(65536, dtype=np.float32)
     check(load().tbrm_selftest_unorm_decode(device, u8.ctypes.data, u16.ctypes.data))
     return u8, u16
+
+
+def selftest_unorm8_roundtrip(values, device=0):
+    v = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.empty_like(v)
+    check(load().tbrm_selftest_unorm8_roundtrip(device, v.ctypes.data, v.size, out.ctypes.data))
+    return out
 
 
 def device_count():

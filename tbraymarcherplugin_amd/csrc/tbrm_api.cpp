@@ -77,11 +77,10 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
-    float* d_occ[2]{};             // chunk kernel: occlusion plane stack of a span, one per stream (allocated on first use)
+    float* d_occ = nullptr;        // chunk kernel: page of ones + the occlusion plane stacks of a span (allocated on first use)
     size_t occ_elems = 0;
     uint8_t* d_occ_zero[2]{};      // empty-block flags of the two occlusion buffers
     uint32_t* d_occ_list = nullptr; // work lists of the pass (one uint32 per flag) followed by 4096 per-chunk counts
-    float* d_zero_page = nullptr;  // 4 KiB of zeros
     size_t occ_zero_bytes = 0;
 
     // empty-space-skipping metadata
@@ -294,17 +293,24 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     int S = 64; // measured on MI355X, fused Change at 512^3: S = 16 3.87 ms, 32 3.46, 64 3.30, 128 3.29
     if (const char* e = getenv("TBRM_OCC_SLICES")) S = atoi(e);
     S = std::max(M, (S / M) * M);
-    const int n_spans = ceil_div(D, S);
 
-    // occlusion scratch: 2 (streams) stacks of S planes, allocated on first use
-    const size_t occ_elems = (size_t) S * W * H;
+    // occlusion scratch, allocated on first use: ONE allocation = [page of ones | guard][stream a: S planes][guard]
+    // [stream r: S planes][guard], so that the chain addresses every copy source as base + 32-bit offset
+    size_t occ_elems = (size_t) S * W * H;
+    while (S > M && (2 * occ_elems + 3 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) { S -= M; occ_elems = (size_t) S * W * H; }
+    const size_t occ_total = 2 * occ_elems + 3 * kPlaneGuard;
+    if (occ_total * sizeof(float) >= ((size_t) 1 << 32)) return TBRM_ERR_UNSUPPORTED;
     if (occ_elems > r->occ_elems) {
         HIP_TRY(hipStreamSynchronize(r->stream));
-        for (float*& b : r->d_occ) { (void) hipFree(b); b = nullptr; }
+        (void) hipFree(r->d_occ);
+        r->d_occ = nullptr;
         r->occ_elems = 0;
-        for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**) &r->d_occ[k], (occ_elems + 2 * kPlaneGuard) * sizeof(float)));
+        HIP_TRY(hipMalloc((void**) &r->d_occ, occ_total * sizeof(float)));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_occ, 0x3f800000, 1024, r->stream)); // the page of ones
         r->occ_elems = occ_elems;
     }
+    const int n_spans = ceil_div(D, S);
+    const size_t occ_off_a = kPlaneGuard, occ_off_r = kPlaneGuard + r->occ_elems + kPlaneGuard;
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
     // workgroup of the whole pass, computed up front, and per span the ascending list of the workgroups with work
@@ -331,7 +337,6 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
             r->occ_zero_bytes = zbytes;
         }
         p.empty_bits = r->d_empty;
-        p.zero_page = r->d_zero_page;
         p.occ_flags_out = r->d_occ_zero[0];
         p.occ_list_out = work_list ? r->d_occ_list : nullptr;
         p.occ_count_out = (int*) (r->d_occ_list + r->occ_zero_bytes);
@@ -344,8 +349,9 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     p.tile_i0 = p.tile_j0 = 0;
     p.tiles_x = ceil_div(W, kChunkTile);
     p.tiles_y = ceil_div(H, kChunkTile);
-    p.a.occ_next = r->d_occ[0] + kPlaneGuard;
-    p.r.occ_next = r->d_occ[1] + kPlaneGuard;
+    p.occ_base = r->d_occ;
+    p.a.occ_next = r->d_occ + occ_off_a;
+    p.r.occ_next = r->d_occ + occ_off_r;
     // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple of 4
     // does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
     auto chunk_sparse_ok = [&](int c) { return (std::min(M, D - c * M) * -p.dx_lo) % 4 == 0; };
@@ -373,8 +379,8 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
             const int cur = (c & 1), nxt = cur ^ 1;
             p.a.plane_in = r->d_plane[cur] + kPlaneGuard; p.a.plane_out = r->d_plane[nxt] + kPlaneGuard;
             p.r.plane_in = r->d_plane[2 + cur] + kPlaneGuard; p.r.plane_out = r->d_plane[2 + nxt] + kPlaneGuard;
-            p.a.occ_cur = p.a.occ_next + (size_t) k0 * W * H;
-            p.r.occ_cur = p.r.occ_next + (size_t) k0 * W * H;
+            p.a.occ_off = (uint32_t) (occ_off_a + (size_t) k0 * W * H);
+            p.r.occ_off = (uint32_t) (occ_off_r + (size_t) k0 * W * H);
             p.occ_phase = k0 % kOccSlices;
             p.occ_flags = span_sparse ? r->d_occ_zero[0] + (size_t) sp * flags_per_span + (size_t) (k0 / kOccSlices) * flags_per_group : nullptr;
             HIP_TRY(launch_light_chain(p, change, r->lv_fmt, r->stream));
@@ -620,8 +626,6 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
     CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**) &r->d_counter, sizeof(unsigned long long)));
-    CREATE_TRY(hipMalloc((void**) &r->d_zero_page, 4096));
-    CREATE_TRY(hipMemsetAsync(r->d_zero_page, 0, 4096, r->stream));
     for (int k = 0; k < 2; ++k)
         for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));
     // the light volume render target starts cleared
@@ -642,10 +646,9 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (auto& axis : r->d_buf)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
-    for (float* oc : r->d_occ) (void) hipFree(oc);
+    (void) hipFree(r->d_occ);
     for (uint8_t* z : r->d_occ_zero) (void) hipFree(z);
     (void) hipFree(r->d_occ_list);
-    (void) hipFree(r->d_zero_page);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     (void) hipFree(r->d_alpha_prefix);
@@ -888,6 +891,21 @@ int tbrm_selftest_unorm_decode(int device, float* out_u8_256, float* out_u16_655
     hipError_t e = launch_selftest_decode(d, d + 256, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out_u8_256, d, 256 * sizeof(float), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_u16_65536, d + 256, 65536 * sizeof(float), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    HIP_TRY(e);
+    return TBRM_OK;
+}
+
+int tbrm_selftest_unorm8_roundtrip(int device, const float* in, size_t n, float* out)
+{
+    if (!in || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return TBRM_OK;
+    HIP_TRY(hipSetDevice(device));
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**) &d, 2 * n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, in, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_selftest_roundtrip(d, d + n, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d + n, n * sizeof(float), hipMemcpyDeviceToHost);
     (void) hipFree(d);
     HIP_TRY(e);
     return TBRM_OK;

@@ -72,22 +72,21 @@ __device__ __forceinline__ float pow_(float x, float y)
 }
 
 // ---- UNORM conversion (D3D11 functional spec: load c/(2^n-1); store trunc(clamp(x,0,1)*255+0.5), NaN->0)
-// c/d through the fma-corrected reciprocal (q = c*r; q += fma(-q, d, c)*r): 3 instructions instead of the ~10 of a
-// correctly rounded v_div sequence, and bit-identical to IEEE c/d for every UNORM8 and UNORM16 code (checked
-// exhaustively: tests/test_gpu_parity.py::test_unorm_decode_is_exact_division).
-__device__ __forceinline__ float div_by_const(float c, float d, float r)
+// Load: c/d as fma(c, r, c*r2) with r = RN(1/d) and r2 = RN(1/d - r), the reciprocal split in two floats: 2 instructions
+// instead of the ~10 of a correctly rounded v_div sequence, and bit-identical to IEEE c/d for every UNORM8 and UNORM16
+// code (checked exhaustively on the device: tests/test_gpu_properties.py::test_unorm_decode_is_exact_division, and in exact
+// rational arithmetic: tests/test_host_math.py::test_split_reciprocal_decode_is_exact).
+__device__ __forceinline__ float decode_u8f(float c) { return fma_(c, 0x1.010102p-8f, c * -0x1.fdfdfep-33f); }
+__device__ __forceinline__ float decode_u16f(float c) { return fma_(c, 0x1.0001p-16f, c * 0x1.0001p-48f); }
+__device__ __forceinline__ float decode_u8(uint32_t c) { return decode_u8f((float) c); }
+__device__ __forceinline__ float decode_u16(uint32_t c) { return decode_u16f((float) c); }
+// Store: the code as a float. v_med3_f32 returns the minimum of the non-NaN operands when an operand is NaN, i.e. 0 —
+// the D3D rule — so the clamp needs no separate NaN test; x*255+0.5 is >= 0.5, so floor == the spec's truncation.
+__device__ __forceinline__ float quantize_u8(float x)
 {
-    const float q = c * r;
-    return fma_(fma_(-q, d, c), r, q);
+    return __builtin_floorf(__builtin_amdgcn_fmed3f(x, 0.0f, 1.0f) * 255.0f + 0.5f);
 }
-__device__ __forceinline__ float decode_u8(uint32_t c) { return div_by_const((float) c, 255.0f, 1.0f / 255.0f); }
-__device__ __forceinline__ float decode_u16(uint32_t c) { return div_by_const((float) c, 65535.0f, 1.0f / 65535.0f); }
-__device__ __forceinline__ uint32_t encode_u8(float x)
-{
-    if (x != x) return 0;
-    x = fminf(fmaxf(x, 0.0f), 1.0f);
-    return (uint32_t) (x * 255.0f + 0.5f);
-}
+__device__ __forceinline__ uint32_t encode_u8(float x) { return (uint32_t) quantize_u8(x); }
 
 // Texel split of a normalised coordinate: floor/frac of u*N - 0.5 (clamped to +-2^30 so the conversion is defined).
 __device__ __forceinline__ void texel_split(float u, float n, int& i0, float& f)

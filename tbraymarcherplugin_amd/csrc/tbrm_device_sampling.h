@@ -39,7 +39,7 @@ __device__ __forceinline__ void store_voxel(void* p, size_t i, float v)
 template <int FMT>
 __device__ __forceinline__ float through_format(float v)
 {
-    if constexpr (FMT == FMT_U8) return decode_u8(encode_u8(v));
+    if constexpr (FMT == FMT_U8) return decode_u8f(quantize_u8(v));
     else return v;
 }
 

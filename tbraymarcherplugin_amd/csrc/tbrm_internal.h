@@ -64,7 +64,7 @@ struct ChunkStream {
     float init_value;       // what the cleared read/write buffers decode to (first chunk)
     const float* plane_in;  // propagated light after the previous chunk (W x H floats); unused in the first chunk
     float* plane_out;       // propagated light after this chunk
-    const float* occ_cur;   // occlusion (CurrentSample) of this chunk's slices: [n_steps][H][W], written by the previous launch
+    uint32_t occ_off;       // chain: float index, relative to ChunkParams::occ_base, of the occlusion plane of the chunk's first slice
     float* occ_next;        // occlusion of the next chunk's slices: [next_n][H][W]
 };
 
@@ -97,7 +97,7 @@ struct ChunkParams {
     int occ_tiles_x, occ_tiles_y;
     // empty-block hand-off: k_occ_flags marks, once per pass, every occlusion workgroup (16x16 pixels x 8 slices) whose
     // samples can only touch data bricks that map every value to opacity 0. Such a workgroup exits at once and the chain
-    // stages zeros for its pixels from a page of zeros instead of the plane stack.
+    // stages the factor 1 - 0 for its pixels from a page of ones instead of the plane stack.
     const uint32_t* empty_bits;   // per data brick (k_brick_empty); used by k_occ_flags only
     const uint8_t* occ_flags;     // flags from the slice group holding the chunk's first slice on: [slice group][block y][block x];
                                   // null: feature off for this chunk
@@ -105,7 +105,8 @@ struct ChunkParams {
     uint8_t* occ_flags_out;       // k_occ_flags: the whole pass, [chunk][slice group][block y][block x]
     int occ_blocks_x, occ_blocks_y, occ_groups; // blocks per plane row / column, slice groups per chunk
     int pass_start, pass_slices, chunk_slices;  // k_occ_flags: first slice, slices in the pass, slices per chunk
-    const float* zero_page;       // 4 KiB of zeros: the copy source for flagged blocks (keeps the copies per wave uniform)
+    const float* occ_base;        // the allocation holding the page of ones (its first 4 KiB: the copy source for flagged
+                                  // blocks, which keeps the copies per wave uniform) and both streams' occlusion stacks
     // work list: the non-empty workgroups of each chunk in ascending order (k_occ_compact). The occlusion launch keeps its
     // full grid; workgroup i takes entry i of the list or exits, so the live ones are dealt evenly over the CUs instead
     // of landing wherever the dense part of the volume happens to map.
@@ -173,6 +174,7 @@ constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
 
 // launchers (tbrm_kernels.hip, tbrm_light_kernels.hip)
 hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
+hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)

@@ -418,6 +418,16 @@ __global__ void k_selftest_decode(float* u8, float* u16)
     if (c < 256) u8[c] = decode_u8(c);
     if (c < 65536) u16[c] = decode_u16(c);
 }
+__global__ void k_selftest_roundtrip(const float* in, float* out, size_t n)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = through_format<FMT_U8>(in[i]);
+}
+hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_roundtrip, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
+    return hipGetLastError();
+}
 hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s)
 {
     hipLaunchKernelGGL(k_selftest_decode, dim3(256), dim3(256), 0, s, d_u8, d_u16);

@@ -137,12 +137,15 @@ struct ChunkGeom {
     int n;                  // steps in this chunk
     int lox, hix, loy, hiy;
     int HX, HY;             // hull = window at r = n (the input state)
-    int HXp;                // LDS row stride (HX rounded up to 4 floats: rows are staged with 16-byte copies)
-    int padx, pady;         // LDS index of tile coordinate 0
-    int elems;              // floats per LDS plane (window or staged occlusion)
+    int RS;                 // LDS plane edge / row stride in floats (0: the hull does not fit any instantiation)
+    int padx, pady;         // plane coordinates of tile pixel (0,0)
     int lv_layers;          // 8-slice brick layers of the light volume the chunk touches
     int lv_layer0;          // first of them
 };
+
+// LDS planes are RS x RS floats, RS an odd multiple of 8 (bank-conflict-free 8x8 patches, see k_light_chain)
+__host__ __device__ constexpr int chain_plane_elems(int RS) { return RS * RS + 8; } // + slack for inactive slots' reads
+__host__ __device__ constexpr int chain_row_stride(int hull) { return hull <= 40 ? 40 : (hull <= 56 ? 56 : (hull <= 72 ? 72 : 0)); }
 
 __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
 {
@@ -151,10 +154,9 @@ __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
     g.lox = p.dx_lo; g.hix = p.dx_hi; g.loy = p.dy_lo; g.hiy = p.dy_hi;
     g.HX = kChunkTile + g.n * (g.hix - g.lox);
     g.HY = kChunkTile + g.n * (g.hiy - g.loy);
-    g.HXp = (g.HX + 3) & ~3;
+    g.RS = chain_row_stride(g.HX > g.HY ? g.HX : g.HY);
     g.padx = -g.n * g.lox;
     g.pady = -g.n * g.loy;
-    g.elems = (g.HY * g.HXp + 4 + 3) & ~3; // +4: the last bilinear fetch may touch one float past the last row
     const int ja = p.j0, jb = p.j0 + (g.n - 1) * p.dir;
     const int jlo = ja < jb ? ja : jb, jhi = ja < jb ? jb : ja;
     g.lv_layer0 = jlo >> 3;
@@ -173,12 +175,14 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// instantiated shapes: Change runs RS 40/56 (two streams of 72 x 72 planes exceed the LDS), Add RS 40/56/72
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
+    if (g.RS == 0 || (change && g.RS > 56)) return (size_t) 1 << 30;
     const int ns = change ? 2 : 1;
-    size_t total = (size_t) ns * (2 + kOccRing) * g.elems * 4;                 // windows + staged occlusion ring
-    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;            // light-volume tile
+    size_t total = (size_t) ns * (2 + kOccRing) * chain_plane_elems(g.RS) * 4; // windows + staged occlusion ring
+    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;             // light-volume tile
     return total;
 }
 
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                     }
                     occ = windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
                 }
-                out[q * plane_elems] = occ;
+                out[q * plane_elems] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }
         }
     };
@@ -559,13 +563,16 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
 }
 
 // ---- k_light_chain: one tile through the slices of the chunk ---------------------------------------------------
-// Everything a slice needs is in LDS before the slice starts: the propagated-light windows, the occlusion of the
-// window (staged kOccRing slices ahead with asynchronous 16-byte global->LDS copies) and, for UNORM8 light volumes,
-// the tile's light-volume bricks (loaded once, read-modify-written in LDS, stored once). Per slice a workgroup
-// issues a handful of wide vector-memory instructions instead of ~100 narrow ones — the narrow ones, not HBM
-// bandwidth, were what bounded the first versions of this kernel.
+// Everything a slice needs is in LDS before the slice starts: the propagated-light windows, the occlusion factors of
+// the window (staged two slices ahead with asynchronous 16-byte global->LDS copies) and, for UNORM8 light volumes, the
+// tile's light-volume bricks (loaded once, read-modify-written in LDS, stored once).
+//
+// LDS planes are RS x RS floats with RS a compile-time odd multiple of 8: every window/ring/stream offset is an
+// immediate of the ds instruction (one address register per slot and stream instead of five), and the eight rows of a
+// wave's 8x8 patch fall on disjoint groups of eight banks. Per slice: refill the ring slot read in the previous slice
+// with the slice two ahead, issue every LDS read of the slice, compute, write, and meet ONCE at a barrier.
 
-template <int LFMT, bool CHANGE, int AXIS, int KH> // KH = halo pixels per thread: ceil((hull area - tile area) / threads)
+template <int LFMT, bool CHANGE, int AXIS, int KH, int RS> // KH = halo pixels per thread: ceil((hull area - tile area) / threads)
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -573,60 +580,84 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     constexpr int NS = CHANGE ? 2 : 1;
     constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KS = 1 + KH; // + the owned pixel
+    constexpr int PLANE = chain_plane_elems(RS);
+    constexpr int GPR = RS / 4;                                         // 16-byte copy groups per plane row
+    constexpr int GROUPS = RS * GPR;
+    constexpr int ROUNDS = (GROUPS + kChunkThreads - 1) / kChunkThreads; // copy groups per thread
+    static_assert(RS % 16 == 8 && ROUNDS <= 2, "row stride must be an odd multiple of 8");
     const ChunkGeom g = chunk_geometry(p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int plane_elems = p.H * p.W;
     const int base_x = (int) blockIdx.x * T, base_y = (int) blockIdx.y * T;
 
-
-    // LDS map (floats): stream si: [win 0][win 1][occ ring 0..2]; then the light-volume tile (bytes)
+    // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, ring slot q at ((2 + q)*NS + si)*PLANE; then the
+    // light-volume tile (bytes)
     float* const lds = (float*) smem;
-    const int stream_stride = (2 + kOccRing) * g.elems;
-    uint8_t* const lv_tile = (uint8_t*) (lds + NS * stream_stride);
+    uint8_t* const lv_tile = (uint8_t*) (lds + (2 + kOccRing) * NS * PLANE);
+    auto window = [&](int w, int si) -> float* { return lds + (w * NS + si) * PLANE; };
+    auto ring = [&](int q, int si) -> float* { return lds + ((2 + q) * NS + si) * PLANE; };
 
-    // ---- 16-byte staging pattern: thread t copies floats [4t, 4t+4) of an LDS plane = 4 pixels of one hull row ------
-    const int gpr = g.HXp >> 2;                               // copy groups per row
-    const int st_row = (int) (((float) threadIdx.x + 0.5f) * (1.0f / (float) gpr)); // exact: both < 2^11
-    const int st_col = (threadIdx.x - st_row * gpr) * 4;
-    const int st_py = base_y - g.pady + st_row;
-    const int st_src = st_py * p.W + base_x - g.padx + st_col; // may run off the row ends: the planes have guard bands
-    const bool st_ok = st_row < g.HY && (unsigned) st_py < (unsigned) p.H;
-    const int st_dst = wave * 256;                            // this wave's 64 x 4 floats
-    // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: zeros are staged without a copy
-    bool st_zero[2] = {false, false}; // this thread's 4 pixels lie in empty blocks of slice group 0 / 1 of the chunk
-    if (p.occ_flags && st_ok) {
-        const int x_first = base_x - g.padx + st_col, x_last = x_first + 3;
-        const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = st_py >> 4;
+    // ---- 16-byte staging pattern: copy group i = floats [4i, 4i+4) of an LDS plane = 4 pixels of one hull row ------
+    int st_src[ROUNDS];   // pixel index of the group's first pixel inside a plane (may run off the row ends: guard bands)
+    bool st_ok[ROUNDS];
+    int st_dst[ROUNDS];   // this wave's 64 x 4 floats
+    bool st_one[ROUNDS][2] = {}; // the group's 4 pixels lie in empty blocks of slice group 0 / 1 of the chunk
+    int ndma = 0;         // copies this WAVE issues per staged slice (wave-uniform)
 #pragma unroll
-        for (int z = 0; z < 2; ++z) {
-            bool zero = x_last >= 0 && x_first < p.W && z * kOccDepth < p.occ_phase + g.n;
-            if (zero) {
-                const uint8_t* row = p.occ_flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
-                zero = row[bx0] != 0 && row[bx1] != 0;
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int gi = (int) threadIdx.x + rd * kChunkThreads;
+        const int row = gi / GPR, col = (gi - row * GPR) * 4;
+        const int py = base_y - g.pady + row;
+        st_src[rd] = py * p.W + base_x - g.padx + col;
+        st_ok[rd] = gi < GROUPS && row < g.HY && col < g.HX && (unsigned) py < (unsigned) p.H;
+        st_dst[rd] = (wave * 64 + rd * kChunkThreads) * 4;
+        if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NS;
+        // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: their factor 1 - 0 is staged from
+        // a page of ones
+        if (p.occ_flags && st_ok[rd]) {
+            const int x_first = base_x - g.padx + col, x_last = x_first + 3;
+            const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = py >> 4;
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                bool one = x_last >= 0 && x_first < p.W && z * kOccDepth < p.occ_phase + g.n;
+                if (one) {
+                    const uint8_t* frow = p.occ_flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
+                    one = frow[bx0] != 0 && frow[bx1] != 0;
+                }
+                st_one[rd][z] = one;
             }
-            st_zero[z] = zero;
         }
     }
-    auto stage_occ = [&](int sf) {
-        if (sf < g.n && st_ok) {
-            float* dst = lds + 2 * g.elems + (sf % kOccRing) * g.elems + st_dst;
-            // flagged-empty lanes copy from a page of zeros (L2-resident) instead of the plane stack: same number of copy
-            // instructions per wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on
-            const bool zero = st_zero[(p.occ_phase + sf) / kOccDepth];
-            const float* zsrc = p.zero_page + (threadIdx.x & 63) * 4;
-            dma_16(zero ? zsrc : p.a.occ_cur + sf * plane_elems + st_src, dst);
-            if constexpr (CHANGE) dma_16(zero ? zsrc : p.r.occ_cur + sf * plane_elems + st_src, dst + stream_stride);
+    // The occlusion stacks of both streams and the page of ones live in one allocation: a copy's source is the uniform
+    // base plus a 32-bit offset, and flagged-empty lanes only swap the offset (the same number of copy instructions per
+    // wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on).
+    auto stage_occ = [&](int sf, int q) {
+        if (sf >= g.n) return;
+        const int group = (p.occ_phase + sf) / kOccDepth;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            if (!st_ok[rd]) continue;
+            const bool one = group == 0 ? st_one[rd][0] : st_one[rd][1];
+            const uint32_t px = (uint32_t) (sf * plane_elems + st_src[rd]);
+#pragma unroll
+            for (int si = 0; si < NS; ++si) {
+                const uint32_t off = one ? (uint32_t) lane * 4u : (si == 0 ? p.a.occ_off : p.r.occ_off) + px;
+                dma_16(p.occ_base + off, ring(q, si) + st_dst[rd]);
+            }
         }
     };
 
     // ---- input state: the plane after the previous chunk ------------------------------------------------------------
-    if (!p.first_chunk && st_ok) {
-        dma_16(p.a.plane_in + st_src, lds + st_dst);
-        if constexpr (CHANGE) dma_16(p.r.plane_in + st_src, lds + stream_stride + st_dst);
+    if (!p.first_chunk) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            if (!st_ok[rd]) continue;
+            dma_16(p.a.plane_in + st_src[rd], window(0, 0) + st_dst[rd]);
+            if constexpr (CHANGE) dma_16(p.r.plane_in + st_src[rd], window(0, 1) + st_dst[rd]);
+        }
     }
-    stage_occ(0);
-    stage_occ(1);
-    stage_occ(2);
+    stage_occ(0, 0);
+    stage_occ(1, 1);
 
     // ---- light-volume tile: the 4x4 brick columns under the tile, every brick layer the chunk touches --------------
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
@@ -680,7 +711,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     }
     int rmin[KS];          // the slot is inside the window while r >= rmin (huge: never / outside the buffer)
     int li[KS];            // LDS index of the slot inside a plane
-    int tap[NS][KS];       // LDS offset of the first previous-slice tap relative to li
+    int ti[NS][KS];        // LDS index of the first previous-slice tap inside a plane
     float wfx[NS][KS], wfy[NS][KS]; // bilinear weights of the previous-slice fetch
     bool off_plane[KS];    // inside the hull but outside the buffer: holds the border colour
 #pragma unroll
@@ -696,7 +727,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         if (qy >= T) need = max(need, g.hiy > 0 ? (qy - T + g.hiy) / g.hiy : INT32_MAX / 2);
         rmin[k] = inplane ? need : INT32_MAX / 2;
         off_plane[k] = valid && !inplane;
-        li[k] = valid ? (qy + g.pady) * g.HXp + qx + g.padx : 0;
+        li[k] = valid ? (qy + g.pady) * RS + qx + g.padx : 0;
 #pragma unroll
         for (int si = 0; si < NS; ++si) {
             // previous-slice tap split: ((c + 0.5)/size + PrevPixelOffset) -> (tap - c, frac) (AddDirLightShader.usf:81-82)
@@ -709,7 +740,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 ix -= px;
                 iy -= py;
             }
-            tap[si][k] = iy * g.HXp + ix;
+            ti[si][k] = li[k] + iy * RS + ix;
             wfx[si][k] = fx;
             wfy[si][k] = fy;
         }
@@ -750,55 +781,56 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
 #pragma unroll
         for (int si = 0; si < NS; ++si) {
             const ChunkStream& s = si == 0 ? p.a : p.r;
-            float* w0 = lds + si * stream_stride;
-            if (off_plane[k]) { w0[li[k]] = s.border_light; w0[g.elems + li[k]] = s.border_light; }
-            else if (p.first_chunk && rmin[k] < INT32_MAX / 2) w0[li[k]] = s.init_value;
+            if (off_plane[k]) { window(0, si)[li[k]] = s.border_light; window(1, si)[li[k]] = s.border_light; }
+            else if (p.first_chunk && rmin[k] < INT32_MAX / 2) window(0, si)[li[k]] = s.init_value;
         }
     }
     __syncthreads();
 
-    // float light volumes: the owned voxel is fetched kOccRing slices ahead into registers
-    float lvq[kOccRing] = {0.0f, 0.0f, 0.0f};
-    auto fetch_lv = [&](int sf) -> float {
-        if constexpr (LV_LDS) return 0.0f;
-        else return (sf < g.n && rmin[0] == 0) ? load_voxel<LFMT>(p.light, lv_const + lv_slice_off(p.j0 + sf * p.dir)) : 0.0f;
-    };
-    lvq[0] = fetch_lv(0); lvq[1] = fetch_lv(1); lvq[2] = fetch_lv(2);
-
-    // one slice: window `cur` holds the state before it, occlusion ring slot `ring` its opacity samples
-    auto step = [&](int s, int cur, int ring, float lv_reg) {
+    // one slice: window `cur` holds the state before it, ring slot `q` the slice's occlusion factors
+    auto step = [&](int s, int cur, int q) {
         const int r = g.n - 1 - s; // slices that remain after this one
-        const float* wr = lds + cur * g.elems;
-        float* ww = lds + (cur ^ 1) * g.elems;
-        const float* oc = lds + (2 + ring) * g.elems;
+        const uint32_t vi = lv_const + lv_slice_off(p.j0 + s * p.dir);
+        // every LDS read of the slice first (the writes below may alias them as far as the compiler can tell, so reads
+        // issued after a write would wait for it: issued up front, their latencies overlap instead of adding up)
+        bool act[KS];
+        float t00[KS][NS], t01[KS][NS], t10[KS][NS], t11[KS][NS], fac[KS][NS];
+        float lv_old = 0.0f;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            if (r < rmin[k]) continue;
+            act[k] = r >= rmin[k];
+            if (!act[k]) continue;
+#pragma unroll
+            for (int si = 0; si < NS; ++si) {
+                const float* pw = window(cur, si) + ti[si][k];
+                t00[k][si] = pw[0]; t01[k][si] = pw[1]; t10[k][si] = pw[RS]; t11[k][si] = pw[RS + 1];
+                fac[k][si] = ring(q, si)[li[k]];
+            }
+            if (k == 0) {
+                if constexpr (LV_LDS) lv_old = decode_u8(lv_tile[vi]);
+                else lv_old = load_voxel<LFMT>(p.light, vi);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (!act[k]) continue;
             float lval[NS];
 #pragma unroll
             for (int si = 0; si < NS; ++si) {
                 // previous slice, bilinear with border colour (AddDirLightShader.usf:81-82)
-                const float* pw = wr + si * stream_stride + li[k] + tap[si][k];
-                const float prev = lerp_(lerp_(pw[0], pw[1], wfx[si][k]), lerp_(pw[g.HXp], pw[g.HXp + 1], wfx[si][k]), wfy[si][k]);
-                const float l = prev * (1 - oc[si * stream_stride + li[k]]); // :117
+                const float prev = lerp_(lerp_(t00[k][si], t01[k][si], wfx[si][k]), lerp_(t10[k][si], t11[k][si], wfx[si][k]), wfy[si][k]);
+                const float l = prev * fac[k][si]; // :117 (the occlusion kernel stored 1 - CurrentSample)
                 lval[si] = l;
-                ww[si * stream_stride + li[k]] = through_format<LFMT>(l); // WriteBuffer[PixelLoc] = L (:120)
+                window(cur ^ 1, si)[li[k]] = through_format<LFMT>(l); // WriteBuffer[PixelLoc] = L (:120)
             }
             if (k == 0) { // the owned pixel: this workgroup writes its light-volume voxel
-                const uint32_t vi = lv_const + lv_slice_off(p.j0 + s * p.dir);
-                float delta;
+                float nv;
                 bool write;
-                if constexpr (!CHANGE) { delta = lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }      // :123-126
-                else { delta = 0.0f; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }                          // Change :152
+                if constexpr (!CHANGE) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }           // :123-126
+                else { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }            // Change :152-154
                 if (write) {
-                    if constexpr (LV_LDS) {
-                        const float old = decode_u8(lv_tile[vi]);
-                        const float nv = CHANGE ? old + lval[0] - lval[NS - 1] : old + delta;                  // :126 / Change :154
-                        lv_tile[vi] = (uint8_t) encode_u8(nv);
-                    } else {
-                        const float nv = CHANGE ? lv_reg + lval[0] - lval[NS - 1] : lv_reg + delta;
-                        store_voxel<LFMT>(p.light, vi, nv);
-                    }
+                    if constexpr (LV_LDS) lv_tile[vi] = (uint8_t) encode_u8(nv);
+                    else store_voxel<LFMT>(p.light, vi, nv);
                 }
                 if (r == 0) {
 #pragma unroll
@@ -809,30 +841,22 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     };
 
     static_assert(kOccRing == 3, "the slice loop below is unrolled for a ring of three");
-    // Per slice: compute, then refill the ring slot just consumed with the slice three ahead. Before the barrier each
-    // wave waits until at most the two youngest refills (2*NS copies) are still in flight, i.e. the next slice's
-    // occlusion has landed (copies complete in issue order).
+    // Per slice: refill the ring slot the PREVIOUS slice read (every wave left that slice at the barrier) with the slice
+    // two ahead, compute, then wait until only that refill may still be in flight — the copies of slice s+1, issued a
+    // whole slice ago, have landed — and meet at the barrier that also publishes this slice's window writes. Copies
+    // complete in issue order and, with a UNORM8 light volume, are the only vector-memory operations of the loop; a float
+    // light volume adds the owned voxel's load and conditional store, so that variant drains everything.
     for (int s0 = 0; s0 < g.n; s0 += 6) {
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int s = s0 + u;
-            if (s < g.n) {
-                step(s, u & 1, u % 3, lvq[u % 3]);
-                lvq[u % 3] = fetch_lv(s + 3);
-            }
-            lds_barrier(); // every wave is done reading ring slot u%3 and window u&1, and its window writes are visible
-            stage_occ(s + 3);
-            // The copies complete in issue order and, with a UNORM8 light volume, they are the only vector-memory
-            // operations of the loop: once at most the copies of the slices after s+1 (NS per slice, those that exist)
-            // are outstanding, the ones for slice s+1 have landed. A float light volume adds per-lane loads and
-            // conditional stores of the owned voxel to the count, so that variant drains everything.
-            if constexpr (LV_LDS) {
-                const int younger = min(g.n - 2 - s, 2); // slices s+2, s+3 if inside the chunk
-                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NS) : "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier(); // slice s+1's occlusion is visible to every wave
+            stage_occ(s + 2, (u + 2) % 3);
+            if (s < g.n) step(s, u & 1, u % 3);
+            const int pending = (LV_LDS && s + 2 < g.n) ? ndma : 0;
+            if (pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (pending == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            lds_barrier();
         }
     }
 
@@ -879,13 +903,13 @@ hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t
     }
 }
 
-template <int LFMT, bool CHANGE, int AXIS, int KH>
+template <int LFMT, bool CHANGE, int AXIS, int KH, int RS>
 static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 {
     static bool attr = false;
-    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
+    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH, RS>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
 template <int LFMT, bool CHANGE, int AXIS>
@@ -893,19 +917,27 @@ static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
 {
     const ChunkGeom g = chunk_geometry(p);
     const int halo = g.HX * g.HY - kChunkTile * kChunkTile;
-    const int kh = (halo + kChunkThreads - 1) / kChunkThreads;
-    if constexpr (CHANGE) { // two streams double the per-pixel state: the exact count keeps the kernel out of scratch
-        if (kh <= 1) return launch_chain4<LFMT, CHANGE, AXIS, 1>(p, s);
-        if (kh == 2) return launch_chain4<LFMT, CHANGE, AXIS, 2>(p, s);
+    const int kh = (halo + kChunkThreads - 1) / kChunkThreads; // <= 3 for hulls up to 64 x 64
+    if constexpr (CHANGE) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
+        if (g.RS == 40) return launch_chain4<LFMT, CHANGE, AXIS, 1, 40>(p, s);
+        if (g.RS == 56) {
+            if (kh <= 1) return launch_chain4<LFMT, CHANGE, AXIS, 1, 56>(p, s);
+            if (kh == 2) return launch_chain4<LFMT, CHANGE, AXIS, 2, 56>(p, s);
+            return launch_chain4<LFMT, CHANGE, AXIS, 3, 56>(p, s);
+        }
+    } else {
+        if (g.RS == 40) return launch_chain4<LFMT, CHANGE, AXIS, 1, 40>(p, s);
+        if (g.RS == 56) return launch_chain4<LFMT, CHANGE, AXIS, 3, 56>(p, s);
+        if (g.RS == 72 && kh <= 3) return launch_chain4<LFMT, CHANGE, AXIS, 3, 72>(p, s);
     }
-    return launch_chain4<LFMT, CHANGE, AXIS, 3>(p, s); // measured: the single-stream kernel is fastest fully unrolled
+    return hipErrorInvalidConfiguration; // the host's LDS check (chunk_lds_bytes) rules these shapes out
 }
 template <int LFMT, bool CHANGE>
 static hipError_t launch_chain2(const ChunkParams& p, hipStream_t s)
 {
     return p.axis == 0 ? launch_chain3<LFMT, CHANGE, 0>(p, s) : (p.axis == 1 ? launch_chain3<LFMT, CHANGE, 1>(p, s) : launch_chain3<LFMT, CHANGE, 2>(p, s));
 }
-// advances every tile through the chunk (j0, n_steps), reading {a,r}.occ_cur
+// advances every tile through the chunk (j0, n_steps), reading the occlusion planes at occ_base + {a,r}.occ_off
 hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s)
 {
     if (p.n_steps <= 0 || p.tiles_x <= 0 || p.tiles_y <= 0) return hipSuccess;

@@ -89,8 +89,28 @@ def test_skipping_and_tiling_do_not_change_the_image_at_config2_size(gpu):
 
 
 def test_unorm_decode_is_exact_division(gpu):
-    """The 3-instruction UNORM decode of the kernels (c*r corrected by one fma residual) equals IEEE c/255 and c/65535
-    for every code."""
+    """The 2-instruction UNORM decode of the kernels (fma(c, r, c*r2), reciprocal split in two floats) equals IEEE
+    c/255 and c/65535 for every code."""
     u8, u16 = abi.selftest_unorm_decode(0)
     assert np.array_equal(u8, np.arange(256, dtype=np.float32) / np.float32(255))
     assert np.array_equal(u16, np.arange(65536, dtype=np.float32) / np.float32(65535))
+
+
+def test_unorm8_store_roundtrip_matches_d3d_rule(gpu):
+    """The kernels' UNORM8 store (v_med3 clamp that also maps NaN to 0, x*255+0.5, floor) against the D3D11 rule evaluated
+    in numpy, on special values, every rounding boundary and its float neighbours, and a dense random sweep."""
+    rng = np.random.default_rng(7)
+    edges = (np.arange(0, 256, dtype=np.float64) + 0.5) / 255.0
+    e32 = edges.astype(np.float32)
+    vals = np.concatenate([
+        np.array([0.0, -0.0, 1.0, -1.0, 2.0, 0.5, 1e-30, -1e-30, np.inf, -np.inf, np.nan, -np.nan, 1.0 - 2**-24, 2**-149], dtype=np.float32),
+        e32, np.nextafter(e32, np.float32(-1)), np.nextafter(e32, np.float32(2)),
+        np.arange(256, dtype=np.float32) / np.float32(255),
+        rng.uniform(-0.25, 1.25, 200_000).astype(np.float32),
+    ])
+    got = abi.selftest_unorm8_roundtrip(vals)
+    x = np.where(np.isnan(vals), np.float32(0), vals)
+    x = np.minimum(np.maximum(x, np.float32(0)), np.float32(1))
+    code = np.trunc(x * np.float32(255) + np.float32(0.5)).astype(np.float32)  # float32 mul then add, like the shader
+    want = code / np.float32(255)
+    assert np.array_equal(got, want)

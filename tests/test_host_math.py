@@ -128,3 +128,31 @@ def test_transfer_function_construction(oracle_mod):
     # the bench's TF-B keys are those of TF_CT-Bone
     tfb = abi.color_curve_to_lut(S.TF_B_KEYS)
     assert np.array_equal(tfb, bone)
+
+
+def test_split_reciprocal_decode_is_exact():
+    """The kernels decode UNORM codes as fma(c, r, c*r2) with r = RN(1/d), r2 = RN(1/d - r). In exact rational arithmetic
+    with round-to-nearest-even to binary32 after each operation, that equals RN(c/d) for every 8- and 16-bit code — the
+    constants in tbrm_device_math.h are checked here too."""
+    from fractions import Fraction
+
+    def rn(fr):  # Fraction -> nearest binary32 (normal range), as a Fraction
+        if fr == 0:
+            return Fraction(0)
+        sign, fr = (-1, -fr) if fr < 0 else (1, fr)
+        e = fr.numerator.bit_length() - fr.denominator.bit_length()
+        if Fraction(2) ** e > fr:
+            e -= 1
+        q = fr / Fraction(2) ** (e - 23)
+        n, rem = divmod(q.numerator, q.denominator)
+        twice = 2 * rem
+        if twice > q.denominator or (twice == q.denominator and n % 2 == 1):
+            n += 1
+        return sign * n * Fraction(2) ** (e - 23)
+
+    for d, r_hex, r2_hex in ((255, "0x1.010102p-8", "-0x1.fdfdfep-33"), (65535, "0x1.0001p-16", "0x1.0001p-48")):
+        r, r2 = Fraction(float.fromhex(r_hex)), Fraction(float.fromhex(r2_hex))
+        assert r == rn(Fraction(1, d)) and r2 == rn(Fraction(1, d) - r)
+        for c in range(d + 1):
+            t = rn(c * r2)
+            assert rn(c * r + t) == rn(Fraction(c, d)), (d, c)
