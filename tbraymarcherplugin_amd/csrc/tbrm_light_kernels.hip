@@ -206,6 +206,7 @@ __device__ __forceinline__ void dma_16(const void* src, void* lds_wave_base)
 // the two in-plane axes contribute per-thread constants, the slice axis a per-step value from a small LDS table
 // (which also carries the reference's per-thread (Loop+0.5)/res division out of the loop).
 constexpr int kOccTile = 16;  // pixels per side
+constexpr int kOccMaxBricks = 192; // staged bricks per workgroup (96 KiB of UNORM8 bricks)
 constexpr int kOccDepth = 8;  // slices per workgroup (16 was measured: fewer halo bricks per sample, but no faster)
 static_assert(kOccDepth == kOccSlices, "host and kernel disagree on the occlusion workgroup depth");
 
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     __shared__ int s_b0[3], s_nb[3], s_staged, s_interior;
     __shared__ uint32_t s_o0[2][kOccDepth], s_o1[2][kOccDepth];
     __shared__ int s_ends[12], s_end_dim[12];
+    __shared__ uint32_t s_brick[kOccMaxBricks];
 
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
     const int data_dims[3] = {p.data.nx, p.data.ny, p.data.nz};
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
             count *= s_nb[a];
             touches_border = touches_border || lo[a] < 0 || hi[a] >= dn[a];
         }
-        s_staged = (count > 0 && count * 512 * ESZ <= lds_budget_bytes) ? 1 : 0; // else: read taps from global memory
+        s_staged = (count > 0 && count <= kOccMaxBricks && count * 512 * ESZ <= lds_budget_bytes) ? 1 : 0; // else: read taps from global memory
         s_interior = touches_border ? 0 : 1;
     }
     __syncthreads();
@@ -452,15 +454,23 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     const bool staged = s_staged != 0;
     const int b0[3] = {s_b0[0], s_b0[1], s_b0[2]}, nb[3] = {s_nb[0], s_nb[1], s_nb[2]};
     if (staged) { // copy the bricks: 512*ESZ bytes each, 16 bytes per lane
-        constexpr int PIECES = 512 * ESZ / 16;
-        const int total = nb[0] * nb[1] * nb[2] * PIECES;
+        constexpr int PIECES = 512 * ESZ / 16; // a power of two
+        const int bricks = nb[0] * nb[1] * nb[2];
+        // global index of every staged brick, once (the integer divisions stay out of the copy loop)
+        if ((int) threadIdx.x < bricks) {
+            const int lb = threadIdx.x;
+            const int lx = lb % nb[0], ly = (lb / nb[0]) % nb[1], lz = lb / (nb[0] * nb[1]);
+            s_brick[lb] = (uint32_t) ((b0[2] + lz) * p.data.bnxy + (b0[1] + ly) * p.data.bnx + (b0[0] + lx));
+        }
+        __syncthreads();
+        const int total = bricks * PIECES;
         const int wave_base = (threadIdx.x >> 6) * 64, lane = threadIdx.x & 63;
         for (int cb = wave_base; cb < total; cb += 256) {
             const int c = cb + lane;
-            const int lb = c / PIECES, piece = c % PIECES;
-            const int lx = lb % nb[0], ly = (lb / nb[0]) % nb[1], lz = lb / (nb[0] * nb[1]);
-            const uint32_t gb = (uint32_t) ((b0[2] + lz) * p.data.bnxy + (b0[1] + ly) * p.data.bnx + (b0[0] + lx));
-            if (c < total) dma_16((const char*) p.data.data + ((size_t) gb * 512 * ESZ + (size_t) piece * 16), smem + (size_t) cb * 16);
+            if (c < total) {
+                const uint32_t gb = s_brick[c / PIECES];
+                dma_16((const char*) p.data.data + ((size_t) gb * 512 * ESZ + (size_t) (c % PIECES) * 16), smem + (size_t) cb * 16);
+            }
         }
     }
 
@@ -515,13 +525,41 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
             const uint32_t o00 = u0 + v0, o10 = u1 + v0, o01 = u0 + v1, o11 = u1 + v1;
             const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
             float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
+            // One texel plane of the footprint (4 taps at one slice-axis coordinate), reduced as far as the filter order
+            // (x, then y, then z) allows before the slice-axis weight is applied. Consecutive slices of a pass usually
+            // sample consecutive texel planes, so the +1 plane of one step is the base plane of the next: it is kept in
+            // registers and only one new plane (4 LDS taps + decode) is fetched per step instead of two.
+            constexpr int PV = AXIS == 2 ? 1 : (AXIS == 1 ? 2 : 4);
+            struct PlaneVal { float v[PV]; };
+            auto fetch_plane = [&](int q, bool upper) -> PlaneVal {
+                const uint32_t w = upper ? s_o1[si][q] : s_o0[si][q];
+                const bool a = (s_flags[si][q] & (upper ? 2 : 1)) != 0;
+                // tap (u, v): bit0 = u tap, bit1 = v tap
+                const float t00 = tap(o00 + w, k00 && a), t10 = tap(o10 + w, k10 && a);
+                const float t01 = tap(o01 + w, k01 && a), t11 = tap(o11 + w, k11 && a);
+                PlaneVal r;
+                if constexpr (AXIS == 2) r.v[0] = lerp_(lerp_(t00, t10, tu.f), lerp_(t01, t11, tu.f), tv.f); // (u,v,s) = (x,y,z)
+                else if constexpr (AXIS == 1) { r.v[0] = lerp_(t00, t10, tu.f); r.v[1] = lerp_(t01, t11, tu.f); } // x = u, y = slice, z = v
+                else { r.v[0] = t00; r.v[1] = t10; r.v[2] = t01; r.v[3] = t11; }                               // x = slice, y = u, z = v
+                return r;
+            };
+            auto combine = [&](const PlaneVal& lo, const PlaneVal& hi, float fs) -> float {
+                if constexpr (AXIS == 2) return lerp_(lo.v[0], hi.v[0], fs);
+                else if constexpr (AXIS == 1) return lerp_(lerp_(lo.v[0], hi.v[0], fs), lerp_(lo.v[1], hi.v[1], fs), tv.f);
+                else return lerp_(lerp_(lerp_(lo.v[0], hi.v[0], fs), lerp_(lo.v[1], hi.v[1], fs), tu.f),
+                                  lerp_(lerp_(lo.v[2], hi.v[2], fs), lerp_(lo.v[3], hi.v[3], fs), tu.f), tv.f);
+            };
+            PlaneVal lo{}, hi{};
+            int held = INT32_MIN / 2; // slice-axis texel index of `lo`; `hi` is the plane after it
 
-            // the 8 samples of a thread are independent dependency chains (LDS taps -> filter -> TF -> pow): unrolled so the
-            // scheduler interleaves them; with only a few waves per SIMD a rolled loop runs at one chain's latency
-#pragma unroll 4
             for (int q = 0; q < nk; ++q) {
                 const float fs = s_f[si][q];
                 const int fl = s_flags[si][q];
+                const int i = __builtin_amdgcn_readfirstlane(s_i[si][q]); // wave-uniform: scalar branches below
+                if (i == held + 1) { lo = hi; hi = fetch_plane(q, true); }
+                else if (i == held - 1) { hi = lo; lo = fetch_plane(q, false); }
+                else if (i != held) { lo = fetch_plane(q, false); hi = fetch_plane(q, true); }
+                held = i;
                 float aw = 1.0f;
                 if constexpr (CLIP) {
                     const float w = s_w[si][q];
@@ -532,24 +570,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                 bool inside = true;
                 if constexpr (!CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
                 float occ = 0.0f;
-                if (aw > 0.0f && inside) {
-                    const uint32_t w0 = s_o0[si][q], w1 = s_o1[si][q];
-                    const bool a0 = fl & 1, a1 = fl & 2;
-                    // tap t: bit0 = u tap, bit1 = v tap, bit2 = slice tap
-                    const float t0 = tap(o00 + w0, k00 && a0), t1 = tap(o10 + w0, k10 && a0);
-                    const float t2 = tap(o01 + w0, k01 && a0), t3 = tap(o11 + w0, k11 && a0);
-                    const float t4 = tap(o00 + w1, k00 && a1), t5 = tap(o10 + w1, k10 && a1);
-                    const float t6 = tap(o01 + w1, k01 && a1), t7 = tap(o11 + w1, k11 && a1);
-                    float val; // filter x, then y, then z
-                    if (AXIS == 2) { // (u,v,s) = (x,y,z)
-                        val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t2, t3, tu.f), tv.f), lerp_(lerp_(t4, t5, tu.f), lerp_(t6, t7, tu.f), tv.f), fs);
-                    } else if (AXIS == 1) { // x = u, y = slice, z = v
-                        val = lerp_(lerp_(lerp_(t0, t1, tu.f), lerp_(t4, t5, tu.f), fs), lerp_(lerp_(t2, t3, tu.f), lerp_(t6, t7, tu.f), fs), tv.f);
-                    } else { // x = slice, y = u, z = v
-                        val = lerp_(lerp_(lerp_(t0, t4, fs), lerp_(t1, t5, fs), tu.f), lerp_(lerp_(t2, t6, fs), lerp_(t3, t7, fs), tu.f), tv.f);
-                    }
-                    occ = windowed_alpha(val, s.step100, s_alpha, p.win) * aw;
-                }
+                if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
                 out[q * plane_elems] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }
         }
