@@ -115,159 +115,181 @@ __device__ __forceinline__ void cube_setup(const RayParams& p, int px, int py, R
     for (int c = 0; c < 3; ++c) ray.pos[c] = lcp[c] + (t0 * ray.lcv[c]);
 }
 
-__device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, int& px, int& py)
+// Pixel of the tile for ray (i, j) of a launch; rows interleave in groups of 8 across GPUs (tbrm_tile.row_group_step)
+__device__ __forceinline__ bool tile_pixel_at(const RayParams& p, int i, int j, int& px, int& py)
 {
-    // 16x16 pixel block per workgroup, one 8x8 sub-tile per wave64 (coherent rays per wave)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    i = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    j = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
     px = p.tile_x0 + i;
     py = p.tile_y0 + (j >> 3) * 8 * p.row_group_step + (j & 7);
     return i < p.tile_w && j < p.tile_h;
 }
 
+__device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, int& px, int& py)
+{
+    // 16x16 pixel block per workgroup, one 8x8 sub-tile per wave64 (count kernel)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    i = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    j = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    return tile_pixel_at(p, i, j, px, py);
+}
+
+// ---- k_raymarch_lit ---------------------------------------------------------------------------------------------
+// A ray is a serial loop in the reference (positions by repeated addition, front-to-back accumulation with early
+// exit). One ray per lane makes a frame as slow as its longest ray: a 512-step ray is 512 dependent memory round trips
+// while most of the chip has long run out of work (measured: 1.5 resident waves per SIMD on average, 14 % VALU issue).
+// Here a wave marches 8 rays (a 4x2 pixel patch) with 8 lanes each: per trip lane b of a ray evaluates sample 8*trip + b
+// — position, clip / empty-brick test, 16 taps, transfer function, opacity correction, light — so the expensive part of
+// 8 consecutive samples runs side by side, and only the cheap part stays serial: the 8 lanes exchange their
+// (colour*alpha, alpha) through LDS and each replays AccumulateLightEnergy over the 8 samples in ray order, which also
+// decides the early exit exactly where the reference takes it. Arithmetic per sample and per accumulation step is the
+// reference's; a lane reaches its sample position by performing every addition of the ray up to it.
+constexpr int kRayLanes = 8;                       // lanes (consecutive samples) per ray
+constexpr int kRayBlockW = 8, kRayBlockH = 4;      // pixels per 256-thread workgroup: 4 waves of 4x2 rays
+
 template <int DFMT, int LFMT, int DMODE>
 __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
 {
     __shared__ float4 s_tf[256];
+    __shared__ float4 s_x[256]; // per lane: (colour * alpha, alpha) of its sample; alpha < 0: nothing to accumulate
     s_tf[threadIdx.x] = p.tf[threadIdx.x];
     __syncthreads();
 
-    int i, j, px, py;
-    const bool valid = tile_pixel(p, i, j, px, py);
-    if (!valid) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = lane & (kRayLanes - 1), r = lane >> 3; // sample slot, ray within the wave
+    const int i = blockIdx.x * kRayBlockW + (wave & 1) * 4 + (r & 3);
+    const int j = blockIdx.y * kRayBlockH + (wave >> 1) * 2 + (r >> 2);
+    int px, py;
+    const bool valid = tile_pixel_at(p, i, j, px, py);
 
     Ray ray;
-    cube_setup(p, px, py, ray);
+    cube_setup(p, valid ? px : p.tile_x0, valid ? py : p.tile_y0, ray);
 
     // PerformWindowedLitRaymarch (WindowedRaymarchMaterials.usf:36-96)
     const float step_size = 1 / p.steps;
     const float actual = p.steps * ray.thickness;
     const float fl = floorf(actual);
-    const int max_steps = (int) fl;
-    const float final_step = actual - fl;
+    const int max_steps = valid ? (int) fl : 0;
+    const float final_step = valid ? actual - fl : 0.0f;
+    const int n_samples = max_steps + (final_step > 0.0f ? 1 : 0); // the full steps, then the fractional one (:84-93)
     const float sv0 = ray.lcv[0] * step_size, sv1 = ray.lcv[1] * step_size, sv2 = ray.lcv[2] * step_size;
     const float step_world = 100.0f * step_size;
     float pos0 = ray.pos[0], pos1 = ray.pos[1], pos2 = ray.pos[2];
     if (p.jitter_frame >= 0) { // JitterEntryPos (RaymarchMaterialCommon.usf:73-78)
-        uint32_t r;
-        rand3d_pcg16(px, py, p.jitter_frame & 7, r);
-        const float rnd = (float) r / 65535.0f;
+        uint32_t rr;
+        rand3d_pcg16(px, py, p.jitter_frame & 7, rr);
+        const float rnd = (float) rr / 65535.0f;
         pos0 = pos0 - (sv0 * rnd); pos1 = pos1 - (sv1 * rnd); pos2 = pos2 - (sv2 * rnd);
     }
 
     const float nx = (float) p.data.nx, ny = (float) p.data.ny, nz = (float) p.data.nz;
     const float lnx = (float) p.lv_dims[0], lny = (float) p.lv_dims[1], lnz = (float) p.lv_dims[2];
     const VolumeDev lightv{p.light, p.lv_dims[0], p.lv_dims[1], p.lv_dims[2], LFMT, p.lv_bnx, p.lv_bnxy};
-    float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f;
-    int cached_brick = -1;
-    bool cached_empty = false;
-
     // the light volume shares the data volume's footprint when it has the same size and the position is inside the
     // cube (saturate(CurPos) == CurPos): same texel split, same wrapped indices, same brick offsets
     const bool same_grid = DMODE == ADDR_WRAP && p.share_grid;
 
-    // A sample is split into "issue" (position -> clip / empty-space test -> 16 tap loads) and "shade" (filter, window,
-    // transfer function, opacity correction, light, accumulate). Positions do not depend on shading, so the loads of
-    // sample k+1 are issued before sample k is shaded: the two dependent memory round trips of the reference's loop body
-    // (data fetch, then light fetch) disappear behind the previous sample's arithmetic.
-    struct Pending {
-        bool valid;        // there is a sample
-        bool skip;         // clipped, or inside a brick that maps to opacity 0: exact no-op
-        float step;        // StepSize for the opacity correction
-        float fx, fy, fz;  // data-volume filter weights
-        float gx, gy, gz;  // light-volume filter weights
-        RawTaps<DFMT> d;
-        RawTaps<LFMT> l;
-    };
-    auto issue = [&](float step, Pending& n) {
-        n.valid = true;
-        n.skip = true;
-        n.step = step;
-        if (p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd)) return;
-        int ix, iy, iz;
-        texel_split(pos0, nx, ix, n.fx);
-        texel_split(pos1, ny, iy, n.fy);
-        texel_split(pos2, nz, iz, n.fz);
-        if (p.empty_bits) {
-            const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
-            const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
-            const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
-            const int b = (bz * p.bny + by) * p.bnx + bx;
-            if (b != cached_brick) {
-                cached_brick = b;
-                cached_empty = (p.empty_bits[b >> 5] >> (b & 31)) & 1u;
-            }
-            if (cached_empty) return; // every tap of this sample maps to opacity 0
-        }
-        n.skip = false;
-        const TapOffsets dt = tap_offsets<DMODE>(p.data, ix, iy, iz);
-        n.d.issue(p.data.data, dt);
-        // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
-        const float sp0 = saturate_(pos0), sp1 = saturate_(pos1), sp2 = saturate_(pos2);
-        if (same_grid && sp0 == pos0 && sp1 == pos1 && sp2 == pos2) {
-            n.gx = n.fx; n.gy = n.fy; n.gz = n.fz;
-            n.l.issue(p.light, dt);
-        } else {
-            int lx, ly, lz;
-            texel_split(sp0, lnx, lx, n.gx);
-            texel_split(sp1, lny, ly, n.gy);
-            texel_split(sp2, lnz, lz, n.gz);
-            n.l.issue(p.light, tap_offsets<ADDR_WRAP>(lightv, lx, ly, lz));
-        }
-    };
-    // returns true when the early-exit threshold was crossed
-    auto shade = [&](const Pending& c) -> bool {
-        if (c.skip) return false;
-        const float v = c.d.filter(c.fx, c.fy, c.fz);
-        // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
-        const float tpos = tf_position(v, p.win.center, p.win.width);
-        if ((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f)) return false;
-        float4 cs = sample_tf(s_tf, tpos);
-        const float a_sat = saturate_(cs.w);
-        if (a_sat == 0.0f) return false; // 1 - pow(1, s) = 0: the sample contributes exactly nothing
-        const float a = 1.0f - pow_(1.0f - a_sat, c.step);
-        const float l = c.l.filter(c.gx, c.gy, c.gz);
-        cs.x = cs.x * l; cs.y = cs.y * l; cs.z = cs.z * l;
-        // AccumulateLightEnergy (RaymarchMaterialCommon.usf:82-88)
-        const float om = 1.0f - le3;
-        le0 = le0 + ((cs.x * a) * om);
-        le1 = le1 + ((cs.y * a) * om);
-        le2 = le2 + ((cs.z * a) * om);
-        le3 = le3 + (a * om);
-        return le3 > 0.95f;
-    };
-    // sample idx of the ray: the max_steps full steps (CurPos += LocalCamVec before sampling, :67), then the fractional one
-    auto advance_and_issue = [&](int idx, Pending& n) {
-        if (idx < max_steps) {
-            pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2;
-            issue(step_world, n);
-        } else if (idx == max_steps && final_step > 0.0f) { // :84-93
-            pos0 = pos0 + (sv0 * final_step); pos1 = pos1 + (sv1 * final_step); pos2 = pos2 + (sv2 * final_step);
-            issue(100.0f * final_step, n);
-        } else n.valid = false;
-    };
+    float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f; // LightEnergy, replicated in the 8 lanes of the ray
+    bool done = n_samples == 0;
+    int adds = 0; // full-step additions this lane has applied to its position
+    float4* const xs = s_x + (threadIdx.x & ~(kRayLanes - 1)); // the ray's 8 exchange slots
 
-    Pending pa, pb;
-    int k = 0;
-    advance_and_issue(0, pa);
-    for (;;) { // two samples per trip so the pending buffers swap roles without copies
-        if (!pa.valid) break;
-        advance_and_issue(k + 1, pb);
-        if (shade(pa) && k < max_steps) { le3 = 1.0f; break; } // early exit belongs to the full steps only (:75-79)
-        ++k;
-        if (!pb.valid) break;
-        advance_and_issue(k + 1, pa);
-        if (shade(pb) && k < max_steps) { le3 = 1.0f; break; }
-        ++k;
+    for (int base = 0; __builtin_amdgcn_ballot_w64(!done) != 0; base += kRayLanes) {
+        const int idx = base + b; // this lane's sample of the ray
+        // CurPos += LocalCamVec before every full sample (:67): sample idx < max_steps sits idx+1 additions in, the
+        // fractional sample max_steps additions plus one scaled step
+        const int want = min(idx + 1, max_steps);
+        if (__builtin_amdgcn_ballot_w64(!done && want - adds != kRayLanes) == 0) { // mid-ray everywhere: no predication
+#pragma unroll
+            for (int t = 0; t < kRayLanes; ++t) { pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2; }
+            adds += kRayLanes;
+        } else {
+#pragma unroll
+            for (int t = 0; t < kRayLanes; ++t)
+                if (adds < want) { pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2; ++adds; }
+        }
+        float q0 = pos0, q1 = pos1, q2 = pos2, step = step_world;
+        const bool is_full = idx < max_steps;
+        const bool has = !done && idx < n_samples;
+        if (!is_full) { q0 = pos0 + (sv0 * final_step); q1 = pos1 + (sv1 * final_step); q2 = pos2 + (sv2 * final_step); step = 100.0f * final_step; }
+
+        // the sample: everything of the loop body up to AccumulateLightEnergy
+        float4 x = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        bool live = has && !(p.clip_mode && is_clipped(q0, q1, q2, p.cc, p.cd));
+        int ix = 0, iy = 0, iz = 0;
+        float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+        if (live) {
+            texel_split(q0, nx, ix, fx);
+            texel_split(q1, ny, iy, fy);
+            texel_split(q2, nz, iz, fz);
+            if (p.empty_bits) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
+                const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
+                const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
+                const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
+                const int bi = (bz * p.bny + by) * p.bnx + bx;
+                live = !((p.empty_bits[bi >> 5] >> (bi & 31)) & 1u);
+            }
+        }
+        if (live) {
+            RawTaps<DFMT> dtaps;
+            RawTaps<LFMT> ltaps;
+            float gx, gy, gz;
+            const TapOffsets dt = tap_offsets<DMODE>(p.data, ix, iy, iz);
+            dtaps.issue(p.data.data, dt);
+            // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
+            const float sp0 = saturate_(q0), sp1 = saturate_(q1), sp2 = saturate_(q2);
+            if (same_grid && sp0 == q0 && sp1 == q1 && sp2 == q2) {
+                gx = fx; gy = fy; gz = fz;
+                ltaps.issue(p.light, dt);
+            } else {
+                int lx, ly, lz;
+                texel_split(sp0, lnx, lx, gx);
+                texel_split(sp1, lny, ly, gy);
+                texel_split(sp2, lnz, lz, gz);
+                ltaps.issue(p.light, tap_offsets<ADDR_WRAP>(lightv, lx, ly, lz));
+            }
+            const float v = dtaps.filter(fx, fy, fz);
+            // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
+            const float tpos = tf_position(v, p.win.center, p.win.width);
+            if (!((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f))) {
+                const float4 cs = sample_tf(s_tf, tpos);
+                const float a_sat = saturate_(cs.w);
+                if (a_sat != 0.0f) { // else 1 - pow(1, s) = 0: the sample contributes exactly nothing
+                    const float a = 1.0f - pow_(1.0f - a_sat, step);
+                    const float l = ltaps.filter(gx, gy, gz);
+                    x = make_float4((cs.x * l) * a, (cs.y * l) * a, (cs.z * l) * a, a);
+                }
+            }
+        }
+
+        // AccumulateLightEnergy (RaymarchMaterialCommon.usf:82-88) over the ray's 8 samples, in order, in every lane of
+        // the ray; the early exit belongs to the full steps only (:75-79). A trip in which no lane of the wave has
+        // anything to accumulate (empty space, windowed-out values) needs no exchange.
+        const bool any_x = __builtin_amdgcn_ballot_w64(x.w >= 0.0f || x.w != x.w) != 0;
+        if (any_x) {
+            s_x[threadIdx.x] = x;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < kRayLanes; ++t) {
+                const float4 c = xs[t];
+                if (!done && !(c.w < 0.0f)) {
+                    const float om = 1.0f - le3;
+                    le0 = le0 + (c.x * om);
+                    le1 = le1 + (c.y * om);
+                    le2 = le2 + (c.z * om);
+                    le3 = le3 + (c.w * om);
+                    if (le3 > 0.95f && base + t < max_steps) { le3 = 1.0f; done = true; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (base + kRayLanes >= n_samples) done = true;
     }
-    reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
+    if (valid && b == 0) reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
 }
 
 template <int DFMT, int LFMT>
 static hipError_t launch_ray2(const RayParams& p, hipStream_t s)
 {
-    const dim3 grid((p.tile_w + 15) / 16, (p.tile_h + 15) / 16), block(256);
+    const dim3 grid((p.tile_w + kRayBlockW - 1) / kRayBlockW, (p.tile_h + kRayBlockH - 1) / kRayBlockH), block(256);
     if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP>), grid, block, 0, s, p);
     return hipGetLastError();
