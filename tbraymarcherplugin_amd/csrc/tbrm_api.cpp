@@ -87,6 +87,7 @@ struct tbrm_resources {
     int bn[3]{};
     float2* d_minmax = nullptr;
     uint32_t* d_empty = nullptr;
+    uint8_t* d_dist[2]{};          // empty-space leaping: per-brick distance field (ping-pong of the separable passes; [0] is final)
     int* d_alpha_prefix = nullptr;
     bool minmax_valid = false, empty_valid = false;
 
@@ -500,6 +501,13 @@ int ensure_skipping(tbrm_resources* r)
         HIP_TRY(hipStreamSynchronize(r->stream));
         EmptyParams ep{r->d_minmax, nb, window_dev(r), r->d_alpha_prefix, r->d_empty};
         HIP_TRY(launch_brick_empty(ep, r->stream));
+        // distance field for empty-space leaping: three separable passes, x then y then z
+        const int mode = r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP;
+        for (int axis = 0; axis < 3; ++axis) {
+            DistParams dp{r->d_empty, axis == 0 ? nullptr : r->d_dist[(axis + 1) & 1], r->d_dist[axis & 1],
+                {r->bn[0], r->bn[1], r->bn[2]}, axis};
+            HIP_TRY(launch_brick_dist(dp, mode, r->stream));
+        }
         r->empty_valid = true;
     }
     return TBRM_OK;
@@ -624,6 +632,7 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     for (int k = 0; k < 4; ++k) CREATE_TRY(hipMalloc((void**) &r->d_plane[k], (plane_px + 2 * kPlaneGuard) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**) &r->d_minmax, nb * sizeof(float2)));
     CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
+    for (int k = 0; k < 2; ++k) CREATE_TRY(hipMalloc((void**) &r->d_dist[k], nb_pad));
     CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**) &r->d_counter, sizeof(unsigned long long)));
     for (int k = 0; k < 2; ++k)
@@ -651,6 +660,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     (void) hipFree(r->d_occ_list);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
+    for (uint8_t* d : r->d_dist) (void) hipFree(d);
     (void) hipFree(r->d_alpha_prefix);
     (void) hipFree(r->d_counter);
     (void) hipFree(r->d_out);
@@ -796,6 +806,7 @@ int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tb
     if (rp->enable_skipping) {
         if (int e = ensure_skipping(r)) return e;
         p.empty_bits = r->d_empty;
+        p.skip_dist = r->d_dist[0];
     }
     if (int e = begin_timed(r, 1)) return e;
     HIP_TRY(launch_raymarch(p, r->stream));

@@ -139,6 +139,7 @@ struct RayParams {
     const float* depth; // may be null
     float* out;         // tile_w*tile_h*4
     const uint32_t* empty_bits; // one bit per brick; null when skipping is off
+    const uint8_t* skip_dist;   // per brick: Chebyshev distance (bricks, capped) to the nearest non-empty brick; null when skipping is off
     int bnx, bny, bnz;  // brick grid
     unsigned long long* sample_counter; // count kernel only
 };
@@ -156,6 +157,15 @@ struct EmptyParams {
     WindowDev win;
     const int* alpha_prefix; // 257 entries: # of TF texels j < i with alpha > 0 (or NaN)
     uint32_t* bits;
+};
+
+constexpr int kSkipDistCap = 32;
+struct DistParams {
+    const uint32_t* bits; // pass 0: the k_brick_empty bits
+    const uint8_t* in;    // later passes: the previous pass (null in pass 0)
+    uint8_t* out;
+    int bn[3];
+    int axis;
 };
 
 struct RelayoutParams {
@@ -187,5 +197,6 @@ hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
 hipError_t launch_count_samples(const RayParams& p, hipStream_t s);
 hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s);
 hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s);
+hipError_t launch_brick_dist(const DistParams& p, int addr_mode, hipStream_t s);
 
 } // namespace tbrm

@@ -187,6 +187,10 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
     // cube (saturate(CurPos) == CurPos): same texel split, same wrapped indices, same brick offsets
     const bool same_grid = DMODE == ADDR_WRAP && p.share_grid;
 
+    // empty-space leaping: texels the position moves per full step along its fastest axis
+    const float inv_texels_per_step = 1.0f / fmaxf(fmaxf(fabsf(sv0) * nx, fabsf(sv1) * ny), fabsf(sv2) * nz);
+    int safe_until = -1; // this lane's samples with index <= safe_until are known to be based in empty bricks
+
     float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f; // LightEnergy, replicated in the 8 lanes of the ray
     bool done = n_samples == 0;
     int adds = 0; // full-step additions this lane has applied to its position
@@ -213,19 +217,23 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
 
         // the sample: everything of the loop body up to AccumulateLightEnergy
         float4 x = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-        bool live = has && !(p.clip_mode && is_clipped(q0, q1, q2, p.cc, p.cd));
+        bool live = has && idx > safe_until && !(p.clip_mode && is_clipped(q0, q1, q2, p.cc, p.cd));
         int ix = 0, iy = 0, iz = 0;
         float fx = 0.0f, fy = 0.0f, fz = 0.0f;
         if (live) {
             texel_split(q0, nx, ix, fx);
             texel_split(q1, ny, iy, fy);
             texel_split(q2, nz, iz, fz);
-            if (p.empty_bits) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
+            if (p.skip_dist) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
                 const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
                 const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
                 const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
-                const int bi = (bz * p.bny + by) * p.bnx + bx;
-                live = !((p.empty_bits[bi >> 5] >> (bi & 31)) & 1u);
+                const int dist = p.skip_dist[(bz * p.bny + by) * p.bnx + bx];
+                live = dist == 0;
+                // Every brick within Chebyshev distance < dist is empty as well. From anywhere inside this brick a base
+                // tap has to move more than 8*(dist-1) texels along some axis to leave them, and a base tap moves at
+                // most 1 texel more than the position does: the lane's samples up to that many steps ahead need no test.
+                if (dist >= 2) safe_until = idx + (int) fminf(((float) (8 * (dist - 1)) - 1.25f) * inv_texels_per_step, 1.0e6f);
             }
         }
         if (live) {
@@ -431,6 +439,45 @@ hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s)
 {
     if (p.n_bricks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_empty, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---- empty-space leaping: Chebyshev distance (in bricks) to the nearest non-empty brick -------------------------
+// D(b) = the largest t <= kSkipDistCap such that every brick within Chebyshev distance < t of b is empty (0: b itself
+// is not). Erosion by a cube is separable, so three 1D passes give the exact value: T_x = distance along x to the
+// nearest non-empty brick; T_xy(b) = max{t : T_x(b + dy) >= t for all |dy| < t}; the same along z. Neighbour indices
+// follow the raymarch sampler's addressing (wrap: a torus; clamp: the edge brick repeats).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_brick_dist(const DistParams p)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int nb = p.bn[0] * p.bn[1] * p.bn[2];
+    if (b >= nb) return;
+    int c[3] = {b % p.bn[0], (b / p.bn[0]) % p.bn[1], b / (p.bn[0] * p.bn[1])};
+    const int stride = p.axis == 0 ? 1 : (p.axis == 1 ? p.bn[0] : p.bn[0] * p.bn[1]);
+    const int n = p.axis == 0 ? p.bn[0] : (p.axis == 1 ? p.bn[1] : p.bn[2]);
+    const int c0 = p.axis == 0 ? c[0] : (p.axis == 1 ? c[1] : c[2]);
+    const int row = b - c0 * stride;
+    auto value = [&](int ci) -> int { // the previous pass's T at coordinate ci of this row (pass 0: 0 / cap from the bits)
+        ci = address<MODE>(ci, n);
+        const int q = row + ci * stride;
+        if (p.in) return p.in[q];
+        return ((p.bits[q >> 5] >> (q & 31)) & 1u) ? kSkipDistCap : 0;
+    };
+    int t = value(c0);
+    for (int d = 1; d < t; ++d) {
+        const int m = min(value(c0 - d), value(c0 + d));
+        t = min(t, max(m, d));
+    }
+    p.out[b] = (uint8_t) t;
+}
+
+hipError_t launch_brick_dist(const DistParams& p, int addr_mode, hipStream_t s)
+{
+    const int nb = p.bn[0] * p.bn[1] * p.bn[2];
+    const dim3 grid((nb + 255) / 256), block(256);
+    if (addr_mode == ADDR_CLAMP) hipLaunchKernelGGL(k_brick_dist<ADDR_CLAMP>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_brick_dist<ADDR_WRAP>, grid, block, 0, s, p);
     return hipGetLastError();
 }
 
