@@ -291,7 +291,7 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     // The occlusion launches are decoupled from the chain's chunk length: one launch covers a "span" of S slices (several
     // chunks), so that it has enough workgroups to fill 256 CUs even when the chain has to run short chunks (a strongly
     // slanted pass runs M = 8) and the live-workgroup list of a span deals an even share to every CU.
-    int S = 64; // measured on MI355X, fused Change at 512^3: S = 16 3.87 ms, 32 3.46, 64 3.30, 128 3.29
+    int S = 128; // measured on MI355X, fused Change at 512^3: S = 32 2.80 ms, 64 2.61, 128 2.53, 256 2.52
     if (const char* e = getenv("TBRM_OCC_SLICES")) S = atoi(e);
     S = std::max(M, (S / M) * M);
 
