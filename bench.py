@@ -204,21 +204,15 @@ def main():
                    achieved=illum_bytes / (illum_ms * 1e-3) / 1e9, launch_ms=illum_ms, alg_bytes=illum_bytes)
     # HBM traffic from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
     # summarised by tools/pmc_traffic.py into profiles/): per launch of the raymarch kernel, or summed over the launches
-    # one ChangeDirLight makes
+    # one ChangeDirLight makes (tools/pmc_traffic.py "_per_operator_call")
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc_path) and args.config == 3 and n_gpus == 1:
         try:
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            if dom["kernel"].startswith("k_raymarch"):
-                traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if "k_raymarch_lit" in k)
-            else:
-                chain = [v for k, v in pmc.items() if "k_light_chain" in k and ", true," in k]
-                occ = [v for k, v in pmc.items() if "k_light_occlusion" in k and ", true," in k]
-                per_pair = (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in chain) / sum(v["launches"] for v in chain)
-                            + sum(v["hbm_bytes_per_launch"] * v["launches"] for v in occ) / sum(v["launches"] for v in occ))
-                traffic = per_pair * 2 * math.ceil(n / 16)  # launch pairs of one Change: 2 axis passes x chunks of 16 slices
+            per_call = pmc["_per_operator_call"]
+            traffic = per_call["raymarch_hbm_bytes"] if dom["kernel"].startswith("k_raymarch") else per_call["change_dir_light_hbm_bytes"]
             traffic = int(traffic)
         except Exception:
             traffic = None

@@ -325,9 +325,10 @@ __global__ __launch_bounds__(256) void k_occ_flags(const ChunkParams p, int n_ch
 // ---- k_occ_compact: per chunk, the ascending list of workgroups that are NOT flagged -----------------------------
 // One workgroup per chunk; thread t owns a contiguous run of the chunk's flags, a block-wide exclusive scan of the
 // per-thread counts gives every live workgroup its list position (deterministic, ascending).
-__global__ __launch_bounds__(256) void k_occ_compact(const ChunkParams p)
+__global__ __launch_bounds__(1024) void k_occ_compact(const ChunkParams p)
 {
-    __shared__ int s_scan[256];
+    constexpr int NT = 1024;
+    __shared__ int s_scan[NT];
     const int per_chunk = p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
     const int c = blockIdx.x;
     const uint8_t* flags = p.occ_flags_out + (size_t) c * per_chunk;
@@ -335,13 +336,13 @@ __global__ __launch_bounds__(256) void k_occ_compact(const ChunkParams p)
     const int n = min(p.chunk_slices, p.pass_slices - c * p.chunk_slices);
     const int live_groups = (n + kOccDepth - 1) / kOccDepth;       // slice groups past the chunk's last slice have no work
     const int live = live_groups * p.occ_blocks_y * p.occ_blocks_x;
-    const int run = (per_chunk + 255) / 256;
+    const int run = (per_chunk + NT - 1) / NT;
     const int i0 = min((int) threadIdx.x * run, live), i1 = min(i0 + run, live);
     int mine = 0;
     for (int i = i0; i < i1; ++i) mine += flags[i] ? 0 : 1;
     s_scan[threadIdx.x] = mine;
     __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) { // inclusive Hillis-Steele scan
+    for (int d = 1; d < NT; d <<= 1) { // inclusive Hillis-Steele scan
         const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
         __syncthreads();
         s_scan[threadIdx.x] += v;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_occ_compact(const ChunkParams p)
     int pos = s_scan[threadIdx.x] - mine;
     for (int i = i0; i < i1; ++i)
         if (!flags[i]) list[pos++] = (uint32_t) i;
-    if (threadIdx.x == 255) p.occ_count_out[c] = s_scan[255];
+    if (threadIdx.x == NT - 1) p.occ_count_out[c] = s_scan[NT - 1];
 }
 
 template <bool CHANGE>
@@ -361,7 +362,7 @@ static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t 
     if (p.axis == 0) hipLaunchKernelGGL((k_occ_flags<CHANGE, 0>), grid, block, 0, s, p, n_chunks);
     else if (p.axis == 1) hipLaunchKernelGGL((k_occ_flags<CHANGE, 1>), grid, block, 0, s, p, n_chunks);
     else hipLaunchKernelGGL((k_occ_flags<CHANGE, 2>), grid, block, 0, s, p, n_chunks);
-    if (p.occ_list_out) hipLaunchKernelGGL(k_occ_compact, dim3(n_chunks), block, 0, s, p);
+    if (p.occ_list_out) hipLaunchKernelGGL(k_occ_compact, dim3(n_chunks), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s)

@@ -34,8 +34,20 @@ def main():
         wr = w * 1024 / max(nw, 1)
         out[name] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                      "hbm_bytes_per_launch": rd + wr, "fetch_size_raw_kib": f / max(nf, 1), "write_size_raw_kib": w / max(nw, 1)}
+    # per operator call: every step of the profiled bench command makes one ChangeDirLight and one raymarch, so the number
+    # of raymarch launches is the number of Change calls; the Change's kernels are the <..., true, ...> instantiations
+    ray = [v for k, v in out.items() if "k_raymarch_lit" in k]
+    if ray:
+        calls = sum(v["launches"] for v in ray)
+        change = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items()
+                     if ("k_light_" in k and ", true," in k) or "k_occ_flags<true" in k)
+        out["_per_operator_call"] = {"calls": calls, "change_dir_light_hbm_bytes": change / calls,
+                                     "raymarch_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ray) / calls}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
+        if k.startswith("_"):
+            print(k, v)
+            continue
         print(f"{k:60s} x{v['launches']:5d}  read {v['read_bytes_per_launch']/1e6:9.2f} MB  write {v['write_bytes_per_launch']/1e6:9.2f} MB")
 
 
