@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--no-skipping", action="store_true")
     ap.add_argument("--raymarch-only", action="store_true", help="diagnostic: leave the light update out of the step")
+    ap.add_argument("--light-parallel-reset", action="store_true",
+                    help="N>1: the untimed ResetAllLights deals the lights over the ranks and combines the light volumes with "
+                         "reduce-scatter + all-gather (SURVEY.md §8e) instead of adding every light on every GPU")
     args = ap.parse_args()
 
     import torch
@@ -111,10 +114,37 @@ def main():
     light_dirs = [S.LIGHTS[i][0] for i in cfg["lights"]]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res.clear_light_volume(0.0)  # ResetAllLights (RaymarchVolume.cpp:418-451)
-    for l in lights:
-        res.add_dir_light(l, True, world)
-    res.flush()
+    if args.light_parallel_reset and dist is not None and not cfg["light_32bit"]:
+        from tbraymarcherplugin_amd import sharding
+
+        def combine_u8(t):
+            def reduce_scatter_sum(acc):
+                if one_gpu_dry_run:  # gloo: no reduce_scatter
+                    c = acc.cpu()
+                    dist.all_reduce(c)
+                    k = c.numel() // n_gpus
+                    return c[rank * k:(rank + 1) * k].to(device)
+                mine = torch.empty(acc.numel() // n_gpus, dtype=acc.dtype, device=device)
+                dist.reduce_scatter_tensor(mine, acc)
+                return mine
+
+            def all_gather(chunk):
+                if one_gpu_dry_run:
+                    parts = [torch.empty(chunk.shape, dtype=chunk.dtype) for _ in range(n_gpus)]
+                    dist.all_gather(parts, chunk.cpu())
+                    return torch.cat(parts).to(device)
+                full = torch.empty(chunk.numel() * n_gpus, dtype=chunk.dtype, device=device)
+                dist.all_gather_into_tensor(full, chunk)
+                return full
+
+            return sharding.combine_light_codes(t, n_gpus, reduce_scatter_sum, all_gather)
+
+        sharding.reset_all_lights_light_parallel(res, lights, world, rank, n_gpus, combine_u8)
+    else:
+        res.clear_light_volume(0.0)  # ResetAllLights (RaymarchVolume.cpp:418-451)
+        for l in lights:
+            res.add_dir_light(l, True, world)
+        res.flush()
     reset_ms = (time.perf_counter() - t0) * 1e3
 
     out = torch.empty((rows_per_rank, fb_w, 4), dtype=torch.float32, device=device)
@@ -239,7 +269,8 @@ def main():
                        "volume": [n, n, n], "framebuffer": [fb_w, fb_h], "steps": int(steps), "lights": len(lights),
                        "parallelism": f"image tiles x{n_gpus} (interleaved 8-row groups), volumes replicated"
                                       if n_gpus > 1 else "single GPU",
-                       "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only)},
+                       "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only),
+                       "light_parallel_reset": bool(args.light_parallel_reset and n_gpus > 1)},
             "nominal_samples_per_step": total_samples,
             "gathered_frame_equals_single_gpu_render": gather_ok,
             "gpu_ms": {"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4), "reset_all_lights_setup": round(reset_ms, 2)},

@@ -284,6 +284,7 @@ class Resources:
         check(self.lib.tbrm_resources_light_volume_dims(self.handle, C.byref(d)))
         self.light_dims = tuple(d[:])
         self.light_dtype = np.float32 if light_32bit else np.uint8
+        self.device = int(device)
 
     def close(self):
         if self.handle:
