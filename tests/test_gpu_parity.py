@@ -212,3 +212,73 @@ def test_raymarch_clip_plane_tiles_and_depth(gpu, oracle_mod):
         ref_d, _ = orc.raymarch_lit(cam, abi.Tile(0, 0, 64, 48), rp, world, scene_depth=depth)
         assert np.abs(out.cpu().numpy() - ref_d).max() <= TIGHT_TOL
         assert not np.array_equal(ref_d, full_ref)
+
+
+def test_raymarch_short_rays_and_odd_tiles(gpu, oracle_mod):
+    """The kernel evaluates 8 consecutive samples of a ray side by side and replays the accumulation in order: rays whose
+    sample count falls on every side of a multiple of 8 (0, 1, 7, 8, 9, ...), fractional last steps, early exits in the
+    middle of a group and tiles that are no multiple of the 8x4 pixel block must all match the serial oracle."""
+    res, orc, world = lit_pair(gpu, oracle_mod, (32, 32, 32), np.uint16)
+    with res:
+        for w, h, x0, y0 in [(37, 23, 5, 3), (8, 4, 0, 0), (1, 1, 20, 17)]:
+            cam = S.default_camera(64, 48)
+            tile = abi.Tile(x0, y0, w, h)
+            for steps in (0.75, 1.0, 4.3, 7.0, 7.999, 8.0, 8.5, 9.0, 15.9, 16.0, 17.25, 40.0):
+                for jitter in (-1, 5):
+                    rp = abi.RaymarchParams(steps, jitter, True)
+                    got = res.raymarch_lit(cam, tile, rp, world)
+                    ref, n_ref = orc.raymarch_lit(cam, tile, rp, world)
+                    assert np.abs(got - ref).max() <= TIGHT_TOL, (w, h, steps, jitter)
+                    assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
+        # a dense transfer function makes rays terminate early at many different sample indices
+        dense = np.zeros((256, 4), dtype=np.float32)
+        dense[:, :3] = np.linspace(0.2, 1.0, 256)[:, None]
+        dense[:, 3] = np.linspace(0.0, 0.6, 256)
+        res.set_tf_lut(dense)
+        orc.set_tf_lut(dense)
+        cam = S.default_camera(72, 56)
+        tile = abi.Tile(0, 0, 72, 56)
+        rp = abi.RaymarchParams(50.0, -1, True)
+        got = res.raymarch_lit(cam, tile, rp, world)
+        ref, _ = orc.raymarch_lit(cam, tile, rp, world)
+        assert np.abs(got - ref).max() <= TIGHT_TOL
+        assert (ref[..., 3] == 1.0).mean() > 0.05  # early exits are common among the rays that hit the cube
+
+
+def test_raymarch_leaping_over_sparse_blobs(gpu, oracle_mod):
+    """Empty-space leaping (per-brick distance field): a volume that is empty except for a few small blobs — long leaps,
+    blobs entered from empty space at every angle, wrap and clamp addressing — renders exactly as without skipping, and
+    as the oracle renders it."""
+    rng = np.random.default_rng(11)
+    n = 96
+    z, y, x = np.mgrid[0:n, 0:n, 0:n].astype(np.float32)
+    vol = np.zeros((n, n, n), dtype=np.float32)
+    for _ in range(9):
+        c = rng.uniform(6, n - 6, 3)
+        r = rng.uniform(2.5, 7.0)
+        d2 = (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2
+        vol = np.maximum(vol, np.clip(1.2 - np.sqrt(d2) / r, 0.0, 1.0))
+    vol[0:2, :, :] = 0.9  # something at the volume's face: leaps across the wrap seam must see it
+    vol_u16 = (vol * 65535.0 + 0.5).astype(np.uint16)
+    lut = abi.color_curve_to_lut(S.TF_A_KEYS)
+    win = abi.WindowingParams(0.6, 0.7, True, False)
+    world = S.default_world()
+    for addr in (abi.ADDRESS_WRAP, abi.ADDRESS_CLAMP):
+        res = abi.Resources((n, n, n), abi.FMT_G16, False, False, 0, addr, abi.BORDER_ENGINE_8BIT)
+        orc = oracle_mod.OracleScene(vol_u16, False, False, addr, abi.BORDER_ENGINE_8BIT)
+        with res:
+            res.upload_volume(vol_u16)
+            for o in (res, orc):
+                o.set_tf_lut(lut)
+                o.set_windowing(win)
+                o.add_dir_light(S.light(0), True, world)
+            cam = S.default_camera(160, 128)
+            tile = abi.Tile(0, 0, 160, 128)
+            for steps, jitter in ((96.0, -1), (333.0, 2)):
+                a = res.raymarch_lit(cam, tile, abi.RaymarchParams(steps, jitter, False), world)
+                b = res.raymarch_lit(cam, tile, abi.RaymarchParams(steps, jitter, True), world)
+                assert np.array_equal(a, b), "leaping changed the image"
+                assert b[..., 3].max() > 0.3
+            ref, _ = orc.raymarch_lit(cam, tile, abi.RaymarchParams(96.0, -1, True), world)
+            got = res.raymarch_lit(cam, tile, abi.RaymarchParams(96.0, -1, True), world)
+            assert np.abs(got - ref).max() <= TIGHT_TOL
