@@ -224,6 +224,18 @@ TBRM_API int tbrm_raymarch_lit_device(tbrm_resources* res, const tbrm_camera* ca
                                       const tbrm_raymarch_params* params, const tbrm_world_params* world,
                                       const float* device_scene_depth, float* device_out_rgba);
 
+/* The Intensity render mode (ERaymarchMaterial::Intensity, SwitchRenderer RaymarchVolume.cpp:786-800):
+ * PerformRaymarchCubeSetup + PerformWindowedIntensityRaymarch (WindowedRaymarchMaterials.usf:187-242) — per pixel the
+ * windowed intensity (clamped TF position, as RGB with alpha 1) of the first sample the clipping plane does not remove,
+ * read with the material's clamp sampler; (0,0,0,0) when every sample is clipped. No transfer function, light volume or
+ * early exit is involved; params->enable_skipping is ignored. Output layout and scene_depth as for tbrm_raymarch_lit. */
+TBRM_API int tbrm_raymarch_intensity(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                     const tbrm_raymarch_params* params, const tbrm_world_params* world,
+                                     float* host_out_rgba);
+TBRM_API int tbrm_raymarch_intensity_device(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                            const tbrm_raymarch_params* params, const tbrm_world_params* world,
+                                            const float* device_scene_depth, float* device_out_rgba);
+
 /* Nominal samples of one tile: sum over rays of floor(Steps*thickness) + [frac > 0]. Runs on
  * the GPU with the same cube-setup arithmetic as the raymarch; result is written to *out_samples.        */
 TBRM_API int tbrm_count_nominal_samples(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,

@@ -293,6 +293,24 @@ public:
         return tbrm_raymarch_lit(RaymarchResources.Handle, &Camera, &tile, &rp, &w, OutRGBA) == TBRM_OK;
     }
 
+    // Offscreen replacement of the M_Intensity_Raymarch material pass (the slice view, RaymarchVolume.cpp:72-73,:122-128).
+    bool RenderIntensity(const tbrm_camera& Camera, float* OutRGBA, int JitterFrame = -1)
+    {
+        if (!RaymarchResources.Handle) return false;
+        const tbrm_tile tile{0, 0, Camera.width, Camera.height, 1, 0};
+        const tbrm_raymarch_params rp{RaymarchingSteps, JitterFrame, 0, 0};
+        const tbrm_world_params w = WorldParameters.abi();
+        ++Stats.Frames;
+        return tbrm_raymarch_intensity(RaymarchResources.Handle, &Camera, &tile, &rp, &w, OutRGBA) == TBRM_OK;
+    }
+
+    // What the cube mesh would show with the currently selected material (SwitchRenderer, :786-800).
+    bool Render(const tbrm_camera& Camera, float* OutRGBA, int JitterFrame = -1)
+    {
+        return SelectRaymarchMaterial == ERaymarchMaterial::Intensity ? RenderIntensity(Camera, OutRGBA, JitterFrame)
+                                                                        : RenderLit(Camera, OutRGBA, JitterFrame);
+    }
+
     void FreeRaymarchResources() // :922-949
     {
         if (RaymarchResources.Handle) tbrm_resources_destroy(RaymarchResources.Handle);

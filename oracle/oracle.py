@@ -64,6 +64,7 @@ def load():
     lib.orc_change_dir_light.argtypes = [P(Scene), P(abi.DirLightParams), P(abi.DirLightParams), P(abi.WorldParams)]
     lib.orc_clear_light_volume.argtypes = [P(Scene), f]
     lib.orc_raymarch_lit.argtypes = [P(Scene), P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp, P(C.c_uint64)]
+    lib.orc_raymarch_intensity.argtypes = [P(Scene), P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp]
     lib.orc_probe_sample_volume.restype = f
     lib.orc_probe_sample_volume.argtypes = [P(VolumeView), f, f, f, C.c_int, f]
     lib.orc_probe_windowed_tf.argtypes = [f, f, vp, P(abi.WindowingParams), P(f * 4)]
@@ -178,3 +179,14 @@ class OracleScene:
         self.lib.orc_raymarch_lit(C.byref(sc), C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
                                   depth_ptr, None if out is None else out.ctypes.data, C.byref(n))
         return out, int(n.value)
+
+    def raymarch_intensity(self, camera, tile, params, world, scene_depth=None):
+        sc = self._scene()
+        out = np.empty((tile.h, tile.w, 4), dtype=np.float32)
+        depth_ptr = None
+        if scene_depth is not None:
+            scene_depth = np.ascontiguousarray(scene_depth, dtype=np.float32)
+            depth_ptr = scene_depth.ctypes.data
+        self.lib.orc_raymarch_intensity(C.byref(sc), C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
+                                        depth_ptr, out.ctypes.data)
+        return out

@@ -843,6 +843,60 @@ void orc_raymarch_lit(const orc_scene* sc, const tbrm_camera* cam, const tbrm_ti
     if (out_nominal_samples) *out_nominal_samples = total;
 }
 
+/* PerformWindowedIntensityRaymarch (WindowedRaymarchMaterials.usf:187-242): the windowed intensity of the first sample that
+ * the clipping plane does not remove — the slice view of the cut surface. The data volume is read with the material's CLAMP
+ * sampler at saturate(CurPos) in the full steps (:213-216) and at the unsaturated CurPos in the fractional step (:229-232). */
+void orc_raymarch_intensity(const orc_scene* sc, const tbrm_camera* cam, const tbrm_tile* tile,
+                            const tbrm_raymarch_params* rp, const tbrm_world_params* world,
+                            const float* scene_depth, float* out_rgba)
+{
+    ray_consts rc;
+    make_ray_consts(cam, world, &rc);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int j = 0; j < tile->h; ++j) {
+        const int py = tile_row(tile, j);
+        for (int i = 0; i < tile->w; ++i) {
+            const int px = tile->x0 + i;
+            float pos[3], thickness, lcv[3];
+            cube_setup(&rc, cam, px, py, scene_depth, pos, &thickness, lcv);
+            const float step_count = rp->steps;
+            const float step_size = 1 / step_count;             /* :197 */
+            const float actual = step_count * thickness;        /* :199 */
+            const float fl = floorf(actual);
+            const int max_steps = (int) fl;                     /* :201 */
+            const float final_step = actual - fl;               /* :203 */
+            const float sv[3] = {lcv[0] * step_size, lcv[1] * step_size, lcv[2] * step_size}; /* :206 */
+            if (rp->jitter_frame >= 0) { /* JitterEntryPos (:208) */
+                uint32_t r[3];
+                rand3d_pcg16(px, py, rp->jitter_frame & 7, r);
+                const float rnd = (float) r[0] / 65535.0f;
+                for (int c = 0; c < 3; ++c) pos[c] = pos[c] - (sv[c] * rnd);
+            }
+            float* o = out_rgba + ((size_t) j * tile->w + i) * 4;
+            o[0] = o[1] = o[2] = o[3] = 0.0f;                   /* :241 didn't hit anything */
+            int hit = 0;
+            for (int k = 0; k < max_steps && !hit; k++) {
+                for (int c = 0; c < 3; ++c) pos[c] = pos[c] + sv[c]; /* :213 */
+                const float sp[3] = {saturatef(pos[0]), saturatef(pos[1]), saturatef(pos[2])};
+                if (!is_clipped(sp, rc.cc, rc.cd)) {            /* :215 */
+                    const float v = sample_volume_trilinear(&sc->data, sp[0], sp[1], sp[2], ADDR_CLAMP, 0.0f); /* :217 */
+                    const float t = saturatef(get_transfer_func_position(v, sc->windowing.center, sc->windowing.width)); /* :220 */
+                    o[0] = o[1] = o[2] = t; o[3] = 1.0f;        /* :222 */
+                    hit = 1;
+                }
+            }
+            if (!hit && final_step > 0.0f) {                    /* :227-239 */
+                for (int c = 0; c < 3; ++c) pos[c] = pos[c] + (sv[c] * final_step);
+                if (!is_clipped(pos, rc.cc, rc.cd)) {
+                    const float v = sample_volume_trilinear(&sc->data, pos[0], pos[1], pos[2], ADDR_CLAMP, 0.0f);
+                    const float t = saturatef(get_transfer_func_position(v, sc->windowing.center, sc->windowing.width));
+                    o[0] = o[1] = o[2] = t; o[3] = 1.0f;
+                }
+            }
+        }
+    }
+}
+
 /* Single-sample probes used by the known-answer tests. */
 float orc_probe_sample_volume(const orc_volume_view* vol, float u, float v, float w, int mode, float border)
 {

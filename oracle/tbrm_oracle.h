@@ -56,6 +56,11 @@ void orc_raymarch_lit(const orc_scene* sc, const tbrm_camera* cam, const tbrm_ti
                       const tbrm_raymarch_params* rp, const tbrm_world_params* world,
                       const float* scene_depth, float* out_rgba, uint64_t* out_nominal_samples);
 
+/* the Intensity render mode (ERaymarchMaterial::Intensity) */
+void orc_raymarch_intensity(const orc_scene* sc, const tbrm_camera* cam, const tbrm_tile* tile,
+                            const tbrm_raymarch_params* rp, const tbrm_world_params* world,
+                            const float* scene_depth, float* out_rgba);
+
 float orc_probe_sample_volume(const orc_volume_view* vol, float u, float v, float w, int mode, float border);
 void orc_probe_windowed_tf(float value, float step_size, const float* tf, const tbrm_windowing_params* wp, float out[4]);
 void orc_probe_ray_aabb(const float origin[3], const float dir[3], float out_t[2]);

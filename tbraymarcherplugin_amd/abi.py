@@ -109,7 +109,8 @@ SYMBOLS = [
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
     "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
-    "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_count_nominal_samples",
+    "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
+    "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
     "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
@@ -157,6 +158,8 @@ def load():
     lib.tbrm_clear_light_volume.argtypes = [vp, C.c_float]
     lib.tbrm_raymarch_lit.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
     lib.tbrm_raymarch_lit_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
+    lib.tbrm_raymarch_intensity.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
+    lib.tbrm_raymarch_intensity_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
     lib.tbrm_count_nominal_samples.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), P(C.c_uint64)]
     lib.tbrm_download_light_volume.argtypes = [vp, vp, C.c_size_t]
     lib.tbrm_upload_light_volume.argtypes = [vp, vp, C.c_size_t]
@@ -341,6 +344,15 @@ class Resources:
     def raymarch_lit_device(self, camera, tile, params, world, out_ptr, depth_ptr=None):
         check(self.lib.tbrm_raymarch_lit_device(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
                                                 C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
+
+    def raymarch_intensity(self, camera, tile, params, world):
+        out = np.empty((tile.h, tile.w, 4), dtype=np.float32)
+        check(self.lib.tbrm_raymarch_intensity(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world), out.ctypes.data))
+        return out
+
+    def raymarch_intensity_device(self, camera, tile, params, world, out_ptr, depth_ptr=None):
+        check(self.lib.tbrm_raymarch_intensity_device(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
+                                                      C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
 
     def count_nominal_samples(self, camera, tile, params, world):
         n = C.c_uint64(0)

@@ -836,6 +836,44 @@ int tbrm_raymarch_lit(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile
     return TBRM_OK;
 }
 
+int tbrm_raymarch_intensity_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                                   const tbrm_world_params* world, const float* device_scene_depth, float* device_out_rgba)
+{
+    if (!r || !cam || !tile || !rp || !world || !device_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!r->has_volume) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume");
+    if (int e = bind(r)) return e;
+    RayParams p;
+    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
+    p.depth = device_scene_depth;
+    p.out = device_out_rgba;
+    if (int e = begin_timed(r, 1)) return e;
+    HIP_TRY(launch_raymarch_intensity(p, r->stream));
+    ++r->launches[2];
+    return end_timed(r, 1);
+}
+
+int tbrm_raymarch_intensity(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                            const tbrm_world_params* world, float* host_out_rgba)
+{
+    if (!r || !tile || !host_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (tile->w < 0 || tile->h < 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile size");
+    const size_t bytes = (size_t) tile->w * tile->h * 4 * sizeof(float);
+    if (bytes == 0) return TBRM_OK;
+    if (int e = bind(r)) return e;
+    if (bytes > r->out_bytes) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->d_out);
+        r->d_out = nullptr;
+        r->out_bytes = 0;
+        HIP_TRY(hipMalloc((void**) &r->d_out, bytes));
+        r->out_bytes = bytes;
+    }
+    if (int e = tbrm_raymarch_intensity_device(r, cam, tile, rp, world, nullptr, r->d_out)) return e;
+    HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
 int tbrm_count_nominal_samples(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
                                const tbrm_world_params* world, uint64_t* out_samples)
 {

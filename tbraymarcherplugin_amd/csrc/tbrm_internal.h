@@ -194,6 +194,7 @@ hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hip
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
+hipError_t launch_raymarch_intensity(const RayParams& p, hipStream_t s);
 hipError_t launch_count_samples(const RayParams& p, hipStream_t s);
 hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s);
 hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s);

@@ -317,6 +317,73 @@ hipError_t launch_raymarch(const RayParams& p, hipStream_t s)
     }
 }
 
+// ---- k_raymarch_intensity: PerformWindowedIntensityRaymarch (WindowedRaymarchMaterials.usf:187-242) ----------------
+// The slice view: the windowed intensity of the first sample the clipping plane leaves. Without a clipping plane that is
+// every ray's first sample, so one ray per lane is the right shape here (no long serial loop to split up).
+template <int DFMT>
+__global__ __launch_bounds__(256) void k_raymarch_intensity(const RayParams p)
+{
+    int i, j, px, py;
+    if (!tile_pixel(p, i, j, px, py)) return;
+    Ray ray;
+    cube_setup(p, px, py, ray);
+    const float step_size = 1 / p.steps;
+    const float actual = p.steps * ray.thickness;
+    const float fl = floorf(actual);
+    const int max_steps = (int) fl;
+    const float final_step = actual - fl;
+    const float sv0 = ray.lcv[0] * step_size, sv1 = ray.lcv[1] * step_size, sv2 = ray.lcv[2] * step_size;
+    float pos0 = ray.pos[0], pos1 = ray.pos[1], pos2 = ray.pos[2];
+    if (p.jitter_frame >= 0) {
+        uint32_t rr;
+        rand3d_pcg16(px, py, p.jitter_frame & 7, rr);
+        const float rnd = (float) rr / 65535.0f;
+        pos0 = pos0 - (sv0 * rnd); pos1 = pos1 - (sv1 * rnd); pos2 = pos2 - (sv2 * rnd);
+    }
+    const float nx = (float) p.data.nx, ny = (float) p.data.ny, nz = (float) p.data.nz;
+    auto intensity = [&](float u, float v, float w) -> float { // DataVolume.SampleLevel(Clamp, uvw).r -> clamp(TFPos, 0, 1)
+        int ix, iy, iz;
+        float fx, fy, fz;
+        texel_split(u, nx, ix, fx);
+        texel_split(v, ny, iy, fy);
+        texel_split(w, nz, iz, fz);
+        const float val = sample_trilinear_at<DFMT>(p.data.data, tap_offsets<ADDR_CLAMP>(p.data, ix, iy, iz), fx, fy, fz);
+        return __builtin_amdgcn_fmed3f(tf_position(val, p.win.center, p.win.width), 0.0f, 1.0f);
+    };
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // didn't hit anything (:241)
+    bool hit = false;
+    for (int k = 0; k < max_steps; ++k) {
+        pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2;
+        const float s0 = saturate_(pos0), s1 = saturate_(pos1), s2 = saturate_(pos2);
+        if (!(p.clip_mode && is_clipped(s0, s1, s2, p.cc, p.cd))) {
+            const float t = intensity(s0, s1, s2);
+            out = make_float4(t, t, t, 1.0f);
+            hit = true;
+            break;
+        }
+    }
+    if (!hit && final_step > 0.0f) {
+        pos0 = pos0 + (sv0 * final_step); pos1 = pos1 + (sv1 * final_step); pos2 = pos2 + (sv2 * final_step);
+        if (!(p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd))) {
+            const float t = intensity(pos0, pos1, pos2);
+            out = make_float4(t, t, t, 1.0f);
+        }
+    }
+    reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = out;
+}
+
+hipError_t launch_raymarch_intensity(const RayParams& p, hipStream_t s)
+{
+    if (p.tile_w <= 0 || p.tile_h <= 0) return hipSuccess;
+    const dim3 grid((p.tile_w + 15) / 16, (p.tile_h + 15) / 16), block(256);
+    switch (p.data.fmt) {
+        case FMT_U8: hipLaunchKernelGGL(k_raymarch_intensity<FMT_U8>, grid, block, 0, s, p); break;
+        case FMT_U16: hipLaunchKernelGGL(k_raymarch_intensity<FMT_U16>, grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL(k_raymarch_intensity<FMT_F32>, grid, block, 0, s, p); break;
+    }
+    return hipGetLastError();
+}
+
 // Nominal samples: sum over rays of floor(Steps*thickness) + [frac > 0].
 __global__ __launch_bounds__(256) void k_count_samples(const RayParams p)
 {

@@ -78,6 +78,13 @@ int main(int argc, char** argv)
     double sum_a = 0, max_a = 0;
     for (size_t i = 3; i < img.size(); i += 4) { sum_a += img[i]; max_a = img[i] > max_a ? img[i] : max_a; }
     std::printf("render mean_alpha=%.6f max_alpha=%.6f\n", sum_a / (64 * 64), max_a);
+    // SwitchRenderer(Intensity): the slice view needs no lights; switching back to Lit requests a recompute (:786-800)
+    volume.SwitchRenderer(tbrm_plugin::ERaymarchMaterial::Intensity);
+    if (!volume.Render(cam, img.data())) { std::printf("error=%s\n", tbrm_last_error()); return 4; }
+    double hit = 0, sum_i = 0;
+    for (size_t i = 0; i < img.size(); i += 4) { hit += img[i + 3]; sum_i += img[i]; }
+    std::printf("intensity hit_fraction=%.6f mean_intensity_of_hits=%.6f\n", hit / (64 * 64), hit > 0 ? sum_i / hit : 0.0);
+    volume.SwitchRenderer(tbrm_plugin::ERaymarchMaterial::Lit);
     uint64_t counters[3];
     tbrm_launch_counters(volume.RaymarchResources.Handle, counters);
     std::printf("launches chunk=%llu slice=%llu raymarch=%llu\n", (unsigned long long) counters[0], (unsigned long long) counters[1], (unsigned long long) counters[2]);

@@ -33,4 +33,7 @@ def test_facade_tick_policy_on_gpu(tmp_path, gpu):
     assert lines["after_window_change"] == "resets=3 adds=9 changes=1"   # windowing change -> bRequestedRecompute
     mean_a = float(lines["render"].split("mean_alpha=")[1].split()[0])
     assert 0.01 < mean_a < 0.9
-    assert "slice=0" in lines["launches"] and "raymarch=1" in lines["launches"]
+    hit = float(lines["intensity"].split("hit_fraction=")[1].split()[0])
+    grey = float(lines["intensity"].split("mean_intensity_of_hits=")[1].split()[0])
+    assert 0.05 < hit < 1.0 and 0.0 <= grey <= 1.0                       # SwitchRenderer(Intensity): the slice view
+    assert "slice=0" in lines["launches"] and "raymarch=2" in lines["launches"]  # one lit + one intensity frame

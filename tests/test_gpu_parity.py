@@ -282,3 +282,37 @@ def test_raymarch_leaping_over_sparse_blobs(gpu, oracle_mod):
             ref, _ = orc.raymarch_lit(cam, tile, abi.RaymarchParams(96.0, -1, True), world)
             got = res.raymarch_lit(cam, tile, abi.RaymarchParams(96.0, -1, True), world)
             assert np.abs(got - ref).max() <= TIGHT_TOL
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_raymarch_intensity_matches_oracle(gpu, oracle_mod, dtype):
+    """The Intensity render mode (PerformWindowedIntensityRaymarch): with and without a clip plane, jitter, tiles,
+    scene depth; the clamp sampler is used whatever address mode the lit material has."""
+    res, orc = make_pair(gpu, oracle_mod, (40, 36, 44), dtype, addr=abi.ADDRESS_WRAP, window=(0.45, 0.6, True, True))
+    tr = abi.identity_transform(scale=(100.0, 120.0, 90.0), rotation=(0.0, 0.2588190, 0.0, 0.9659258))
+    worlds = [S.default_world(), abi.make_world(tr, clip_center=(5.0, 0.0, 0.0), clip_direction=(0.5, 0.5, 0.7)),
+              abi.make_world(tr, clip_center=(500.0, 0.0, 0.0), clip_direction=(1.0, 0.0, 0.0))]
+    cam = S.default_camera(72, 56)
+    full_tile = abi.Tile(0, 0, 72, 56)
+    with res:
+        for wi, world in enumerate(worlds):
+            for steps, jitter in ((64.0, -1), (37.5, 4), (0.6, -1)):
+                rp = abi.RaymarchParams(steps, jitter, True)
+                got = res.raymarch_intensity(cam, full_tile, rp, world)
+                ref = orc.raymarch_intensity(cam, full_tile, rp, world)
+                assert np.abs(got - ref).max() <= TIGHT_TOL, (wi, steps, jitter)
+                assert np.array_equal(got[..., 3], ref[..., 3])
+        world = worlds[1]
+        rp = abi.RaymarchParams(64.0, 2, True)
+        full = res.raymarch_intensity(cam, full_tile, rp, world)
+        assert (full[..., 3] == 1).any() and (full[..., 3] == 0).any()
+        sub = res.raymarch_intensity(cam, abi.Tile(17, 9, 30, 21), rp, world)
+        assert np.array_equal(sub, full[9:30, 17:47])
+        import torch
+        depth = np.full((56, 72), 150.0, dtype=np.float32)
+        d_dev = torch.from_numpy(depth).cuda()
+        out = torch.empty((56, 72, 4), dtype=torch.float32, device="cuda")
+        res.raymarch_intensity_device(cam, full_tile, rp, world, out.data_ptr(), d_dev.data_ptr())
+        res.flush()
+        ref_d = orc.raymarch_intensity(cam, full_tile, rp, world, scene_depth=depth)
+        assert np.abs(out.cpu().numpy() - ref_d).max() <= TIGHT_TOL

@@ -212,3 +212,41 @@ def test_pcg_jitter_and_tiles(oracle_mod):
     assert np.array_equal(sub, a[16:24, 8:24])
     inter, _ = orc.raymarch_lit(cam, abi.Tile(0, 8, 32, 16, 2), abi.RaymarchParams(40.0, -1, False), world)
     assert np.array_equal(inter, a[[8 + (j // 8) * 16 + j % 8 for j in range(16)]])
+
+
+def test_intensity_renderer_known_answers(oracle_mod):
+    """PerformWindowedIntensityRaymarch (WindowedRaymarchMaterials.usf:187-242): the first unclipped sample's clamped TF
+    position as grey with alpha 1. A volume that is a linear ramp along x (v = x-texel-centre coordinate) makes the answer a
+    closed form of the sample position: without a clip plane the first sample sits one step inside the entry face; with a
+    plane through the centre keeping +x it is the first sample past x = 0.5."""
+    n = 64
+    ramp = ((np.arange(n, dtype=np.float32) + 0.5) / n)  # value = u at every texel centre -> trilinear value = u
+    vol = np.broadcast_to(ramp[None, None, :], (n, n, n)).copy()
+    orc = oracle_mod.OracleScene(vol, light_32bit=True)
+    orc.set_tf_lut(const_tf((1, 1, 1), 1.0))
+    centre, width = 0.5, 0.8
+    orc.set_windowing(abi.WindowingParams(centre, width, True, True))
+    world = S.default_world()
+    cam = abi.look_at_camera((-300.0, 0.0, 0.0), (0, 0, 0), (0, 0, 1), 60.0, 1, 1)  # one ray along +x through the centre
+    steps = 50.0
+    img = orc.raymarch_intensity(cam, abi.Tile(0, 0, 1, 1), abi.RaymarchParams(steps, -1, False), world)
+    u = 1.0 / steps  # first sample: one step inside
+    want = min(max((u - centre + width / 2) / width, 0.0), 1.0)
+    assert img[0, 0, 3] == 1.0 and img[0, 0, 0] == img[0, 0, 1] == img[0, 0, 2]
+    assert img[0, 0, 0] == pytest.approx(want, abs=1e-5)
+    plane_u = 0.51  # between two samples, so rounding of the repeated additions cannot move a sample across it
+    clipped = abi.make_world(abi.identity_transform(S.VOLUME_SCALE), clip_center=((plane_u - 0.5) * S.VOLUME_SCALE, 0, 0),
+                             clip_direction=(1, 0, 0))
+    img = orc.raymarch_intensity(cam, abi.Tile(0, 0, 1, 1), abi.RaymarchParams(steps, -1, False), clipped)
+    k = math.floor(plane_u * steps) + 1  # first sample with u > plane_u (dot(p - centre, dir) <= 0 is clipped)
+    want = min(max((k / steps - centre + width / 2) / width, 0.0), 1.0)
+    assert img[0, 0, 3] == 1.0 and img[0, 0, 0] == pytest.approx(want, abs=1e-5)
+    # a plane that removes the whole cube: nothing is hit
+    gone = abi.make_world(abi.identity_transform(S.VOLUME_SCALE), clip_center=(200, 0, 0), clip_direction=(1, 0, 0))
+    img = orc.raymarch_intensity(cam, abi.Tile(0, 0, 1, 1), abi.RaymarchParams(steps, -1, False), gone)
+    assert not img.any()
+    # rays that miss the cube stay (0,0,0,0); values outside the window clamp to 0 / 1
+    wide = S.default_camera(32, 32)
+    img = orc.raymarch_intensity(wide, abi.Tile(0, 0, 32, 32), abi.RaymarchParams(steps, -1, False), world)
+    assert (img[..., 3] == 0).any() and (img[..., 3] == 1).any()
+    assert set(np.unique(img[..., 3])) <= {0.0, 1.0} and img[..., 0].min() >= 0.0 and img[..., 0].max() <= 1.0
