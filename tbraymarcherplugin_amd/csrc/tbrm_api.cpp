@@ -271,8 +271,6 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     tx.lo = std::min(tx.lo, 0); tx.hi = std::max(tx.hi, 0);
     ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
     p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
-    p.cx = 0;
-    p.cy = 0;
     p.b_added = b_added;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
     if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
@@ -347,7 +345,6 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         HIP_TRY(launch_occ_flags(p, change, n_spans, r->stream));
     }
 
-    p.tile_i0 = p.tile_j0 = 0;
     p.tiles_x = ceil_div(W, kChunkTile);
     p.tiles_y = ceil_div(H, kChunkTile);
     p.occ_base = r->d_occ;

@@ -54,8 +54,7 @@ struct PropParams {
     PropStream r;      // the removed light (Change only)
 };
 
-// One launch of the chunked propagation kernel: `n_steps` consecutive slices of one axis pass for every tile of
-// the slice plane (tbrm_light_kernels.hip, DESIGN.md "Illumination kernel").
+// One light stream of a chunked propagation pass (Add: the added light; Change: a = added, r = removed).
 struct ChunkStream {
     float border_light;
     float off_u, off_v;
@@ -65,12 +64,12 @@ struct ChunkStream {
     const float* plane_in;  // propagated light after the previous chunk (W x H floats); unused in the first chunk
     float* plane_out;       // propagated light after this chunk
     uint32_t occ_off;       // chain: float index, relative to ChunkParams::occ_base, of the occlusion plane of the chunk's first slice
-    float* occ_next;        // occlusion of the next chunk's slices: [next_n][H][W]
+    float* occ_next;        // occlusion launch: where the span's factors 1 - CurrentSample go, [span slices][H][W]
 };
 
-// One launch of the fused propagation kernel (tbrm_light_kernels.hip, DESIGN.md "Illumination kernel"):
-// "chain" workgroups advance every tile of the slice plane through the `n_steps` slices of the current chunk while
-// "occlusion" workgroups compute the opacity samples of the NEXT chunk's slices.
+// Parameters of the chunked propagation kernels (tbrm_light_kernels.hip). One struct serves the per-pass
+// launches (k_occ_flags, k_occ_compact), the occlusion launch of a span (j0 / n_steps = the span) and the chain launch
+// of a chunk (j0 / n_steps = the chunk).
 struct ChunkParams {
     VolumeDev data;
     float data_border;
@@ -84,17 +83,11 @@ struct ChunkParams {
     int axis;
     int W, H;               // TD.X, TD.Y
     int dir;                // +-1
-    // chain part
-    int j0, n_steps;        // first slice of the chunk, steps in this chunk (0: no chain work in this launch)
-    int first_chunk;
-    int tile_i0, tile_j0;   // index of the first tile (may be negative: sheared passes need lead-in tiles)
-    int tiles_x, tiles_y;
-    int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch
-    int cx, cy;             // per-step shift of the ownership frame, within [d*_lo, d*_hi]
+    int j0, n_steps;        // first slice and number of slices of this launch (a span for the occlusion, a chunk for the chain)
+    int first_chunk;        // chain: the pass starts here (windows start from the cleared buffers' value)
+    int tiles_x, tiles_y;   // chain: 32x32 tiles of the slice plane
+    int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch, widened to contain 0
     float b_added;
-    // occlusion part
-    int next_j0, next_n;    // first slice and number of slices of the next chunk (0: none)
-    int occ_tiles_x, occ_tiles_y;
     // empty-block hand-off: k_occ_flags marks, once per pass, every occlusion workgroup (16x16 pixels x 8 slices) whose
     // samples can only touch data bricks that map every value to opacity 0. Such a workgroup exits at once and the chain
     // stages the factor 1 - 0 for its pixels from a page of ones instead of the plane stack.

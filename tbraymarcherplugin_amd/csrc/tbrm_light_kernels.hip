@@ -1,26 +1,27 @@
 // tbrm_light_kernels.hip — gfx950 kernels of the illumination pass (Sunden/Ropinski selective light updates).
 //
-//   k_light_occlusion + k_light_chain : the production pair. Per chunk of up to 16 consecutive slices, the first
-//                       computes the opacity sample of every voxel of the chunk (no halo, fully parallel), the
-//                       second advances EVERY tile of the slice plane through the chunk, so an axis pass over a
-//                       512-deep volume is 2 x 32 launches instead of the reference's 512 dispatches
-//                       (LightingShaders.cpp:132-158).
-//   k_propagate_slice : the reference's structure, one slice per launch (AddDirLightShader.usf:68-128,
-//                       ChangeDirLightShader.usf:74-156). Fallback for passes the chunk kernel declines
-//                       (degenerate offsets) and the A/B baseline (TBRM_FORCE_SLICE_KERNEL=1).
+//   k_occ_flags, k_occ_compact        : once per axis pass — which 16x16x8 occlusion blocks can only see empty bricks,
+//                                       and per span the ascending list of the blocks that cannot.
+//   k_light_occlusion                 : once per span of up to 128 slices — the factor 1 - CurrentSample
+//                                       (AddDirLightShader.usf:85-117) of every voxel of the span, no halo, fully
+//                                       parallel, live blocks dealt evenly over the CUs from the list.
+//   k_light_chain                     : once per chunk of 16 / 8 / 4 slices — advances EVERY 32x32 tile of the slice
+//                                       plane through the chunk, so an axis pass over a 512-deep volume is 4 + 32..64
+//                                       launches instead of the reference's 512 dispatches (LightingShaders.cpp:132-158).
+//   k_propagate_slice                 : the reference's structure, one slice per launch (AddDirLightShader.usf:68-128,
+//                                       ChangeDirLightShader.usf:74-156). Fallback for passes the chunk kernels
+//                                       decline (degenerate offsets) and the A/B baseline (TBRM_FORCE_SLICE_KERNEL=1).
 //
 // Why chunks work: slice k only needs the previous slice's propagated light inside a small bilinear footprint,
 // offset by the constant PrevPixelOffset. A workgroup that owns a 32x32 tile at the END of a chunk therefore only
 // needs a (32 + steps*g)^2 window of the plane at the START of the chunk (g = width of the footprint in texels,
 // normally 1) and recomputes that shrinking window privately in LDS — no inter-workgroup traffic inside a chunk,
-// one kernel boundary between chunks. The window moves with the light (integer shear cx,cy per slice) so strongly
-// slanted second-axis passes keep the same small halo. The expensive part of a voxel — the windowed, opacity-
-// corrected data sample "CurrentSample" (AddDirLightShader.usf:85-114) — does not depend on the propagated light, so
-// it is computed once per voxel, without halo, by k_light_occlusion and handed over through a scratch plane stack
-// that k_light_chain stages into LDS with asynchronous global->LDS loads before its first step; the chain itself is
-// then a handful of LDS reads and one multiply per voxel, with no memory latency between slices. Arithmetic per voxel is
-// exactly the reference's, including the per-slice UNORM8 re-quantisation of the propagated light
-// (RaymarchVolume.cpp:857-866).
+// one kernel boundary between chunks. The expensive part of a voxel — the windowed, opacity-corrected data sample
+// "CurrentSample" (AddDirLightShader.usf:85-114) — does not depend on the propagated light, so it is computed once per
+// voxel, without halo, by k_light_occlusion and handed over through a scratch plane stack that k_light_chain stages
+// into LDS with asynchronous global->LDS copies two slices ahead of their use; the chain itself is then a handful of
+// LDS reads and one multiply per voxel, with no memory latency between slices. Arithmetic per voxel is exactly the
+// reference's, including the per-slice UNORM8 re-quantisation of the propagated light (RaymarchVolume.cpp:857-866).
 #include "tbrm_device_sampling.h"
 
 #include <type_traits>
