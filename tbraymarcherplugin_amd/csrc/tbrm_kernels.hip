@@ -136,27 +136,29 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // A ray is a serial loop in the reference (positions by repeated addition, front-to-back accumulation with early
 // exit). One ray per lane makes a frame as slow as its longest ray: a 512-step ray is 512 dependent memory round trips
 // while most of the chip has long run out of work (measured: 1.5 resident waves per SIMD on average, 14 % VALU issue).
-// Here a wave marches 8 rays (a 4x2 pixel patch) with 8 lanes each: per trip lane b of a ray evaluates sample 8*trip + b
+// Here a wave marches 16 rays with 4 lanes each (or 8 with 8; a 4x4 / 4x2 pixel patch): per trip lane b of a ray evaluates
+// sample L*trip + b
 // — position, clip / empty-brick test, 16 taps, transfer function, opacity correction, light — so the expensive part of
-// 8 consecutive samples runs side by side, and only the cheap part stays serial: the 8 lanes exchange their
-// (colour*alpha, alpha) through LDS and each replays AccumulateLightEnergy over the 8 samples in ray order, which also
+// L consecutive samples runs side by side, and only the cheap part stays serial: the L lanes exchange their
+// (colour*alpha, alpha) through LDS and each replays AccumulateLightEnergy over the L samples in ray order, which also
 // decides the early exit exactly where the reference takes it. Arithmetic per sample and per accumulation step is the
 // reference's; a lane reaches its sample position by performing every addition of the ray up to it.
-constexpr int kRayLanes = 8;                       // lanes (consecutive samples) per ray
-constexpr int kRayBlockW = 8, kRayBlockH = 4;      // pixels per 256-thread workgroup: 4 waves of 4x2 rays
-
-template <int DFMT, int LFMT, int DMODE>
+template <int DFMT, int LFMT, int DMODE, int kRayLanes>
 __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
 {
+    static_assert(kRayLanes == 4 || kRayLanes == 8, "instantiated for 4 and 8 lanes per ray");
+    constexpr int PW = 4, PH = kRayLanes == 4 ? 4 : 2; // rays of a wave: a PW x PH pixel patch
+    constexpr int kRayBlockW = 2 * PW, kRayBlockH = 2 * PH;
+    constexpr int LSH = kRayLanes == 4 ? 2 : 3;
     __shared__ float4 s_tf[256];
     __shared__ float4 s_x[256]; // per lane: (colour * alpha, alpha) of its sample; alpha < 0: nothing to accumulate
     s_tf[threadIdx.x] = p.tf[threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = lane & (kRayLanes - 1), r = lane >> 3; // sample slot, ray within the wave
-    const int i = blockIdx.x * kRayBlockW + (wave & 1) * 4 + (r & 3);
-    const int j = blockIdx.y * kRayBlockH + (wave >> 1) * 2 + (r >> 2);
+    const int b = lane & (kRayLanes - 1), r = lane >> LSH; // sample slot, ray within the wave
+    const int i = blockIdx.x * kRayBlockW + (wave & 1) * PW + (r % PW);
+    const int j = blockIdx.y * kRayBlockH + (wave >> 1) * PH + (r / PW);
     int px, py;
     const bool valid = tile_pixel_at(p, i, j, px, py);
 
@@ -294,13 +296,26 @@ __global__ __launch_bounds__(256) void k_raymarch_lit(const RayParams p)
     if (valid && b == 0) reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
 }
 
+template <int DFMT, int LFMT, int RL>
+static hipError_t launch_ray3(const RayParams& p, hipStream_t s)
+{
+    constexpr int BW = 8, BH = RL == 4 ? 8 : 4; // 4 waves of 4x4 / 4x2 rays
+    const dim3 grid((p.tile_w + BW - 1) / BW, (p.tile_h + BH - 1) / BH), block(256);
+    if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP, RL>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP, RL>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
 template <int DFMT, int LFMT>
 static hipError_t launch_ray2(const RayParams& p, hipStream_t s)
 {
-    const dim3 grid((p.tile_w + kRayBlockW - 1) / kRayBlockW, (p.tile_h + kRayBlockH - 1) / kRayBlockH), block(256);
-    if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP>), grid, block, 0, s, p);
-    return hipGetLastError();
+    // Lanes per ray, measured on MI355X (ms per frame; 2 lanes: 0.85 / 0.64 / 0.27, 16 lanes: 0.80 / 1.50 / 0.15):
+    //                     config 3 (1024^2 rays)   config 5 (2048^2)   config 2 (512^2)
+    //   4 lanes per ray          0.57                    0.68                0.18
+    //   8 lanes per ray          0.61                    0.95                0.14
+    // More lanes per ray shorten the serial chain, fewer keep more rays (and their setup) per wave: small frames want 8.
+    const char* e = getenv("TBRM_RAY_LANES");
+    const int rl = e ? atoi(e) : ((long long) p.tile_w * p.tile_h <= 300000 ? 8 : 4);
+    return rl == 8 ? launch_ray3<DFMT, LFMT, 8>(p, s) : launch_ray3<DFMT, LFMT, 4>(p, s);
 }
 template <int DFMT>
 static hipError_t launch_ray1(const RayParams& p, hipStream_t s)

@@ -49,6 +49,13 @@ def kernel_variant(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=["4", "8"])
+def ray_lanes(request, monkeypatch):
+    """Runs a raymarch test with both lanes-per-ray variants of k_raymarch_lit (the launcher picks by frame size otherwise)."""
+    monkeypatch.setenv("TBRM_RAY_LANES", request.param)
+    return request.param
+
+
 FACE_LIGHTS = [((1, .35, -.5), 0.5), ((-1, .2, .4), 0.6), ((.3, 1, -.2), 0.5), ((.25, -1, .5), 0.7),
                ((.1, .45, 1), 0.5), ((-.35, .2, -1), 0.9), ((1, 0, 0), 0.5), ((0, 0, -1), 0.8), ((1, 1, 0), 0.6)]
 
@@ -155,7 +162,7 @@ def lit_pair(gpu, oracle_mod, dims=(48, 48, 48), dtype=np.uint16, light_32bit=Fa
 
 @pytest.mark.parametrize("dtype,light_32bit,addr", [(np.uint16, False, abi.ADDRESS_WRAP), (np.float32, True, abi.ADDRESS_WRAP),
                                                     (np.uint8, False, abi.ADDRESS_CLAMP)])
-def test_raymarch_lit_matches_oracle(gpu, oracle_mod, dtype, light_32bit, addr):
+def test_raymarch_lit_matches_oracle(gpu, oracle_mod, dtype, light_32bit, addr, ray_lanes):
     res, orc, world = lit_pair(gpu, oracle_mod, (48, 40, 44), dtype, light_32bit, addr=addr)
     cam = S.default_camera(96, 80)
     tile = abi.Tile(0, 0, 96, 80)
@@ -182,7 +189,7 @@ def test_raymarch_skipping_is_exact_and_bone_tf(gpu, oracle_mod):
         assert (ref[..., 3] == 1.0).any()  # early termination is exercised
 
 
-def test_raymarch_clip_plane_tiles_and_depth(gpu, oracle_mod):
+def test_raymarch_clip_plane_tiles_and_depth(gpu, oracle_mod, ray_lanes):
     res, orc = make_pair(gpu, oracle_mod, (40, 40, 40), np.uint16)
     tr = abi.identity_transform(scale=(100.0, 100.0, 100.0), rotation=(0.0, 0.2588190, 0.0, 0.9659258))
     world = abi.make_world(tr, clip_center=(5.0, 0.0, 0.0), clip_direction=(0.5, 0.5, 0.7))
@@ -214,7 +221,7 @@ def test_raymarch_clip_plane_tiles_and_depth(gpu, oracle_mod):
         assert not np.array_equal(ref_d, full_ref)
 
 
-def test_raymarch_short_rays_and_odd_tiles(gpu, oracle_mod):
+def test_raymarch_short_rays_and_odd_tiles(gpu, oracle_mod, ray_lanes):
     """The kernel evaluates 8 consecutive samples of a ray side by side and replays the accumulation in order: rays whose
     sample count falls on every side of a multiple of 8 (0, 1, 7, 8, 9, ...), fractional last steps, early exits in the
     middle of a group and tiles that are no multiple of the 8x4 pixel block must all match the serial oracle."""
@@ -245,7 +252,7 @@ def test_raymarch_short_rays_and_odd_tiles(gpu, oracle_mod):
         assert (ref[..., 3] == 1.0).mean() > 0.05  # early exits are common among the rays that hit the cube
 
 
-def test_raymarch_leaping_over_sparse_blobs(gpu, oracle_mod):
+def test_raymarch_leaping_over_sparse_blobs(gpu, oracle_mod, ray_lanes):
     """Empty-space leaping (per-brick distance field): a volume that is empty except for a few small blobs — long leaps,
     blobs entered from empty space at every angle, wrap and clamp addressing — renders exactly as without skipping, and
     as the oracle renders it."""
