@@ -75,7 +75,9 @@ def main():
     one_gpu_dry_run = os.environ.get("TBRM_BENCH_ONE_GPU_DRY_RUN") == "1"
     if one_gpu_dry_run:
         local_rank = 0
-    if n_gpus > 1:
+    # TBRM_BENCH_FORCE_DIST=1 runs the N>1 code path (RCCL collectives included) with a single rank: the only way to
+    # exercise it over RCCL on a 1-GPU box.
+    if n_gpus > 1 or os.environ.get("TBRM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -147,8 +149,12 @@ def main():
         res.flush()
     reset_ms = (time.perf_counter() - t0) * 1e3
 
-    out = torch.empty((rows_per_rank, fb_w, 4), dtype=torch.float32, device=device)
-    gathered = torch.empty((n_gpus, rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) if n_gpus > 1 else None
+    # Two output tiles / gather buffers: the all-gather of frame k runs (asynchronously, on RCCL's stream) while the light
+    # update of frame k+1 is already executing on the library's stream; a buffer is reused only after its gather is done.
+    outs = [torch.empty((rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) for _ in range(2)]
+    gathers = [torch.empty((n_gpus, rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) for _ in range(2)] if dist is not None else [None, None]
+    pending = [None, None]
+    out, gathered = outs[0], gathers[0]
     my_samples = res.count_nominal_samples(cam, tile, rp, world)
     total_samples = my_samples
     red_device = torch.device("cpu") if one_gpu_dry_run else device
@@ -159,6 +165,7 @@ def main():
 
     angle = [0.0] * len(lights)
     ms_illum, ms_ray = [], []
+    last = [0]  # buffer index of the most recent frame
 
     def one_step(k, record):
         if not args.raymarch_only:
@@ -167,15 +174,21 @@ def main():
             new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li]), lights[li].light_intensity)
             res.change_dir_light(lights[li], new, world)
             lights[li] = new
-        res.raymarch_lit_device(cam, tile, rp, world, out.data_ptr())
+        b = k & 1
+        if pending[b] is not None:  # the gather that last read outs[b] / wrote gathers[b]
+            pending[b].wait()
+            torch.cuda.current_stream().synchronize()
+            pending[b] = None
+        res.raymarch_lit_device(cam, tile, rp, world, outs[b].data_ptr())
         if dist is not None:
-            res.flush()  # the tile must be complete before RCCL reads it on torch's stream
+            res.flush()  # the tile must be complete before RCCL reads it
             if one_gpu_dry_run:
-                parts = [torch.empty(out.shape, dtype=out.dtype) for _ in range(n_gpus)]
-                dist.all_gather(parts, out.cpu())
-                gathered.copy_(torch.stack(parts))
+                parts = [torch.empty(outs[b].shape, dtype=outs[b].dtype) for _ in range(n_gpus)]
+                dist.all_gather(parts, outs[b].cpu())
+                gathers[b].copy_(torch.stack(parts))
             else:
-                dist.all_gather_into_tensor(gathered, out)
+                pending[b] = dist.all_gather_into_tensor(gathers[b], outs[b], async_op=True)
+        last[0] = b
         if record:
             if not args.raymarch_only:
                 ms_illum.append(res.last_gpu_time_ms(0))
@@ -189,10 +202,15 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k, False)
+    for h in pending:
+        if h is not None:
+            h.wait()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    pending = [None, None]
+    out, gathered = outs[last[0]], gathers[last[0]]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,6 +234,9 @@ def main():
     # ---- per-kernel GPU time with HIP events on the library's stream (separate, untimed pass) -------------
     for k in range(max(3, min(args.steps, 10))):
         one_step(args.warmup + args.steps + k, True)
+    for h in pending:
+        if h is not None:
+            h.wait()
     torch.cuda.synchronize()
     ray_ms = float(np.mean(ms_ray))
     illum_ms = float(np.mean(ms_illum)) if ms_illum else 0.0
@@ -270,7 +291,7 @@ def main():
                        "parallelism": f"image tiles x{n_gpus} (interleaved 8-row groups), volumes replicated"
                                       if n_gpus > 1 else "single GPU",
                        "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only),
-                       "light_parallel_reset": bool(args.light_parallel_reset and n_gpus > 1)},
+                       "light_parallel_reset": bool(args.light_parallel_reset and dist is not None)},
             "nominal_samples_per_step": total_samples,
             "gathered_frame_equals_single_gpu_render": gather_ok,
             "gpu_ms": {"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4), "reset_all_lights_setup": round(reset_ms, 2)},
