@@ -894,14 +894,22 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     }
 }
 
+constexpr int kMaxDevices = 64;
+static int current_device()
+{
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+
 template <int DFMT, bool CHANGE, int AXIS>
 static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
 {
     const dim3 grid((p.W + kOccTile - 1) / kOccTile, (p.H + kOccTile - 1) / kOccTile, (p.n_steps + kOccDepth - 1) / kOccDepth), block(256);
     size_t lds = occlusion_lds_bytes(p);
     if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
-    static bool attr = false;
-    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_occlusion<DFMT, CHANGE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr = true; }
+    static bool attr[kMaxDevices] = {}; // the attribute is per device
+    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_occlusion<DFMT, CHANGE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr[dev] = true; }
     hipLaunchKernelGGL((k_light_occlusion<DFMT, CHANGE, AXIS>), grid, block, lds, s, p, (int) lds);
     return hipGetLastError();
 }
@@ -929,8 +937,8 @@ hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t
 template <int LFMT, bool CHANGE, int AXIS, int KH, int RS>
 static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 {
-    static bool attr = false;
-    if (!attr) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static bool attr[kMaxDevices] = {}; // the attribute is per device
+    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
     const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
     hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH, RS>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
