@@ -387,17 +387,19 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
 
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
     const int data_dims[3] = {p.data.nx, p.data.ny, p.data.nz};
-    // which block of the chunk: its own grid position, or (sparse chunks) entry `linear id` of the chunk's work list —
-    // workgroups flagged empty by k_occ_flags (every CurrentSample exactly 0, and the chain knows it) are not on the list
-    int gx = blockIdx.x, gy = blockIdx.y, gz = blockIdx.z;
-    if (p.occ_list) {
-        const int slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (slot >= *p.occ_count) return;
-        const int id = (int) p.occ_list[slot];
-        gx = id % p.occ_blocks_x;
-        gy = (id / p.occ_blocks_x) % p.occ_blocks_y;
-        gz = id / (p.occ_blocks_x * p.occ_blocks_y);
-    } else if (p.occ_flags && p.occ_flags[(gz * p.occ_blocks_y + gy) * p.occ_blocks_x + gx]) return; // list off (A/B runs)
+    // The launch is a 1-D grid rounded up to a multiple of 8 workgroups. Workgroups are dealt to the 8 XCDs round-robin by
+    // id (an affinity used for speed only): XCD x takes the x-th eighth of the work, so blocks that are neighbours in the
+    // volume — and stage the same halo bricks — run behind the same L2.
+    const int groups = (p.n_steps + kOccDepth - 1) / kOccDepth;
+    const int total = p.occ_list ? *p.occ_count : groups * p.occ_blocks_y * p.occ_blocks_x;
+    const int per_xcd = (total + 7) >> 3;
+    const int entry = ((int) blockIdx.x & 7) * per_xcd + ((int) blockIdx.x >> 3);
+    if (((int) blockIdx.x >> 3) >= per_xcd || entry >= total) return;
+    // which block of the span: the entry itself, or (sparse spans) that entry of the span's work list — workgroups flagged
+    // empty by k_occ_flags (every CurrentSample exactly 0, and the chain knows it) are not on the list
+    const int id = p.occ_list ? (int) p.occ_list[entry] : entry;
+    const int gx = id % p.occ_blocks_x, gy = (id / p.occ_blocks_x) % p.occ_blocks_y, gz = id / (p.occ_blocks_x * p.occ_blocks_y);
+    if (!p.occ_list && p.occ_flags && p.occ_flags[id]) return; // list off (A/B runs)
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
     const int nk = min(kOccDepth, p.n_steps - k0);
 
@@ -611,7 +613,14 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const ChunkGeom g = chunk_geometry(p);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int plane_elems = p.H * p.W;
-    const int base_x = (int) blockIdx.x * T, base_y = (int) blockIdx.y * T;
+    // Tile of this workgroup. Workgroups go to the 8 XCDs round-robin by linear id (an affinity used for speed only): XCD x
+    // takes the x-th eighth of the row-major tile list — a band of neighbouring tiles whose overlapping halo reads of the
+    // occlusion planes then meet in one L2.
+    const int n_tiles = p.tiles_x * p.tiles_y, per_xcd = (n_tiles + 7) >> 3;
+    const int tile_id = ((int) blockIdx.x & 7) * per_xcd + ((int) blockIdx.x >> 3);
+    if (((int) blockIdx.x >> 3) >= per_xcd || tile_id >= n_tiles) return;
+    const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
+    const int base_x = tile_x * T, base_y = tile_y * T;
 
     // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, ring slot q at ((2 + q)*NS + si)*PLANE; then the
     // light-volume tile (bytes)
@@ -905,7 +914,8 @@ static int current_device()
 template <int DFMT, bool CHANGE, int AXIS>
 static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
 {
-    const dim3 grid((p.W + kOccTile - 1) / kOccTile, (p.H + kOccTile - 1) / kOccTile, (p.n_steps + kOccDepth - 1) / kOccDepth), block(256);
+    const int blocks = ((p.W + kOccTile - 1) / kOccTile) * ((p.H + kOccTile - 1) / kOccTile) * ((p.n_steps + kOccDepth - 1) / kOccDepth);
+    const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
     size_t lds = occlusion_lds_bytes(p);
     if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
     static bool attr[kMaxDevices] = {}; // the attribute is per device
@@ -940,7 +950,7 @@ static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
     static bool attr[kMaxDevices] = {}; // the attribute is per device
     if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
     const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH, RS>), dim3(p.tiles_x, p.tiles_y), dim3(kChunkThreads), lds, s, p);
+    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH, RS>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
 template <int LFMT, bool CHANGE, int AXIS>
