@@ -741,6 +741,11 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             sqy[1 + k] = ly - g.pady;
         }
     }
+    // floor(a / d) for 0 <= a < 4096 and a small positive integer d, as a multiplication: (a + 0.5) / d is never within
+    // 0.5 / d of an integer, far more than the rounding error of the product
+    auto small_div = [](int a, float inv_d) -> int { return (int) (((float) a + 0.5f) * inv_d); };
+    const float inv_lox = g.lox < 0 ? 1.0f / (float) -g.lox : 0.0f, inv_hix = g.hix > 0 ? 1.0f / (float) g.hix : 0.0f;
+    const float inv_loy = g.loy < 0 ? 1.0f / (float) -g.loy : 0.0f, inv_hiy = g.hiy > 0 ? 1.0f / (float) g.hiy : 0.0f;
     int rmin[KS];          // the slot is inside the window while r >= rmin (huge: never / outside the buffer)
     int li[KS];            // LDS index of the slot inside a plane
     int ti[NS][KS];        // LDS index of the first previous-slice tap inside a plane
@@ -752,14 +757,16 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         const int px = base_x + qx, py = base_y + qy;
         const bool valid = qx > INT32_MIN / 4;
         const bool inplane = valid && (unsigned) px < (unsigned) p.W && (unsigned) py < (unsigned) p.H;
-        int need = 0; // smallest r whose window contains the slot
-        if (qx < 0) need = max(need, g.lox < 0 ? (-qx + (-g.lox) - 1) / (-g.lox) : INT32_MAX / 2);
-        if (qx >= T) need = max(need, g.hix > 0 ? (qx - T + g.hix) / g.hix : INT32_MAX / 2);
-        if (qy < 0) need = max(need, g.loy < 0 ? (-qy + (-g.loy) - 1) / (-g.loy) : INT32_MAX / 2);
-        if (qy >= T) need = max(need, g.hiy > 0 ? (qy - T + g.hiy) / g.hiy : INT32_MAX / 2);
+        int need = 0; // smallest r whose window contains the slot: ceil(distance to the tile / growth per slice)
+        if (qx < 0) need = max(need, g.lox < 0 ? small_div(-qx + (-g.lox) - 1, inv_lox) : INT32_MAX / 2);
+        if (qx >= T) need = max(need, g.hix > 0 ? small_div(qx - T + g.hix, inv_hix) : INT32_MAX / 2);
+        if (qy < 0) need = max(need, g.loy < 0 ? small_div(-qy + (-g.loy) - 1, inv_loy) : INT32_MAX / 2);
+        if (qy >= T) need = max(need, g.hiy > 0 ? small_div(qy - T + g.hiy, inv_hiy) : INT32_MAX / 2);
         rmin[k] = inplane ? need : INT32_MAX / 2;
         off_plane[k] = valid && !inplane;
         li[k] = valid ? (qy + g.pady) * RS + qx + g.padx : 0;
+        // (PixelLoc + 0.5) / BufferSize: the same for both streams
+        const float pu = ((float) (uint32_t) px + 0.5f) / (float) p.W, pv = ((float) (uint32_t) py + 0.5f) / (float) p.H;
 #pragma unroll
         for (int si = 0; si < NS; ++si) {
             // previous-slice tap split: ((c + 0.5)/size + PrevPixelOffset) -> (tap - c, frac) (AddDirLightShader.usf:81-82)
@@ -767,8 +774,8 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             int ix = 0, iy = 0;
             float fx = 0.0f, fy = 0.0f;
             if (inplane) {
-                texel_split((((float) (uint32_t) px + 0.5f) / (float) p.W) + s.off_u, (float) p.W, ix, fx);
-                texel_split((((float) (uint32_t) py + 0.5f) / (float) p.H) + s.off_v, (float) p.H, iy, fy);
+                texel_split(pu + s.off_u, (float) p.W, ix, fx);
+                texel_split(pv + s.off_v, (float) p.H, iy, fy);
                 ix -= px;
                 iy -= py;
             }
