@@ -236,6 +236,23 @@ TBRM_API int tbrm_raymarch_intensity_device(tbrm_resources* res, const tbrm_came
                                             const tbrm_raymarch_params* params, const tbrm_world_params* world,
                                             const float* device_scene_depth, float* device_out_rgba);
 
+/* The Octree render mode (ERaymarchMaterial::Octree; experimental in the reference: its march does no skipping yet).
+ * tbrm_generate_octree = URaymarchUtils::GenerateOctree (RaymarchUtils.cpp:94-102) -> GenerateOctreeForVolume_RenderThread
+ * (OctreeShaders.cpp:28-54) + GenerateOctreeShader.usf:28-107: a 4-mip UNORM16 max pyramid whose base level has the
+ * volume's dimensions rounded up to powers of two (RaymarchVolume.cpp:873-877); mip 0 copies the volume (0 outside it).
+ * tbrm_octree_mip_dims / tbrm_download_octree_mip expose a level (dense, x fastest, uint16 codes).
+ * tbrm_raymarch_octree[_device] = the M_Octree_Raymarch material: PerformRaymarchCubeSetup + PerformWindowedRaymarchOctree
+ * (WindowedRaymarchMaterials.usf:99-183): the unlit march over level `octree_mip` (OctreeVolumeMip), point sampled. */
+TBRM_API int tbrm_generate_octree(tbrm_resources* res);
+TBRM_API int tbrm_octree_mip_dims(const tbrm_resources* res, int mip, int32_t out_dims[3]);
+TBRM_API int tbrm_download_octree_mip(tbrm_resources* res, int mip, uint16_t* host_out, size_t bytes);
+TBRM_API int tbrm_raymarch_octree(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                  const tbrm_raymarch_params* params, const tbrm_world_params* world, int octree_mip,
+                                  float* host_out_rgba);
+TBRM_API int tbrm_raymarch_octree_device(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                         const tbrm_raymarch_params* params, const tbrm_world_params* world, int octree_mip,
+                                         const float* device_scene_depth, float* device_out_rgba);
+
 /* Nominal samples of one tile: sum over rays of floor(Steps*thickness) + [frac > 0]. Runs on
  * the GPU with the same cube-setup arithmetic as the raymarch; result is written to *out_samples.        */
 TBRM_API int tbrm_count_nominal_samples(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,

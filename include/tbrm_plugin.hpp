@@ -123,6 +123,12 @@ struct URaymarchUtils { // RaymarchUtils.h:33-93; all static, like the Blueprint
         tbrm_change_dir_light(Resources.Handle, &o, &n, &w, &flag);
         LightAdded = flag != 0;
     }
+    // RaymarchUtils.cpp:94-102
+    static bool GenerateOctree(FBasicRaymarchRenderingResources& Resources)
+    {
+        return Resources.Handle && tbrm_generate_octree(Resources.Handle) == TBRM_OK;
+    }
+
     static void ClearResourceLightVolumes(FBasicRaymarchRenderingResources Resources, float ClearValue)
     {
         if (!Resources.Handle) return;
@@ -186,6 +192,7 @@ public:
         if (!RaymarchResources.Handle) return false;
         const size_t bytes = (size_t) SizeX * SizeY * SizeZ * (Format == TBRM_FMT_G8 ? 1 : (Format == TBRM_FMT_G16 ? 2 : 4));
         if (tbrm_upload_volume(RaymarchResources.Handle, Voxels, bytes) != TBRM_OK) return false;
+        bRequestedOctreeRebuild = true; // :554
         if (!bHasTF) {
             std::vector<float> lut;
             URaymarchUtils::MakeDefaultTFTexture(lut);
@@ -219,7 +226,12 @@ public:
     void SetLowCutoff(bool Cutoff) { if (Cutoff != RaymarchResources.WindowingParameters.LowCutoff) { RaymarchResources.WindowingParameters.LowCutoff = Cutoff; WindowingChanged(); } }
     void SetHighCutoff(bool Cutoff) { if (Cutoff != RaymarchResources.WindowingParameters.HighCutoff) { RaymarchResources.WindowingParameters.HighCutoff = Cutoff; WindowingChanged(); } }
     void SetRaymarchSteps(float InSteps) { RaymarchingSteps = InSteps; } // :802-819
-    void SwitchRenderer(ERaymarchMaterial InSelectRaymarchMaterial) { SelectRaymarchMaterial = InSelectRaymarchMaterial; if (InSelectRaymarchMaterial == ERaymarchMaterial::Lit) bRequestedRecompute = true; } // :786-800
+    void SwitchRenderer(ERaymarchMaterial InSelectRaymarchMaterial) // :786-800, :304-307
+    {
+        SelectRaymarchMaterial = InSelectRaymarchMaterial;
+        if (InSelectRaymarchMaterial == ERaymarchMaterial::Lit) bRequestedRecompute = true;
+        if (InSelectRaymarchMaterial == ERaymarchMaterial::Octree) bRequestedOctreeRebuild = true;
+    }
 
     FRaymarchWorldParameters GetWorldParameters() const // :630-646
     {
@@ -304,11 +316,32 @@ public:
         return tbrm_raymarch_intensity(RaymarchResources.Handle, &Camera, &tile, &rp, &w, OutRGBA) == TBRM_OK;
     }
 
+    // Offscreen replacement of the M_Octree_Raymarch material pass over level OctreeVolumeMip; the pyramid is rebuilt
+    // when a rebuild was requested (new volume, SwitchRenderer(Octree)), as ARaymarchVolume::Tick does (:358-363).
+    int OctreeVolumeMip = 0; // RaymarchVolume.h: the level the octree material samples
+    bool bRequestedOctreeRebuild = true;
+    bool RenderOctree(const tbrm_camera& Camera, float* OutRGBA, int JitterFrame = -1)
+    {
+        if (!RaymarchResources.Handle) return false;
+        if (bRequestedOctreeRebuild) {
+            if (!URaymarchUtils::GenerateOctree(RaymarchResources)) return false;
+            bRequestedOctreeRebuild = false;
+        }
+        const tbrm_tile tile{0, 0, Camera.width, Camera.height, 1, 0};
+        const tbrm_raymarch_params rp{RaymarchingSteps, JitterFrame, 0, 0};
+        const tbrm_world_params w = WorldParameters.abi();
+        ++Stats.Frames;
+        return tbrm_raymarch_octree(RaymarchResources.Handle, &Camera, &tile, &rp, &w, OctreeVolumeMip, OutRGBA) == TBRM_OK;
+    }
+
     // What the cube mesh would show with the currently selected material (SwitchRenderer, :786-800).
     bool Render(const tbrm_camera& Camera, float* OutRGBA, int JitterFrame = -1)
     {
-        return SelectRaymarchMaterial == ERaymarchMaterial::Intensity ? RenderIntensity(Camera, OutRGBA, JitterFrame)
-                                                                        : RenderLit(Camera, OutRGBA, JitterFrame);
+        switch (SelectRaymarchMaterial) {
+            case ERaymarchMaterial::Intensity: return RenderIntensity(Camera, OutRGBA, JitterFrame);
+            case ERaymarchMaterial::Octree: return RenderOctree(Camera, OutRGBA, JitterFrame);
+            default: return RenderLit(Camera, OutRGBA, JitterFrame);
+        }
     }
 
     void FreeRaymarchResources() // :922-949

@@ -65,6 +65,9 @@ def load():
     lib.orc_clear_light_volume.argtypes = [P(Scene), f]
     lib.orc_raymarch_lit.argtypes = [P(Scene), P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp, P(C.c_uint64)]
     lib.orc_raymarch_intensity.argtypes = [P(Scene), P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp]
+    lib.orc_octree_dims.argtypes = [P(VolumeView), C.c_int, P(C.c_int32 * 3)]
+    lib.orc_generate_octree.argtypes = [P(VolumeView), P(vp * 4)]
+    lib.orc_raymarch_octree.argtypes = [P(Scene), vp, C.c_int, P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp]
     lib.orc_probe_sample_volume.restype = f
     lib.orc_probe_sample_volume.argtypes = [P(VolumeView), f, f, f, C.c_int, f]
     lib.orc_probe_windowed_tf.argtypes = [f, f, vp, P(abi.WindowingParams), P(f * 4)]
@@ -179,6 +182,32 @@ class OracleScene:
         self.lib.orc_raymarch_lit(C.byref(sc), C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
                                   depth_ptr, None if out is None else out.ctypes.data, C.byref(n))
         return out, int(n.value)
+
+    def generate_octree(self):
+        """-> list of 4 uint16 arrays [z, y, x] (GenerateOctreeShader.usf): mip 0 at power-of-two dimensions, then max-reduced."""
+        sc = self._scene()
+        mips = []
+        for m in range(4):
+            d = (C.c_int32 * 3)()
+            self.lib.orc_octree_dims(C.byref(sc.data), m, C.byref(d))
+            mips.append(np.zeros((d[2], d[1], d[0]), dtype=np.uint16))
+        ptrs = (C.c_void_p * 4)(*[m.ctypes.data for m in mips])
+        self.lib.orc_generate_octree(C.byref(sc.data), C.byref(ptrs))
+        self.octree = mips
+        return mips
+
+    def raymarch_octree(self, camera, tile, params, world, octree_mip, scene_depth=None):
+        sc = self._scene()
+        if not hasattr(self, "octree"):
+            self.generate_octree()
+        out = np.empty((tile.h, tile.w, 4), dtype=np.float32)
+        depth_ptr = None
+        if scene_depth is not None:
+            scene_depth = np.ascontiguousarray(scene_depth, dtype=np.float32)
+            depth_ptr = scene_depth.ctypes.data
+        self.lib.orc_raymarch_octree(C.byref(sc), self.octree[octree_mip].ctypes.data, int(octree_mip), C.byref(camera), C.byref(tile),
+                                     C.byref(params), C.byref(world), depth_ptr, out.ctypes.data)
+        return out
 
     def raymarch_intensity(self, camera, tile, params, world, scene_depth=None):
         sc = self._scene()

@@ -897,6 +897,124 @@ void orc_raymarch_intensity(const orc_scene* sc, const tbrm_camera* cam, const t
     }
 }
 
+/* ---- Octree render mode (ERaymarchMaterial::Octree) ------------------------------------------------------------------
+ * GenerateOctreeShader.usf:28-107 driven by OctreeShaders.cpp:28-54: a 4-mip UNORM16 render target whose base level has the
+ * volume's dimensions rounded up to powers of two (RaymarchVolume.cpp:873-877); mip 0 = Volume.Load(pos) * MinMaxValues.y
+ * with MinMaxValues = (0, 1) (OctreeShaders.h:49) — loads outside the volume return 0 —, mip m = the maximum of the 2x2x2
+ * texels of mip m-1 (:66-101). UNORM16 store: trunc(clamp(x, 0, 1) * 65535 + 0.5). */
+static inline int pow2_at_least(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline uint16_t encode_unorm16(float x)
+{
+    if (x != x) return 0;
+    x = fminf(fmaxf(x, 0.0f), 1.0f);
+    return (uint16_t) (x * 65535.0f + 0.5f);
+}
+void orc_octree_dims(const orc_volume_view* vol, int mip, int32_t out_dims[3])
+{
+    const int d[3] = {pow2_at_least(vol->dim_x), pow2_at_least(vol->dim_y), pow2_at_least(vol->dim_z)};
+    for (int c = 0; c < 3; ++c) { int v = d[c] >> mip; out_dims[c] = v < 1 ? 1 : v; }
+}
+void orc_generate_octree(const orc_volume_view* vol, uint16_t* const mips[4])
+{
+    int32_t d0[3];
+    orc_octree_dims(vol, 0, d0);
+#pragma omp parallel for
+    for (int z = 0; z < d0[2]; ++z)
+        for (int y = 0; y < d0[1]; ++y)
+            for (int x = 0; x < d0[0]; ++x) {
+                const int in = x < vol->dim_x && y < vol->dim_y && z < vol->dim_z;
+                const float v = in ? decode_voxel(vol->data, vol->format, ((size_t) z * vol->dim_y + y) * vol->dim_x + x) * 1.0f : 0.0f;
+                mips[0][((size_t) z * d0[1] + y) * d0[0] + x] = encode_unorm16(v);
+            }
+    for (int m = 1; m < 4; ++m) {
+        int32_t dl[3], dm[3];
+        orc_octree_dims(vol, m - 1, dl);
+        orc_octree_dims(vol, m, dm);
+#pragma omp parallel for
+        for (int z = 0; z < dm[2]; ++z)
+            for (int y = 0; y < dm[1]; ++y)
+                for (int x = 0; x < dm[0]; ++x) {
+                    uint16_t mx = 0; /* "float Max = 0" (:79) over UNORM values: the same order as over their codes */
+                    for (int c = 0; c < 2; ++c)
+                        for (int b = 0; b < 2; ++b)
+                            for (int a = 0; a < 2; ++a) {
+                                const int sx = 2 * x + a, sy = 2 * y + b, sz = 2 * z + c;
+                                if (sx < dl[0] && sy < dl[1] && sz < dl[2]) {
+                                    const uint16_t t = mips[m - 1][((size_t) sz * dl[1] + sy) * dl[0] + sx];
+                                    if (mx < t) mx = t;
+                                }
+                            }
+                    mips[m][((size_t) z * dm[1] + y) * dm[0] + x] = mx;
+                }
+    }
+}
+
+/* PerformWindowedRaymarchOctree (WindowedRaymarchMaterials.usf:99-183): the unlit march over one mip of the octree, point
+ * sampled with Load (SampleWindowedVolumeOctreeStep, WindowedSampling.usf:47-52; texels outside the mip read 0). */
+void orc_raymarch_octree(const orc_scene* sc, const uint16_t* mip, int octree_mip, const tbrm_camera* cam, const tbrm_tile* tile,
+                         const tbrm_raymarch_params* rp, const tbrm_world_params* world, const float* scene_depth, float* out_rgba)
+{
+    ray_consts rc;
+    make_ray_consts(cam, world, &rc);
+    int32_t d0[3], dm[3];
+    orc_octree_dims(&sc->data, 0, d0);
+    orc_octree_dims(&sc->data, octree_mip, dm);
+    const float ow = (float) dm[0], oh = (float) dm[1], od = (float) dm[2];
+    const float data_depth = (float) sc->data.dim_z, od0 = (float) d0[2];
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int j = 0; j < tile->h; ++j) {
+        const int py = tile_row(tile, j);
+        for (int i = 0; i < tile->w; ++i) {
+            const int px = tile->x0 + i;
+            float pos[3], thickness, lcv[3];
+            cube_setup(&rc, cam, px, py, scene_depth, pos, &thickness, lcv);
+            const float step_count = rp->steps;
+            const float step_size = 1 / step_count;             /* :113 */
+            const float actual = step_count * thickness;
+            const float fl = floorf(actual);
+            const int max_steps = (int) fl;
+            const float final_step = actual - fl;
+            const float sv[3] = {lcv[0] * step_size, lcv[1] * step_size, lcv[2] * step_size};
+            const float step_world = 100.0f * step_size;        /* :124 */
+            float le[4] = {0, 0, 0, 0};
+            if (rp->jitter_frame >= 0) {
+                uint32_t r[3];
+                rand3d_pcg16(px, py, rp->jitter_frame & 7, r);
+                const float rnd = (float) r[0] / 65535.0f;
+                for (int c = 0; c < 3; ++c) pos[c] = pos[c] - (sv[c] * rnd);
+            }
+            int k = 0;
+            for (k = 0; k <= max_steps; k++) {
+                float ss = step_world;
+                if (k < max_steps) {
+                    for (int c = 0; c < 3; ++c) pos[c] = pos[c] + sv[c];       /* :143 */
+                } else {
+                    if (!(final_step > 0.0f)) break;                            /* :169 */
+                    for (int c = 0; c < 3; ++c) pos[c] = pos[c] + (sv[c] * final_step);
+                    /* the fractional step still uses StepSizeWorld (:176), unlike the lit march */
+                }
+                if (is_clipped(pos, rc.cc, rc.cd)) continue;
+                /* int3 VoxelPos = float3(x * W, y * H, (z * DataDepth / OctreeDepth0) * OctreeDepth) (:150,:174): truncation */
+                const float fxp = pos[0] * ow, fyp = pos[1] * oh, fzp = ((pos[2] * data_depth) / od0) * od;
+                const int vx = (int) fxp, vy = (int) fyp, vz = (int) fzp;
+                float v = 0.0f;
+                if (fxp == fxp && fyp == fyp && fzp == fzp && vx >= 0 && vy >= 0 && vz >= 0 && vx < dm[0] && vy < dm[1] && vz < dm[2])
+                    v = (float) mip[((size_t) vz * dm[1] + vy) * dm[0] + vx] / 65535.0f;
+                float s[4];
+                sample_windowed_transfer_function(v, ss, sc->tf, &sc->windowing, s);
+                const float om = 1.0f - le[3];                                  /* AccumulateLightEnergy */
+                le[0] = le[0] + ((s[0] * s[3]) * om);
+                le[1] = le[1] + ((s[1] * s[3]) * om);
+                le[2] = le[2] + ((s[2] * s[3]) * om);
+                le[3] = le[3] + (s[3] * om);
+                if (k < max_steps && le[3] > 0.95f) { le[3] = 1.0f; break; }   /* :158-162 */
+            }
+            float* o = out_rgba + ((size_t) j * tile->w + i) * 4;
+            o[0] = le[0]; o[1] = le[1]; o[2] = le[2]; o[3] = le[3];
+        }
+    }
+}
+
 /* Single-sample probes used by the known-answer tests. */
 float orc_probe_sample_volume(const orc_volume_view* vol, float u, float v, float w, int mode, float border)
 {

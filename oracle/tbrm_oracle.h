@@ -61,6 +61,12 @@ void orc_raymarch_intensity(const orc_scene* sc, const tbrm_camera* cam, const t
                             const tbrm_raymarch_params* rp, const tbrm_world_params* world,
                             const float* scene_depth, float* out_rgba);
 
+/* the Octree render mode (ERaymarchMaterial::Octree): 4-mip UNORM16 max pyramid + its unlit, point-sampled march */
+void orc_octree_dims(const orc_volume_view* vol, int mip, int32_t out_dims[3]);
+void orc_generate_octree(const orc_volume_view* vol, uint16_t* const mips[4]);
+void orc_raymarch_octree(const orc_scene* sc, const uint16_t* mip, int octree_mip, const tbrm_camera* cam, const tbrm_tile* tile,
+                         const tbrm_raymarch_params* rp, const tbrm_world_params* world, const float* scene_depth, float* out_rgba);
+
 float orc_probe_sample_volume(const orc_volume_view* vol, float u, float v, float w, int mode, float border);
 void orc_probe_windowed_tf(float value, float step_size, const float* tf, const tbrm_windowing_params* wp, float out[4]);
 void orc_probe_ray_aabb(const float origin[3], const float dir[3], float out_t[2]);

@@ -110,6 +110,7 @@ SYMBOLS = [
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
     "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
+    "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
     "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
@@ -160,6 +161,11 @@ def load():
     lib.tbrm_raymarch_lit_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
     lib.tbrm_raymarch_intensity.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
     lib.tbrm_raymarch_intensity_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
+    lib.tbrm_generate_octree.argtypes = [vp]
+    lib.tbrm_octree_mip_dims.argtypes = [vp, C.c_int, P(C.c_int32 * 3)]
+    lib.tbrm_download_octree_mip.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    lib.tbrm_raymarch_octree.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), C.c_int, vp]
+    lib.tbrm_raymarch_octree_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), C.c_int, vp, vp]
     lib.tbrm_count_nominal_samples.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), P(C.c_uint64)]
     lib.tbrm_download_light_volume.argtypes = [vp, vp, C.c_size_t]
     lib.tbrm_upload_light_volume.argtypes = [vp, vp, C.c_size_t]
@@ -353,6 +359,25 @@ class Resources:
     def raymarch_intensity_device(self, camera, tile, params, world, out_ptr, depth_ptr=None):
         check(self.lib.tbrm_raymarch_intensity_device(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
                                                       C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
+
+    def generate_octree(self):
+        check(self.lib.tbrm_generate_octree(self.handle))
+
+    def octree_mip_dims(self, mip):
+        d = (C.c_int32 * 3)()
+        check(self.lib.tbrm_octree_mip_dims(self.handle, int(mip), C.byref(d)))
+        return tuple(d[:])
+
+    def download_octree_mip(self, mip):
+        d = self.octree_mip_dims(mip)
+        out = np.empty(d[::-1], dtype=np.uint16)
+        check(self.lib.tbrm_download_octree_mip(self.handle, int(mip), out.ctypes.data, out.nbytes))
+        return out
+
+    def raymarch_octree(self, camera, tile, params, world, octree_mip):
+        out = np.empty((tile.h, tile.w, 4), dtype=np.float32)
+        check(self.lib.tbrm_raymarch_octree(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world), int(octree_mip), out.ctypes.data))
+        return out
 
     def count_nominal_samples(self, camera, tile, params, world):
         n = C.c_uint64(0)

@@ -91,6 +91,11 @@ struct tbrm_resources {
     int* d_alpha_prefix = nullptr;
     bool minmax_valid = false, empty_valid = false;
 
+    // Octree render mode: 4-level UNORM16 max pyramid (allocated by the first tbrm_generate_octree)
+    uint16_t* d_octree[4]{};
+    int oct_dims[4][3]{};
+    bool octree_valid = false;
+
     unsigned long long* d_counter = nullptr;
     float* d_out = nullptr; // staging for the host-pointer raymarch variant
     size_t out_bytes = 0;
@@ -657,6 +662,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     (void) hipFree(r->d_occ_list);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
+    for (uint16_t* o : r->d_octree) (void) hipFree(o);
     for (uint8_t* d : r->d_dist) (void) hipFree(d);
     (void) hipFree(r->d_alpha_prefix);
     (void) hipFree(r->d_counter);
@@ -692,6 +698,7 @@ int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_byte
     (void) hipFree(staging);
     HIP_TRY(e1);
     r->has_volume = true;
+    r->octree_valid = false;
     r->minmax_valid = false;
     return TBRM_OK;
 }
@@ -705,6 +712,7 @@ int tbrm_upload_volume_device(tbrm_resources* r, const void* device_voxels, size
     HIP_TRY(launch_relayout(relayout_params(device_voxels, r->d_data, dims, r->dbn, format_bytes(r->desc.data_format), true), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->has_volume = true;
+    r->octree_valid = false;
     r->minmax_valid = false;
     return TBRM_OK;
 }
@@ -866,6 +874,93 @@ int tbrm_raymarch_intensity(tbrm_resources* r, const tbrm_camera* cam, const tbr
         r->out_bytes = bytes;
     }
     if (int e = tbrm_raymarch_intensity_device(r, cam, tile, rp, world, nullptr, r->d_out)) return e;
+    HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
+int tbrm_octree_mip_dims(const tbrm_resources* r, int mip, int32_t out_dims[3])
+{
+    if (!r || !out_dims || mip < 0 || mip > 3) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
+    const int d[3] = {r->desc.dim_x, r->desc.dim_y, r->desc.dim_z};
+    for (int c = 0; c < 3; ++c) {
+        int p2 = 1;
+        while (p2 < d[c]) p2 <<= 1; // FMath::RoundUpToPowerOfTwo (RaymarchVolume.cpp:876-877)
+        out_dims[c] = std::max(p2 >> mip, 1);
+    }
+    return TBRM_OK;
+}
+
+int tbrm_generate_octree(tbrm_resources* r)
+{
+    if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!r->has_volume) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume");
+    if (int e = bind(r)) return e;
+    for (int m = 0; m < 4; ++m) {
+        int32_t d[3];
+        (void) tbrm_octree_mip_dims(r, m, d);
+        for (int c = 0; c < 3; ++c) r->oct_dims[m][c] = d[c];
+        if (!r->d_octree[m]) HIP_TRY(hipMalloc((void**) &r->d_octree[m], (size_t) d[0] * d[1] * d[2] * sizeof(uint16_t)));
+        OctreeParams op{};
+        op.data = data_view(r);
+        op.lower = m ? r->d_octree[m - 1] : nullptr;
+        for (int c = 0; c < 3; ++c) { op.dims[c] = d[c]; op.lower_dims[c] = m ? r->oct_dims[m - 1][c] : 0; }
+        op.out = r->d_octree[m];
+        HIP_TRY(launch_octree_level(op, m == 0, r->stream));
+    }
+    r->octree_valid = true;
+    return TBRM_OK;
+}
+
+int tbrm_download_octree_mip(tbrm_resources* r, int mip, uint16_t* host_out, size_t bytes)
+{
+    if (!r || !host_out || mip < 0 || mip > 3) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
+    if (!r->octree_valid) return fail(TBRM_ERR_NOT_INITIALIZED, "no octree: call tbrm_generate_octree after uploading the volume");
+    if (int e = bind(r)) return e;
+    const size_t need = (size_t) r->oct_dims[mip][0] * r->oct_dims[mip][1] * r->oct_dims[mip][2] * sizeof(uint16_t);
+    if (bytes != need) return fail(TBRM_ERR_INVALID_ARG, "octree level %d is %zu bytes, got %zu", mip, need, bytes);
+    HIP_TRY(hipMemcpyAsync(host_out, r->d_octree[mip], need, hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return TBRM_OK;
+}
+
+int tbrm_raymarch_octree_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                                const tbrm_world_params* world, int octree_mip, const float* device_scene_depth, float* device_out_rgba)
+{
+    if (!r || !cam || !tile || !rp || !world || !device_out_rgba || octree_mip < 0 || octree_mip > 3) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
+    if (!r->has_volume || !r->has_tf) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
+    if (!r->octree_valid) return fail(TBRM_ERR_NOT_INITIALIZED, "no octree: call tbrm_generate_octree after uploading the volume");
+    if (int e = bind(r)) return e;
+    RayParams p;
+    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
+    p.depth = device_scene_depth;
+    p.out = device_out_rgba;
+    p.octree = r->d_octree[octree_mip];
+    for (int c = 0; c < 3; ++c) p.oct_dims[c] = r->oct_dims[octree_mip][c];
+    p.oct_depth0 = (float) r->oct_dims[0][2];
+    if (int e = begin_timed(r, 1)) return e;
+    HIP_TRY(launch_raymarch_octree(p, r->stream));
+    ++r->launches[2];
+    return end_timed(r, 1);
+}
+
+int tbrm_raymarch_octree(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                         const tbrm_world_params* world, int octree_mip, float* host_out_rgba)
+{
+    if (!r || !tile || !host_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (tile->w < 0 || tile->h < 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile size");
+    const size_t bytes = (size_t) tile->w * tile->h * 4 * sizeof(float);
+    if (bytes == 0) return TBRM_OK;
+    if (int e = bind(r)) return e;
+    if (bytes > r->out_bytes) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->d_out);
+        r->d_out = nullptr;
+        r->out_bytes = 0;
+        HIP_TRY(hipMalloc((void**) &r->d_out, bytes));
+        r->out_bytes = bytes;
+    }
+    if (int e = tbrm_raymarch_octree_device(r, cam, tile, rp, world, octree_mip, nullptr, r->d_out)) return e;
     HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return TBRM_OK;

@@ -135,6 +135,9 @@ struct RayParams {
     const uint8_t* skip_dist;   // per brick: Chebyshev distance (bricks, capped) to the nearest non-empty brick; null when skipping is off
     int bnx, bny, bnz;  // brick grid
     unsigned long long* sample_counter; // count kernel only
+    const uint16_t* octree;     // octree march only: the level marched (dense, x fastest)
+    int oct_dims[3];            // its dimensions
+    float oct_depth0;           // depth of octree level 0 (the z coordinate is rescaled by data depth / this)
 };
 
 struct BrickParams {
@@ -159,6 +162,14 @@ struct DistParams {
     uint8_t* out;
     int bn[3];
     int axis;
+};
+
+struct OctreeParams {
+    VolumeDev data;        // level 0: the bricked data volume
+    const uint16_t* lower; // levels 1..3: the level below
+    int lower_dims[3];
+    uint16_t* out;
+    int dims[3];
 };
 
 struct RelayoutParams {
@@ -188,6 +199,8 @@ hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s)
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
 hipError_t launch_raymarch_intensity(const RayParams& p, hipStream_t s);
+hipError_t launch_raymarch_octree(const RayParams& p, hipStream_t s);
+hipError_t launch_octree_level(const OctreeParams& p, bool base, hipStream_t s);
 hipError_t launch_count_samples(const RayParams& p, hipStream_t s);
 hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s);
 hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s);

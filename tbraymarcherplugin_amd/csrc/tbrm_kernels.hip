@@ -399,6 +399,110 @@ hipError_t launch_raymarch_intensity(const RayParams& p, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- Octree render mode (experimental in the reference) -------------------------------------------------------------
+// GenerateOctreeShader.usf:28-107: level 0 = the volume (x MinMaxValues.y = 1, OctreeShaders.h:49) as UNORM16, 0 outside the
+// volume; level m = max over the 2x2x2 texels of level m-1. One thread per output texel (the reference runs one thread
+// per 8^3 leaf, [numthreads(1,1,1)]).
+template <int DFMT>
+__global__ __launch_bounds__(256) void k_octree_base(const OctreeParams p)
+{
+    const size_t n = (size_t) p.dims[0] * p.dims[1] * p.dims[2];
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int) (i % p.dims[0]), y = (int) ((i / p.dims[0]) % p.dims[1]), z = (int) (i / ((size_t) p.dims[0] * p.dims[1]));
+    float v = 0.0f;
+    if (x < p.data.nx && y < p.data.ny && z < p.data.nz) v = load_voxel<DFMT>(p.data.data, brick_off(x, y, z, p.data.bnx, p.data.bnxy)) * 1.0f;
+    p.out[i] = (uint16_t) __builtin_floorf(__builtin_amdgcn_fmed3f(v, 0.0f, 1.0f) * 65535.0f + 0.5f); // UNORM16 store, NaN -> 0
+}
+__global__ __launch_bounds__(256) void k_octree_reduce(const OctreeParams p)
+{
+    const size_t n = (size_t) p.dims[0] * p.dims[1] * p.dims[2];
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int) (i % p.dims[0]), y = (int) ((i / p.dims[0]) % p.dims[1]), z = (int) (i / ((size_t) p.dims[0] * p.dims[1]));
+    uint32_t mx = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int sx = 2 * x + (k & 1), sy = 2 * y + ((k >> 1) & 1), sz = 2 * z + (k >> 2);
+        if (sx < p.lower_dims[0] && sy < p.lower_dims[1] && sz < p.lower_dims[2])
+            mx = max(mx, (uint32_t) p.lower[((size_t) sz * p.lower_dims[1] + sy) * p.lower_dims[0] + sx]);
+    }
+    p.out[i] = (uint16_t) mx;
+}
+hipError_t launch_octree_level(const OctreeParams& p, bool base, hipStream_t s)
+{
+    const size_t n = (size_t) p.dims[0] * p.dims[1] * p.dims[2];
+    const dim3 grid((unsigned) ((n + 255) / 256)), block(256);
+    if (!base) hipLaunchKernelGGL(k_octree_reduce, grid, block, 0, s, p);
+    else if (p.data.fmt == FMT_U8) hipLaunchKernelGGL(k_octree_base<FMT_U8>, grid, block, 0, s, p);
+    else if (p.data.fmt == FMT_U16) hipLaunchKernelGGL(k_octree_base<FMT_U16>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_octree_base<FMT_F32>, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
+// PerformWindowedRaymarchOctree (WindowedRaymarchMaterials.usf:99-183): unlit, point-sampled march over one octree level.
+__global__ __launch_bounds__(256) void k_raymarch_octree(const RayParams p)
+{
+    __shared__ float4 s_tf[256];
+    s_tf[threadIdx.x] = p.tf[threadIdx.x];
+    __syncthreads();
+    int i, j, px, py;
+    if (!tile_pixel(p, i, j, px, py)) return;
+    Ray ray;
+    cube_setup(p, px, py, ray);
+    const float step_size = 1 / p.steps;
+    const float actual = p.steps * ray.thickness;
+    const float fl = floorf(actual);
+    const int max_steps = (int) fl;
+    const float final_step = actual - fl;
+    const float sv0 = ray.lcv[0] * step_size, sv1 = ray.lcv[1] * step_size, sv2 = ray.lcv[2] * step_size;
+    const float step_world = 100.0f * step_size;
+    float pos0 = ray.pos[0], pos1 = ray.pos[1], pos2 = ray.pos[2];
+    if (p.jitter_frame >= 0) {
+        uint32_t rr;
+        rand3d_pcg16(px, py, p.jitter_frame & 7, rr);
+        const float rnd = (float) rr / 65535.0f;
+        pos0 = pos0 - (sv0 * rnd); pos1 = pos1 - (sv1 * rnd); pos2 = pos2 - (sv2 * rnd);
+    }
+    const float ow = (float) p.oct_dims[0], oh = (float) p.oct_dims[1], od = (float) p.oct_dims[2], data_depth = (float) p.data.nz;
+    float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f;
+    for (int k = 0; k <= max_steps; ++k) {
+        if (k < max_steps) { pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2; }
+        else {
+            if (!(final_step > 0.0f)) break;
+            pos0 = pos0 + (sv0 * final_step); pos1 = pos1 + (sv1 * final_step); pos2 = pos2 + (sv2 * final_step);
+        }
+        if (p.clip_mode && is_clipped(pos0, pos1, pos2, p.cc, p.cd)) continue;
+        // int3 VoxelPos = float3(x * W, y * H, (z * DataDepth / OctreeDepth0) * OctreeDepth) (:150): truncation; Load outside -> 0
+        const float fx = pos0 * ow, fy = pos1 * oh, fz = ((pos2 * data_depth) / p.oct_depth0) * od;
+        float v = 0.0f;
+        if (fx == fx && fy == fy && fz == fz && fx > -1.0f && fy > -1.0f && fz > -1.0f && fx < ow && fy < oh && fz < od) {
+            const int vx = (int) fx, vy = (int) fy, vz = (int) fz;
+            v = decode_u16(p.octree[((size_t) vz * p.oct_dims[1] + vy) * p.oct_dims[0] + vx]);
+        }
+        // SampleWindowedTransferFunction with StepSizeWorld — also in the fractional step (:176), unlike the lit march
+        const float tpos = tf_position(v, p.win.center, p.win.width);
+        if ((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f)) continue;
+        const float4 cs = sample_tf(s_tf, tpos);
+        const float a_sat = saturate_(cs.w);
+        const float a = 1.0f - pow_(1.0f - a_sat, step_world);
+        const float om = 1.0f - le3; // AccumulateLightEnergy
+        le0 = le0 + ((cs.x * a) * om);
+        le1 = le1 + ((cs.y * a) * om);
+        le2 = le2 + ((cs.z * a) * om);
+        le3 = le3 + (a * om);
+        if (k < max_steps && le3 > 0.95f) { le3 = 1.0f; break; }
+    }
+    reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
+}
+hipError_t launch_raymarch_octree(const RayParams& p, hipStream_t s)
+{
+    if (p.tile_w <= 0 || p.tile_h <= 0) return hipSuccess;
+    const dim3 grid((p.tile_w + 15) / 16, (p.tile_h + 15) / 16), block(256);
+    hipLaunchKernelGGL(k_raymarch_octree, grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
 // Nominal samples: sum over rays of floor(Steps*thickness) + [frac > 0].
 __global__ __launch_bounds__(256) void k_count_samples(const RayParams p)
 {

@@ -84,6 +84,13 @@ int main(int argc, char** argv)
     double hit = 0, sum_i = 0;
     for (size_t i = 0; i < img.size(); i += 4) { hit += img[i + 3]; sum_i += img[i]; }
     std::printf("intensity hit_fraction=%.6f mean_intensity_of_hits=%.6f\n", hit / (64 * 64), hit > 0 ? sum_i / hit : 0.0);
+    // SwitchRenderer(Octree): rebuilds the pyramid on the next frame, marches level OctreeVolumeMip unlit
+    volume.SwitchRenderer(tbrm_plugin::ERaymarchMaterial::Octree);
+    volume.OctreeVolumeMip = 1;
+    if (!volume.Render(cam, img.data())) { std::printf("error=%s\n", tbrm_last_error()); return 5; }
+    double oct_a = 0;
+    for (size_t i = 3; i < img.size(); i += 4) oct_a += img[i];
+    std::printf("octree mean_alpha=%.6f rebuild_pending=%d\n", oct_a / (64 * 64), volume.bRequestedOctreeRebuild ? 1 : 0);
     volume.SwitchRenderer(tbrm_plugin::ERaymarchMaterial::Lit);
     uint64_t counters[3];
     tbrm_launch_counters(volume.RaymarchResources.Handle, counters);

@@ -36,4 +36,6 @@ def test_facade_tick_policy_on_gpu(tmp_path, gpu):
     hit = float(lines["intensity"].split("hit_fraction=")[1].split()[0])
     grey = float(lines["intensity"].split("mean_intensity_of_hits=")[1].split()[0])
     assert 0.05 < hit < 1.0 and 0.0 <= grey <= 1.0                       # SwitchRenderer(Intensity): the slice view
-    assert "slice=0" in lines["launches"] and "raymarch=2" in lines["launches"]  # one lit + one intensity frame
+    oct_a = float(lines["octree"].split("mean_alpha=")[1].split()[0])
+    assert 0.01 < oct_a < 0.95 and "rebuild_pending=0" in lines["octree"]  # SwitchRenderer(Octree): pyramid built, level 1 marched
+    assert "slice=0" in lines["launches"] and "raymarch=3" in lines["launches"]  # one lit + one intensity + one octree frame

@@ -356,3 +356,33 @@ def test_random_lights_and_shapes_against_oracle(gpu, oracle_mod):
             assert_light_equal(res, orc)
             c = res.launch_counters()
             assert c["chunk"] > 0
+
+
+@pytest.mark.parametrize("dtype,dims", [(np.uint16, (20, 12, 9)), (np.uint8, (33, 40, 17)), (np.float32, (16, 16, 16))])
+def test_octree_pyramid_and_march_match_oracle(gpu, oracle_mod, dtype, dims):
+    """The Octree render mode: the 4-level UNORM16 max pyramid is bit-exact, the unlit point-sampled march over every
+    level matches the oracle (clip plane, jitter and fractional last step included)."""
+    res, orc = make_pair(gpu, oracle_mod, dims, dtype, tf="A", window=(0.5, 0.9, True, False))
+    world = abi.make_world(abi.identity_transform(scale=(100.0, 90.0, 110.0), rotation=(0.0, 0.2588190, 0.0, 0.9659258)),
+                           clip_center=(8.0, 0.0, 0.0), clip_direction=(0.6, 0.3, 0.74))
+    with res:
+        with pytest.raises(abi.TbrmError):
+            res.download_octree_mip(0)  # not generated yet
+        res.generate_octree()
+        ref_mips = orc.generate_octree()
+        for m in range(4):
+            assert res.octree_mip_dims(m) == ref_mips[m].shape[::-1]
+            assert np.array_equal(res.download_octree_mip(m), ref_mips[m])
+        cam = S.default_camera(56, 40)
+        tile = abi.Tile(0, 0, 56, 40)
+        for mip in range(4):
+            for steps, jitter in ((48.0, -1), (21.5, 3)):
+                rp = abi.RaymarchParams(steps, jitter, True)
+                got = res.raymarch_octree(cam, tile, rp, world, mip)
+                ref = orc.raymarch_octree(cam, tile, rp, world, mip)
+                assert np.abs(got - ref).max() <= TIGHT_TOL, (mip, steps, jitter)
+        assert ref[..., 3].max() > 0.2
+        # a new volume invalidates the pyramid
+        res.upload_volume(small_volume(dims, dtype, 0x5EED0777))
+        with pytest.raises(abi.TbrmError):
+            res.raymarch_octree(cam, tile, abi.RaymarchParams(16.0, -1, True), world, 0)

@@ -250,3 +250,41 @@ def test_intensity_renderer_known_answers(oracle_mod):
     img = orc.raymarch_intensity(wide, abi.Tile(0, 0, 32, 32), abi.RaymarchParams(steps, -1, False), world)
     assert (img[..., 3] == 0).any() and (img[..., 3] == 1).any()
     assert set(np.unique(img[..., 3])) <= {0.0, 1.0} and img[..., 0].min() >= 0.0 and img[..., 0].max() <= 1.0
+
+
+def test_octree_pyramid_known_answers(oracle_mod):
+    """GenerateOctreeShader.usf: level 0 = the volume as UNORM16 at power-of-two dimensions (0 outside the volume), level
+    m = the 2x2x2 maximum of level m-1 — checked against numpy block maxima; and the unlit octree march over a level
+    whose texels are all equal accumulates the homogeneous-medium closed form."""
+    rng = np.random.default_rng(5)
+    vol = rng.integers(0, 65536, size=(20, 12, 9), dtype=np.uint16)  # z, y, x: none a power of two
+    orc = oracle_mod.OracleScene(vol)
+    mips = orc.generate_octree()
+    assert [m.shape for m in mips] == [(32, 16, 16), (16, 8, 8), (8, 4, 4), (4, 2, 2)]
+    base = np.zeros((32, 16, 16), dtype=np.uint16)
+    base[:20, :12, :9] = vol
+    assert np.array_equal(mips[0], base)
+    ref = base
+    for m in range(1, 4):
+        z, y, x = ref.shape
+        ref = ref.reshape(z // 2, 2, y // 2, 2, x // 2, 2).max(axis=(1, 3, 5))
+        assert np.array_equal(mips[m], ref)
+    # u8 and float inputs land on the UNORM16 grid the same way the render target would store them
+    u8 = rng.integers(0, 256, size=(8, 8, 8), dtype=np.uint8)
+    assert np.array_equal(oracle_mod.OracleScene(u8).generate_octree()[0], u8.astype(np.uint16) * 257)
+    f = np.array([[[-0.5, 0.0, 0.25, 1.0], [2.0, 0.5, 1e-6, 0.999999]]], dtype=np.float32)
+    want = np.trunc(np.clip(f, 0, 1) * np.float32(65535) + np.float32(0.5)).astype(np.uint16)
+    assert np.array_equal(oracle_mod.OracleScene(f).generate_octree()[0][:1, :2, :4], want)
+
+    # homogeneous medium through the octree march: A = 1 - (1-a)^100 for a ray of thickness 1, any level
+    vol = np.full((16, 16, 16), 0.5, dtype=np.float32)
+    orc = oracle_mod.OracleScene(vol, light_32bit=True)
+    a16 = float(np.float32(np.float16(0.02)))
+    orc.set_tf_lut(const_tf((0.25, 0.5, 1.0), 0.02))
+    world = S.default_world()
+    cam = abi.look_at_camera((-300.0, 0.0, 0.0), (0, 0, 0), (0, 0, 1), 60.0, 1, 1)
+    want_a = 1 - (1 - a16) ** 100
+    for mip in (0, 2):
+        img = orc.raymarch_octree(cam, abi.Tile(0, 0, 1, 1), abi.RaymarchParams(50.0, -1, False), world, mip)
+        assert img[0, 0, 3] == pytest.approx(want_a, abs=2e-5)
+        assert img[0, 0, :3] == pytest.approx(np.array([0.25, 0.5, 1.0]) * want_a, abs=2e-5)
