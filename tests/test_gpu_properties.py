@@ -175,3 +175,47 @@ def test_light_parallel_reset_on_device(gpu):
     finally:
         for res in handles:
             res.close()
+
+
+def test_full_size_properties_at_config3(gpu, monkeypatch):
+    """BASELINE config 3 at full size (512^3 UNORM16, 1024^2 frame, 512 steps), where the oracle would take minutes: the
+    production chunk kernels and the reference-structured slice kernel leave the same light volume bit for bit after four
+    Adds and a fused Change; empty-space skipping / leaping does not change a single pixel; interleaved row-group tiles
+    reassemble the frame; an Add followed by its removal returns the light volume to within one UNORM8 code."""
+    world = S.default_world()
+    new1 = abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1])
+    volumes = []
+    for variant in ("chunk", "slice"):
+        if variant == "slice":
+            monkeypatch.setenv("TBRM_FORCE_SLICE_KERNEL", "1")
+        else:
+            monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+        with make(gpu, 512) as res:
+            for i in range(4):
+                res.add_dir_light(S.light(i), True, world)
+            res.change_dir_light(S.light(1), new1, world)
+            volumes.append(res.download_light_volume())
+            if variant == "chunk":
+                cam = S.default_camera(1024, 1024)
+                full_tile = abi.Tile(0, 0, 1024, 1024)
+                a = res.raymarch_lit(cam, full_tile, abi.RaymarchParams(512.0, -1, False), world)
+                b = res.raymarch_lit(cam, full_tile, abi.RaymarchParams(512.0, -1, True), world)
+                assert np.array_equal(a, b), "skipping / leaping changed the frame"
+                assert (b[..., 3] == 1.0).any() and (b[..., 3] == 0.0).any()
+                parts = np.stack([res.raymarch_lit(cam, sharding.rank_tile(1024, 1024, r, 8), abi.RaymarchParams(512.0, -1, True), world)
+                                  for r in range(8)])
+                assert np.array_equal(sharding.assemble(parts, 1024, 8), b)
+                # add a fifth light and take it away again: the same stream is added and subtracted, so apart from voxels that
+                # saturated the UNORM8 light volume returns to within one code (Q(Q(p + x) - x) = p except at fp32 near-ties)
+                before = res.download_light_volume()
+                extra = abi.DirLightParams((0.2, -0.7, 0.4), 0.15)
+                res.add_dir_light(extra, True, world)
+                lit = res.download_light_volume()
+                res.add_dir_light(extra, False, world)
+                after = res.download_light_volume()
+                unsaturated = lit < 255
+                assert (lit.astype(np.int32) >= before).all() and (lit != before).any()
+                d = np.abs(after[unsaturated].astype(np.int32) - before[unsaturated])
+                assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+    assert np.array_equal(volumes[0], volumes[1]), f"{np.count_nonzero(volumes[0] != volumes[1])} voxels differ between the chunk and the slice kernels"
