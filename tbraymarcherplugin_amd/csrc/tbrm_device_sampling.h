@@ -89,10 +89,10 @@ __device__ __forceinline__ TapOffsets tap_offsets(const VolumeDev& v, int ix, in
     const int x0 = address<MODE>(ix, v.nx), y0 = address<MODE>(iy, v.ny), z0 = address<MODE>(iz, v.nz);
     int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
     if constexpr (MODE == ADDR_WRAP) { x1 = x1 == v.nx ? 0 : x1; y1 = y1 == v.ny ? 0 : y1; z1 = z1 == v.nz ? 0 : z1; }
-    else {
-        x1 = ix + 1 < 0 ? 0 : (x1 >= v.nx ? v.nx - 1 : x1);
-        y1 = iy + 1 < 0 ? 0 : (y1 >= v.ny ? v.ny - 1 : y1);
-        z1 = iz + 1 < 0 ? 0 : (z1 >= v.nz ? v.nz - 1 : z1);
+    else { // clamp: the +1 tap clamps on its own (a base tap of -1 and its +1 tap are BOTH texel 0)
+        x1 = clamp_index(ix + 1, v.nx);
+        y1 = clamp_index(iy + 1, v.ny);
+        z1 = clamp_index(iz + 1, v.nz);
     }
     TapOffsets t;
     t.x0 = brick_off_x(x0); t.x1 = brick_off_x(x1);

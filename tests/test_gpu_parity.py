@@ -386,3 +386,42 @@ def test_octree_pyramid_and_march_match_oracle(gpu, oracle_mod, dtype, dims):
         res.upload_volume(small_volume(dims, dtype, 0x5EED0777))
         with pytest.raises(abi.TbrmError):
             res.raymarch_octree(cam, tile, abi.RaymarchParams(16.0, -1, True), world, 0)
+
+
+@pytest.mark.parametrize("addr", [abi.ADDRESS_WRAP, abi.ADDRESS_CLAMP])
+def test_random_cameras_windows_and_modes_against_oracle(gpu, oracle_mod, ray_lanes, addr):
+    """Seeded sweep of the three render modes over cameras the default view never produces — inside the cube, grazing a face,
+    axis-parallel (1/dir = inf in the slab test), far away, narrow and wide fields of view — with random windows, cutoffs,
+    clip planes, step counts and jitter frames, on a volume whose sides are no multiple of a brick. (This sweep caught the
+    +1 tap of a clamped base tap of -1 being texel 1 instead of texel 0: samples in the outer half-texel shell.)"""
+    rng = np.random.default_rng(77)
+    dims = (45, 38, 52)
+    res, orc = make_pair(gpu, oracle_mod, dims, np.uint16, seed=0x5EED0300, addr=addr)
+    eyes = [(-145, -95, 80), (10, 5, -8), (0, 0, 0), (-49.9, 20, 10), (-300, 0, 0), (0, 0, 400), (55, -300, 0.001), (-60, -60, -60), (35, 260, -140)]
+    with res:
+        world0 = S.default_world()
+        for o in (res, orc):
+            o.add_dir_light(S.light(0), True, world0)
+            o.add_dir_light(S.light(3), True, world0)
+        orc.generate_octree()
+        res.generate_octree()
+        worst = 0.0
+        for k, eye in enumerate(eyes):
+            target = (0.0, 0.0, 0.0) if k != 2 else (30.0, 12.0, -7.0)
+            up = (0.0, 0.0, 1.0) if abs(eye[0]) + abs(eye[1]) > 1e-3 else (0.0, 1.0, 0.0)
+            cam = abi.look_at_camera(eye, target, up, float(rng.choice([20.0, 60.0, 110.0])), 48, 40)
+            world = world0 if k % 3 else abi.make_world(
+                abi.identity_transform(scale=(100.0, 100.0, 100.0)), clip_center=tuple(rng.uniform(-30, 30, 3)), clip_direction=tuple(rng.normal(size=3)))
+            win = abi.WindowingParams(float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.2, 1.2)), bool(rng.integers(2)), bool(rng.integers(2)))
+            res.set_windowing(win)
+            orc.set_windowing(win)
+            tile = abi.Tile(int(rng.integers(0, 8)), int(rng.integers(0, 8)), 37, 29)
+            rp = abi.RaymarchParams(float(rng.uniform(3.0, 90.0)), int(rng.integers(-1, 8)), True)
+            got, (ref, n_ref) = res.raymarch_lit(cam, tile, rp, world), orc.raymarch_lit(cam, tile, rp, world)
+            assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
+            worst = max(worst, float(np.abs(got - ref).max()))
+            assert np.array_equal(got, res.raymarch_lit(cam, tile, abi.RaymarchParams(rp.steps, rp.jitter_frame, False), world))
+            worst = max(worst, float(np.abs(res.raymarch_intensity(cam, tile, rp, world) - orc.raymarch_intensity(cam, tile, rp, world)).max()))
+            mip = int(rng.integers(0, 4))
+            worst = max(worst, float(np.abs(res.raymarch_octree(cam, tile, rp, world, mip) - orc.raymarch_octree(cam, tile, rp, world, mip)).max()))
+        assert worst <= TIGHT_TOL
