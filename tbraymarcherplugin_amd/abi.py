@@ -102,6 +102,16 @@ class LightPass(C.Structure):
                 "start": self.start, "stop": self.stop, "dir": self.dir}
 
 
+class Slab(C.Structure):  # tbrm_slab: the light-volume z range a handle owns
+    _fields_ = [("z_begin", C.c_int32), ("z_end", C.c_int32)]
+
+
+class SlabPass(C.Structure):  # tbrm_slab_pass
+    _fields_ = [("axis", C.c_int32), ("dir", C.c_int32), ("lateral", C.c_int32), ("streams", C.c_int32),
+                ("plane_w", C.c_int32), ("plane_h", C.c_int32), ("chunk_slices", C.c_int32), ("chunks_of_pass", C.c_int32),
+                ("first_chunk", C.c_int32), ("n_chunks", C.c_int32), ("halo_rows", C.c_int32)]
+
+
 # every symbol include/tbrm.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     "tbrm_version", "tbrm_last_error", "tbrm_device_count",
@@ -109,6 +119,7 @@ SYMBOLS = [
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
     "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
+    "tbrm_slab_light_begin", "tbrm_slab_pass_begin", "tbrm_slab_pass_chunk", "tbrm_slab_pass_plane",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
@@ -157,6 +168,10 @@ def load():
     lib.tbrm_add_dir_light.argtypes = [vp, P(DirLightParams), C.c_int, P(WorldParams), P(C.c_int), C.c_int]
     lib.tbrm_change_dir_light.argtypes = [vp, P(DirLightParams), P(DirLightParams), P(WorldParams), P(C.c_int)]
     lib.tbrm_clear_light_volume.argtypes = [vp, C.c_float]
+    lib.tbrm_slab_light_begin.argtypes = [vp, P(DirLightParams), P(DirLightParams), C.c_int, P(WorldParams), P(Slab), P(C.c_int32)]
+    lib.tbrm_slab_pass_begin.argtypes = [vp, C.c_int32, P(SlabPass)]
+    lib.tbrm_slab_pass_chunk.argtypes = [vp, C.c_int32]
+    lib.tbrm_slab_pass_plane.argtypes = [vp, C.c_int32, C.c_int32, P(vp)]
     lib.tbrm_raymarch_lit.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
     lib.tbrm_raymarch_lit_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
     lib.tbrm_raymarch_intensity.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
@@ -341,6 +356,26 @@ class Resources:
 
     def clear_light_volume(self, value=0.0):
         check(self.lib.tbrm_clear_light_volume(self.handle, float(value)))
+
+    # slab-partitioned illumination (tbrm.h "slabs"; driver: slabs.py)
+    def slab_light_begin(self, removed, light, added, world, slab):
+        n = C.c_int32(0)
+        check(self.lib.tbrm_slab_light_begin(self.handle, C.byref(removed) if removed is not None else None, C.byref(light),
+                                             int(bool(added)), C.byref(world), C.byref(slab), C.byref(n)))
+        return int(n.value)
+
+    def slab_pass_begin(self, index):
+        out = SlabPass()
+        check(self.lib.tbrm_slab_pass_begin(self.handle, int(index), C.byref(out)))
+        return out
+
+    def slab_pass_chunk(self, chunk):
+        check(self.lib.tbrm_slab_pass_chunk(self.handle, int(chunk)))
+
+    def slab_pass_plane(self, boundary, stream):
+        p = C.c_void_p()
+        check(self.lib.tbrm_slab_pass_plane(self.handle, int(boundary), int(stream), C.byref(p)))
+        return p.value
 
     def raymarch_lit(self, camera, tile, params, world):
         out = np.empty((tile.h, tile.w, 4), dtype=np.float32)

@@ -100,6 +100,8 @@ struct tbrm_resources {
     float* d_out = nullptr; // staging for the host-pointer raymarch variant
     size_t out_bytes = 0;
 
+    struct SlabOp* slab_op = nullptr; // the slab-partitioned light operation in flight (tbrm_slab_*)
+
     hipEvent_t ev[2][2]{};
     bool ev_valid[2]{};
     uint64_t launches[3]{}; // chunk, slice, raymarch
@@ -243,23 +245,49 @@ void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt)
     s.init_value = through_light_format(lv_fmt, p.light_alpha); // Clear2DTexture of the read/write buffers
 }
 
-// Runs one axis pass (Add: stream a only; Change: a = added, r = removed) with the chunk kernel.
+// One axis pass (Add: stream a only; Change: a = added, r = removed) as a plan: everything that is constant over the
+// pass, worked out once, and the chunks then enqueued one by one (plan_pass / enqueue_plan_chunk). A single-GPU pass
+// enqueues all of them back to back; a slab-partitioned pass (tbrm_slab_*) stops after each chunk so that the host can
+// exchange the propagated planes between ranks.
+struct PassPlan {
+    ChunkParams p{};
+    bool change = false;
+    int M = 0, S = 0;           // slices per chain chunk / per occlusion span
+    int D = 0;                  // slices this handle runs (the whole pass, or its slab's part of a pass along z)
+    int start = 0, dir = 1;     // first of them
+    int n_chunks = 0, n_spans = 0;
+    bool pass_begins_here = true; // chunk 0 starts from the cleared buffers' value (else from imported planes)
+    bool sparse = false, work_list = false;
+    size_t flags_per_group = 0, flags_per_span = 0, occ_off_a = 0, occ_off_r = 0;
+    // slab-partitioned passes
+    bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
+    int first_chunk_of_pass = 0, chunks_of_pass = 0;
+};
+
+// why plan_pass last declined a pass (diagnostics of the slab entry points, which have no fallback)
+thread_local const char* g_plan_note = "";
+int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; }
+
 // Returns TBRM_ERR_UNSUPPORTED (nothing enqueued) when the pass has to take the slice-per-launch path.
-int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr,
-                         float b_added)
+// slab: the light-volume z range this handle owns (null: everything).
+int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+              const tbrm_slab* slab, PassPlan& plan)
 {
-    if (force_slice_kernel()) return TBRM_ERR_UNSUPPORTED;
+    g_plan_note = "";
+    if (force_slice_kernel()) return declined("TBRM_FORCE_SLICE_KERNEL is set");
     const bool change = pr != nullptr;
-    const int W = pa.td[0], H = pa.td[1], D = pa.td[2];
+    const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
     TapRange tx = prev_tap_range(W, pa.prev_pixel_offset[0]), ty = prev_tap_range(H, pa.prev_pixel_offset[1]);
-    if (!tx.ok || !ty.ok) return TBRM_ERR_UNSUPPORTED;
+    if (!tx.ok || !ty.ok) return declined("previous-slice offset out of range");
     if (change) {
         const TapRange rx = prev_tap_range(W, pr->prev_pixel_offset[0]), ry = prev_tap_range(H, pr->prev_pixel_offset[1]);
-        if (!rx.ok || !ry.ok) return TBRM_ERR_UNSUPPORTED;
+        if (!rx.ok || !ry.ok) return declined("previous-slice offset out of range");
         tx.lo = std::min(tx.lo, rx.lo); tx.hi = std::max(tx.hi, rx.hi);
         ty.lo = std::min(ty.lo, ry.lo); ty.hi = std::max(ty.hi, ry.hi);
     }
-    ChunkParams p{};
+    plan = PassPlan{};
+    plan.change = change;
+    ChunkParams& p = plan.p;
     p.data = base.data;
     p.data_border = base.data_border;
     p.tf = base.tf;
@@ -285,11 +313,46 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     int M = 0;
     for (int cand : {16, 8, 4}) {
         if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
-        p.n_steps = std::min(cand, D);
+        p.n_steps = std::min(cand, D_pass);
         p.j0 = pa.start;
         if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, change, r->lv_fmt) <= 156 * 1024) { M = cand; break; }
     }
-    if (M <= 0) return TBRM_ERR_UNSUPPORTED;
+    if (M <= 0) return declined("the previous-slice taps reach too far for a 4-slice chunk");
+    plan.M = M;
+
+    // what this handle runs: the whole pass, or (slab-partitioned) its rows of every slice / its slices of a pass along z
+    plan.D = D_pass;
+    plan.start = pa.start;
+    plan.dir = pa.dir;
+    p.tiles_x = ceil_div(W, kChunkTile);
+    p.tiles_y = ceil_div(H, kChunkTile);
+    p.tile_row0 = 0;
+    p.occ_blocks_x = ceil_div(W, 16);
+    p.occ_blocks_y = ceil_div(H, 16);
+    p.roi_by0 = 0;
+    p.roi_by1 = p.occ_blocks_y;
+    plan.chunks_of_pass = ceil_div(D_pass, M);
+    if (slab) {
+        const int nz = r->lv_dims[2];
+        if (slab->z_begin < 0 || slab->z_end > nz || slab->z_begin >= slab->z_end || slab->z_begin % kChunkTile || slab->z_end % kChunkTile ||
+            nz % kChunkTile)
+            return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep: bounds and depth must be multiples of %d",
+                        slab->z_begin, slab->z_end, nz, kChunkTile);
+        if (pa.axis == 2) { // the pass runs along the slab axis: this handle advances its own slices, planes are handed on
+            plan.D = slab->z_end - slab->z_begin;
+            plan.start = pa.dir > 0 ? slab->z_begin : slab->z_end - 1;
+            plan.first_chunk_of_pass = (pa.dir > 0 ? slab->z_begin : nz - slab->z_end) / M;
+            plan.pass_begins_here = plan.first_chunk_of_pass == 0;
+        } else { // z is the plane's row axis: the slab's tile rows, and the occlusion of every row their windows can reach
+            plan.lateral = true;
+            p.tile_row0 = slab->z_begin / kChunkTile;
+            p.tiles_y = (slab->z_end - slab->z_begin) / kChunkTile;
+            p.roi_by0 = std::max(slab->z_begin - kChunkTile, 0) / 16;
+            p.roi_by1 = std::min(ceil_div(slab->z_end + kChunkTile, 16), p.occ_blocks_y);
+        }
+    }
+    const int D = plan.D;
+    plan.n_chunks = ceil_div(D, M);
 
     // The occlusion launches are decoupled from the chain's chunk length: one launch covers a "span" of S slices (several
     // chunks), so that it has enough workgroups to fill 256 CUs even when the chain has to run short chunks (a strongly
@@ -303,7 +366,7 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
     size_t occ_elems = (size_t) S * W * H;
     while (S > M && (2 * occ_elems + 3 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) { S -= M; occ_elems = (size_t) S * W * H; }
     const size_t occ_total = 2 * occ_elems + 3 * kPlaneGuard;
-    if (occ_total * sizeof(float) >= ((size_t) 1 << 32)) return TBRM_ERR_UNSUPPORTED;
+    if (occ_total * sizeof(float) >= ((size_t) 1 << 32)) return declined("slice plane too large for the occlusion scratch");
     if (occ_elems > r->occ_elems) {
         HIP_TRY(hipStreamSynchronize(r->stream));
         (void) hipFree(r->d_occ);
@@ -313,22 +376,22 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_occ, 0x3f800000, 1024, r->stream)); // the page of ones
         r->occ_elems = occ_elems;
     }
-    const int n_spans = ceil_div(D, S);
-    const size_t occ_off_a = kPlaneGuard, occ_off_r = kPlaneGuard + r->occ_elems + kPlaneGuard;
+    plan.S = S;
+    plan.n_spans = ceil_div(D, S);
+    plan.occ_off_a = kPlaneGuard;
+    plan.occ_off_r = kPlaneGuard + r->occ_elems + kPlaneGuard;
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
     // workgroup of the whole pass, computed up front, and per span the ascending list of the workgroups with work
-    const bool sparse = !getenv("TBRM_NO_SPARSE_OCC");
-    const bool work_list = sparse && !getenv("TBRM_NO_OCC_LIST");
-    p.occ_blocks_x = ceil_div(W, 16);
-    p.occ_blocks_y = ceil_div(H, 16);
+    plan.sparse = !getenv("TBRM_NO_SPARSE_OCC");
+    plan.work_list = plan.sparse && !getenv("TBRM_NO_OCC_LIST");
     p.occ_groups = ceil_div(S, kOccSlices);
-    const size_t flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
-    const size_t flags_per_span = (size_t) p.occ_groups * flags_per_group;
-    if (sparse) {
-        if (n_spans > 4096) return TBRM_ERR_UNSUPPORTED;
+    plan.flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
+    plan.flags_per_span = (size_t) p.occ_groups * plan.flags_per_group;
+    if (plan.sparse) {
+        if (plan.n_spans > 4096) return declined("too many occlusion spans");
         if (int e = ensure_skipping(r)) return e;
-        const size_t zbytes = flags_per_span * n_spans;
+        const size_t zbytes = plan.flags_per_span * plan.n_spans;
         if (zbytes > r->occ_zero_bytes) {
             HIP_TRY(hipStreamSynchronize(r->stream));
             (void) hipFree(r->d_occ_zero[0]);
@@ -342,54 +405,71 @@ int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_l
         }
         p.empty_bits = r->d_empty;
         p.occ_flags_out = r->d_occ_zero[0];
-        p.occ_list_out = work_list ? r->d_occ_list : nullptr;
+        p.occ_list_out = plan.work_list ? r->d_occ_list : nullptr;
         p.occ_count_out = (int*) (r->d_occ_list + r->occ_zero_bytes);
-        p.pass_start = pa.start;
+        p.pass_start = plan.start;
         p.pass_slices = D;
         p.chunk_slices = S;
-        HIP_TRY(launch_occ_flags(p, change, n_spans, r->stream));
+        HIP_TRY(launch_occ_flags(p, change, plan.n_spans, r->stream));
     }
-
-    p.tiles_x = ceil_div(W, kChunkTile);
-    p.tiles_y = ceil_div(H, kChunkTile);
     p.occ_base = r->d_occ;
-    p.a.occ_next = r->d_occ + occ_off_a;
-    p.r.occ_next = r->d_occ + occ_off_r;
+    p.a.occ_next = r->d_occ + plan.occ_off_a;
+    p.r.occ_next = r->d_occ + plan.occ_off_r;
+    return TBRM_OK;
+}
+
+// The plane holding the propagated light of stream `si` (0: a, 1: r) BEFORE chunk `boundary` (boundary = n_chunks: after
+// the last one): chunk c reads the planes of parity c & 1 and writes the others.
+float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_plane[2 * si + (boundary & 1)] + kPlaneGuard; }
+
+// Enqueues chunk c of the plan: the occlusion of its span first if the span starts here, then the chain.
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
+{
+    ChunkParams p = plan.p;
+    const int M = plan.M, S = plan.S, D = plan.D, W = p.W, H = p.H;
+    const int sp = (c * M) / S;
+    const int s0 = sp * S, sn = std::min(S, D - s0);
+    const int c0 = s0 / M, c1 = ceil_div(s0 + sn, M);
     // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple of 4
     // does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
-    auto chunk_sparse_ok = [&](int c) { return (std::min(M, D - c * M) * -p.dx_lo) % 4 == 0; };
-    for (int sp = 0; sp < n_spans; ++sp) {
-        const int s0 = sp * S, sn = std::min(S, D - s0);
-        const int c0 = s0 / M, c1 = ceil_div(s0 + sn, M);
-        bool span_sparse = sparse;
-        for (int c = c0; c < c1; ++c) span_sparse = span_sparse && chunk_sparse_ok(c); // else the whole span runs dense
+    auto chunk_sparse_ok = [&](int cc) { return (std::min(M, D - cc * M) * -p.dx_lo) % 4 == 0; };
+    bool span_sparse = plan.sparse;
+    for (int cc = c0; cc < c1; ++cc) span_sparse = span_sparse && chunk_sparse_ok(cc); // else the whole span runs dense
+    const bool work_list = plan.work_list;
 
-        // occlusion of the span: fills {a,r}.occ_next with sn planes
-        p.j0 = pa.start + s0 * pa.dir;
+    if (c == c0) { // occlusion of the span: fills {a,r}.occ_next with sn planes
+        p.j0 = plan.start + s0 * plan.dir;
         p.n_steps = sn;
         p.occ_flags = nullptr;
-        p.occ_list = span_sparse && work_list ? r->d_occ_list + (size_t) sp * flags_per_span : nullptr;
+        p.occ_list = span_sparse && work_list ? r->d_occ_list + (size_t) sp * plan.flags_per_span : nullptr;
         p.occ_count = span_sparse && work_list ? (const int*) (r->d_occ_list + r->occ_zero_bytes) + sp : nullptr;
-        if (span_sparse && !work_list) p.occ_flags = r->d_occ_zero[0] + (size_t) sp * flags_per_span;
-        HIP_TRY(launch_light_occlusion(p, change, r->stream));
-
-        // the chain, chunk by chunk
-        for (int c = c0; c < c1; ++c) {
-            const int k0 = c * M - s0; // first slice of the chunk within the span
-            p.n_steps = std::min(M, D - c * M);
-            p.j0 = pa.start + c * M * pa.dir;
-            p.first_chunk = c == 0;
-            const int cur = (c & 1), nxt = cur ^ 1;
-            p.a.plane_in = r->d_plane[cur] + kPlaneGuard; p.a.plane_out = r->d_plane[nxt] + kPlaneGuard;
-            p.r.plane_in = r->d_plane[2 + cur] + kPlaneGuard; p.r.plane_out = r->d_plane[2 + nxt] + kPlaneGuard;
-            p.a.occ_off = (uint32_t) (occ_off_a + (size_t) k0 * W * H);
-            p.r.occ_off = (uint32_t) (occ_off_r + (size_t) k0 * W * H);
-            p.occ_phase = k0 % kOccSlices;
-            p.occ_flags = span_sparse ? r->d_occ_zero[0] + (size_t) sp * flags_per_span + (size_t) (k0 / kOccSlices) * flags_per_group : nullptr;
-            HIP_TRY(launch_light_chain(p, change, r->lv_fmt, r->stream));
-            ++r->launches[0];
-        }
+        if (span_sparse && !work_list) p.occ_flags = r->d_occ_zero[0] + (size_t) sp * plan.flags_per_span;
+        HIP_TRY(launch_light_occlusion(p, plan.change, r->stream));
     }
+    const int k0 = c * M - s0; // first slice of the chunk within the span
+    p.n_steps = std::min(M, D - c * M);
+    p.j0 = plan.start + c * M * plan.dir;
+    p.first_chunk = c == 0 && plan.pass_begins_here;
+    p.a.plane_in = plan_plane(r, c, 0); p.a.plane_out = plan_plane(r, c + 1, 0);
+    p.r.plane_in = plan_plane(r, c, 1); p.r.plane_out = plan_plane(r, c + 1, 1);
+    p.a.occ_off = (uint32_t) (plan.occ_off_a + (size_t) k0 * W * H);
+    p.r.occ_off = (uint32_t) (plan.occ_off_r + (size_t) k0 * W * H);
+    p.occ_phase = k0 % kOccSlices;
+    p.occ_list = nullptr;
+    p.occ_count = nullptr;
+    p.occ_flags = span_sparse ? r->d_occ_zero[0] + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
+    HIP_TRY(launch_light_chain(p, plan.change, r->lv_fmt, r->stream));
+    ++r->launches[0];
+    return TBRM_OK;
+}
+
+int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr,
+                         float b_added)
+{
+    PassPlan plan;
+    if (int e = plan_pass(r, base, pa, pr, b_added, nullptr, plan)) return e;
+    for (int c = 0; c < plan.n_chunks; ++c)
+        if (int e = enqueue_plan_chunk(r, plan, c)) return e;
     return TBRM_OK;
 }
 
@@ -475,6 +555,22 @@ int enqueue_change(tbrm_resources* r, const tbrm_dir_light_params& removed, cons
     }
     return TBRM_OK;
 }
+
+} // namespace
+
+// A light operation taken apart for slab-partitioned execution: its axis passes, and the plan of the one being stepped.
+struct SlabOp {
+    tbrm_slab slab{};
+    bool change = false;
+    float b_added = 0.0f;
+    int n = 0;
+    tbrm_light_pass a[2]{}, r[2]{};
+    PropParams base{};
+    int current = -1; // pass being stepped
+    PassPlan plan;
+};
+
+namespace {
 
 RelayoutParams relayout_params(const void* src, void* dst, const int dims[3], const int bn[3], size_t elem, bool to_bricks)
 {
@@ -657,6 +753,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (auto& axis : r->d_buf)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
+    delete r->slab_op;
     (void) hipFree(r->d_occ);
     for (uint8_t* z : r->d_occ_zero) (void) hipFree(z);
     (void) hipFree(r->d_occ_list);
@@ -785,6 +882,95 @@ int tbrm_change_dir_light(tbrm_resources* r, const tbrm_dir_light_params* old_li
     if (int e = begin_timed(r, 0)) return e;
     if (int e = enqueue_change(r, *old_light, *new_light, *world)) return e;
     return end_timed(r, 0);
+}
+
+// ---- slab-partitioned illumination (tbrm.h "slabs") ------------------------------------------------------------
+
+int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* removed, const tbrm_dir_light_params* light, int added,
+                          const tbrm_world_params* world, const tbrm_slab* slab, int32_t* n_passes)
+{
+    if (!r || !light || !world || !slab || !n_passes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
+    *n_passes = 0;
+    if (!r->slab_op) r->slab_op = new SlabOp;
+    SlabOp& op = *r->slab_op;
+    op.slab = *slab;
+    op.change = removed != nullptr;
+    op.n = 0;
+    op.current = -1;
+    op.base = base_prop_params(r, *world);
+    if (!op.change) { // enqueue_add
+        int n = 0;
+        if (!host_light_passes(*light, *world, r->lv_dims, r->desc.border_mode, op.a, &n)) return TBRM_OK;
+        op.n = n;
+        op.b_added = added ? 1.0f : -1.0f;
+    } else { // enqueue_change
+        tbrm_light_pass rp[2], ap[2];
+        int rn = 0, an = 0;
+        const bool r_ok = host_light_passes(*removed, *world, r->lv_dims, r->desc.border_mode, rp, &rn);
+        const bool a_ok = host_light_passes(*light, *world, r->lv_dims, r->desc.border_mode, ap, &an);
+        if (!r_ok || !a_ok) return TBRM_OK;
+        if (rp[0].face != ap[0].face || rp[1].face != ap[1].face)
+            return fail(TBRM_ERR_UNSUPPORTED, "the two lights' major axes differ: remove the old light and add the new one "
+                                              "(LightingShaders.cpp:192-198)");
+        for (int i = 0; i < 2; ++i) {
+            if (rp[i].light_alpha == 0.0f && ap[i].light_alpha == 0.0f && rp[i].border_light == 0.0f && ap[i].border_light == 0.0f)
+                continue; // both streams dark: the pass cannot touch the light volume (enqueue_change)
+            op.a[op.n] = ap[i];
+            op.r[op.n] = rp[i];
+            ++op.n;
+        }
+        op.b_added = 0.0f;
+    }
+    *n_passes = op.n;
+    return TBRM_OK;
+}
+
+int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
+{
+    if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!r->slab_op || pass < 0 || pass >= r->slab_op->n) return fail(TBRM_ERR_INVALID_ARG, "no such pass (tbrm_slab_light_begin first)");
+    if (int e = bind(r)) return e;
+    SlabOp& op = *r->slab_op;
+    op.current = -1;
+    const int e = plan_pass(r, op.base, op.a[pass], op.change ? &op.r[pass] : nullptr, op.b_added, &op.slab, op.plan);
+    if (e == TBRM_ERR_UNSUPPORTED)
+        return fail(e, "pass %d (axis %d) needs the slice-per-launch kernel, which has no slab-partitioned form: %s", (int) pass,
+                    (int) op.a[pass].axis, g_plan_note);
+    if (e) return e;
+    op.current = pass;
+    const PassPlan& pl = op.plan;
+    out->axis = pl.p.axis;
+    out->dir = pl.dir;
+    out->lateral = pl.lateral ? 1 : 0;
+    out->streams = pl.change ? 2 : 1;
+    out->plane_w = pl.p.W;
+    out->plane_h = pl.p.H;
+    out->chunk_slices = pl.M;
+    out->chunks_of_pass = pl.chunks_of_pass;
+    out->first_chunk = pl.first_chunk_of_pass;
+    out->n_chunks = pl.n_chunks;
+    out->halo_rows = pl.lateral ? kChunkTile : 0;
+    return TBRM_OK;
+}
+
+int tbrm_slab_pass_chunk(tbrm_resources* r, int32_t chunk)
+{
+    if (!r || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight (tbrm_slab_pass_begin first)");
+    const PassPlan& pl = r->slab_op->plan;
+    if (chunk < 0 || chunk >= pl.n_chunks) return fail(TBRM_ERR_INVALID_ARG, "chunk %d of %d", chunk, pl.n_chunks);
+    if (int e = bind(r)) return e;
+    return enqueue_plan_chunk(r, pl, chunk);
+}
+
+int tbrm_slab_pass_plane(tbrm_resources* r, int32_t boundary, int32_t stream, void** device_plane)
+{
+    if (!r || !device_plane || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight");
+    const PassPlan& pl = r->slab_op->plan;
+    if (boundary < 0 || boundary > pl.n_chunks || stream < 0 || stream >= (pl.change ? 2 : 1))
+        return fail(TBRM_ERR_INVALID_ARG, "boundary %d / stream %d out of range", boundary, stream);
+    *device_plane = plan_plane(r, boundary, stream);
+    return TBRM_OK;
 }
 
 int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)

@@ -85,7 +85,9 @@ struct ChunkParams {
     int dir;                // +-1
     int j0, n_steps;        // first slice and number of slices of this launch (a span for the occlusion, a chunk for the chain)
     int first_chunk;        // chain: the pass starts here (windows start from the cleared buffers' value)
-    int tiles_x, tiles_y;   // chain: 32x32 tiles of the slice plane
+    int tiles_x, tiles_y;   // chain: 32x32 tiles of the slice plane this launch advances (tiles_y rows from tile_row0 on)
+    int tile_row0;          // chain: first tile row (slab-partitioned passes run only the rows of their slab; else 0)
+    int roi_by0, roi_by1;   // occlusion: block rows [roi_by0, roi_by1) can be read by those tiles; the rest is never computed
     int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch, widened to contain 0
     float b_added;
     // empty-block hand-off: k_occ_flags marks, once per pass, every occlusion workgroup (16x16 pixels x 8 slices) whose

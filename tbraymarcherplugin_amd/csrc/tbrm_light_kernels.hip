@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256) void k_occ_flags(const ChunkParams p, int n_ch
     const int n = min(p.chunk_slices, p.pass_slices - c * p.chunk_slices);
     const int k0 = zg * kOccDepth;
     uint8_t flag = 0;
-    if (k0 < n) {
+    if (by < p.roi_by0 || by >= p.roi_by1) flag = 1; // outside the slab's reach: never computed, never read
+    else if (k0 < n) {
         const int nk = min(kOccDepth, n - k0);
         const int j0 = p.pass_start + (c * p.chunk_slices + k0) * p.dir, j1 = j0 + (nk - 1) * p.dir;
         const int px0 = bx * kOccTile, py0 = by * kOccTile;
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     const int id = p.occ_list ? (int) p.occ_list[entry] : entry;
     const int gx = id % p.occ_blocks_x, gy = (id / p.occ_blocks_x) % p.occ_blocks_y, gz = id / (p.occ_blocks_x * p.occ_blocks_y);
     if (!p.occ_list && p.occ_flags && p.occ_flags[id]) return; // list off (A/B runs)
+    if (gy < p.roi_by0 || gy >= p.roi_by1) return;             // dense span of a slab-partitioned pass
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
     const int nk = min(kOccDepth, p.n_steps - k0);
 
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int tile_id = ((int) blockIdx.x & 7) * per_xcd + ((int) blockIdx.x >> 3);
     if (((int) blockIdx.x >> 3) >= per_xcd || tile_id >= n_tiles) return;
     const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
-    const int base_x = tile_x * T, base_y = tile_y * T;
+    const int base_x = tile_x * T, base_y = (p.tile_row0 + tile_y) * T;
 
     // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, ring slot q at ((2 + q)*NS + si)*PLANE; then the
     // light-volume tile (bytes)

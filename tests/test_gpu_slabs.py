@@ -1,0 +1,144 @@
+"""Slab-partitioned illumination (tbrm_slab_*, slabs.py) on ONE GPU: several handles in one process stand in for the
+ranks, planes move by device copies. The partitioned light volume must be bit-identical to the unpartitioned operator
+(and through it to the oracle): per voxel the arithmetic and its inputs are the same.
+"""
+import numpy as np
+import pytest
+
+from conftest import small_volume
+from tbraymarcherplugin_amd import abi, slabs, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make_handles(n_handles, dims, dtype, light_32bit=False, half_res=False, seed=0x5EED0400, tf="A", window=(0.5, 0.9, True, False)):
+    vol = small_volume(dims, dtype, seed)
+    lut = abi.color_curve_to_lut(S.tf_keys(tf))
+    w = abi.WindowingParams(*window)
+    out = []
+    for _ in range(n_handles):
+        res = abi.Resources(dims, abi.DTYPE_FMT[np.dtype(dtype)], light_32bit, half_res, 0)
+        res.upload_volume(vol)
+        res.set_tf_lut(lut)
+        res.set_windowing(w)
+        res.clear_light_volume(0.0)
+        out.append(res)
+    return vol, lut, w, out
+
+
+def slab_setup(handles, n_slabs):
+    depth = handles[0].light_dims[2]
+    bounds = slabs.slab_bounds(depth, n_slabs)
+    members = [slabs.DeviceSlab(res, k, *bounds[k]) for k, res in enumerate(handles)]
+    fabric = slabs.make_fabric([b[0] for b in bounds] + [depth])
+    return members, fabric, bounds
+
+
+def assert_slabs_equal(full, members, what):
+    """every member's OWN slices equal the unpartitioned volume"""
+    ref = full.download_light_volume()
+    for m in members:
+        got = m.res.download_light_volume()[m.z_begin:m.z_end]
+        want = ref[m.z_begin:m.z_end]
+        bad = np.count_nonzero(got != want)
+        assert bad == 0, f"{what}: slab {m.slab_index} [{m.z_begin},{m.z_end}): {bad} of {got.size} voxels differ"
+
+
+LIGHTS = [((1, .35, -.5), 0.5), ((-.4, 1, -.3), 0.4), ((.2, -.3, -1), 0.4), ((-1, -.6, .4), 0.3), ((.1, .45, 1), 0.5),
+          ((0, 0, -1), 0.3), ((1, 0, 0), 0.2), ((.6, -1, -.2), 0.3), ((.7, .1, .69), 0.25)]
+
+
+@pytest.mark.parametrize("n_slabs,dims,half_res", [(2, (72, 56, 64), False), (4, (128, 96, 128), False), (2, (80, 64, 128), True)])
+@pytest.mark.parametrize("light_32bit", [False, True])
+def test_slab_partitioned_lights_equal_single_handle(gpu, n_slabs, dims, half_res, light_32bit):
+    _, _, _, handles = make_handles(n_slabs + 1, dims, np.uint16, light_32bit, half_res)
+    full, parts = handles[0], handles[1:]
+    members, fabric, _ = slab_setup(parts, n_slabs)
+    world = S.default_world()
+    try:
+        for i, (d, inten) in enumerate(LIGHTS):
+            light = abi.DirLightParams(d, inten)
+            full.add_dir_light(light, True, world)
+            slabs.add_dir_light(members, fabric, light, True, world)
+            assert_slabs_equal(full, members, f"add {i} {d}")
+        # remove one, change one within its faces (fused), change one across faces (remove + add)
+        rem = abi.DirLightParams(*LIGHTS[3])
+        full.add_dir_light(rem, False, world)
+        slabs.add_dir_light(members, fabric, rem, False, world)
+        assert_slabs_equal(full, members, "remove")
+        old = abi.DirLightParams(*LIGHTS[1])
+        new = abi.DirLightParams(S.rotate_z(LIGHTS[1][0], 5.0), LIGHTS[1][1])
+        full.change_dir_light(old, new, world)
+        slabs.change_dir_light(members, fabric, old, new, world)
+        assert_slabs_equal(full, members, "fused change (lateral + lateral)")
+        old = abi.DirLightParams(*LIGHTS[2])
+        new = abi.DirLightParams((.25, -.2, -1), 0.45)
+        full.change_dir_light(old, new, world)
+        slabs.change_dir_light(members, fabric, old, new, world)
+        assert_slabs_equal(full, members, "fused change (along z)")
+        old = abi.DirLightParams(*LIGHTS[4])
+        new = abi.DirLightParams((1.0, 0.1, -0.2), 0.5)
+        full.change_dir_light(old, new, world)
+        slabs.change_dir_light(members, fabric, old, new, world)
+        assert_slabs_equal(full, members, "change across faces")
+        assert fabric.bytes_moved > 0
+        # the gathered volume is the whole unpartitioned one, on every handle
+        slabs.gather_light_volume(members, fabric)
+        ref = full.download_light_volume()
+        for m in members:
+            assert np.array_equal(m.res.download_light_volume(), ref), f"gathered light volume of slab {m.slab_index}"
+    finally:
+        for h in handles:
+            h.close()
+
+
+def test_slab_lights_equal_oracle_and_render(gpu, oracle_mod):
+    """End to end as config 4 words it: slab-partitioned reset, light-volume gather, frame in image tiles — against the oracle."""
+    from tbraymarcherplugin_amd import sharding
+
+    dims = (64, 64, 64)
+    vol, lut, w, handles = make_handles(2, dims, np.uint16, seed=0x5EED0401)
+    orc = oracle_mod.OracleScene(vol, False, False, abi.ADDRESS_WRAP, abi.BORDER_ENGINE_8BIT)
+    orc.set_tf_lut(lut)
+    orc.set_windowing(w)
+    members, fabric, _ = slab_setup(handles, 2)
+    world = S.default_world()
+    lights = [S.light(i) for i in range(4)]
+    try:
+        slabs.reset_all_lights(members, fabric, lights, world, lambda m: m.res.clear_light_volume(0.0))
+        orc.clear_light_volume(0.0)
+        for l in lights:
+            orc.add_dir_light(l, True, world)
+        slabs.gather_light_volume(members, fabric)
+        for m in members:
+            assert np.array_equal(m.res.download_light_volume(), orc.light)
+        cam = S.default_camera(64, 64)
+        rp = abi.RaymarchParams(64.0, -1, True)
+        want, _ = orc.raymarch_lit(cam, abi.Tile(0, 0, 64, 64, 1), rp, world)
+        parts = [handles[r].raymarch_lit(cam, sharding.rank_tile(64, 64, r, 2), rp, world) for r in range(2)]
+        frame = sharding.assemble(np.stack(parts), 64, 2)
+        np.testing.assert_allclose(frame, want, rtol=0, atol=1e-4)
+    finally:
+        for h in handles:
+            h.close()
+
+
+def test_slab_arguments_are_checked(gpu):
+    _, _, _, (res,) = make_handles(1, (32, 32, 64), np.uint8)
+    world = S.default_world()
+    with res:
+        light = abi.DirLightParams((1, .3, -.5), 0.5)
+        assert res.slab_light_begin(None, light, True, world, abi.Slab(0, 48)) == 2  # bounds are checked when a pass is planned
+        with pytest.raises(abi.TbrmError):
+            res.slab_pass_begin(0)
+        with pytest.raises(abi.TbrmError):
+            res.slab_pass_chunk(0)
+        assert res.slab_light_begin(None, light, True, world, abi.Slab(0, 32)) == 2
+        with pytest.raises(abi.TbrmError):
+            res.slab_pass_begin(2)
+        d = res.slab_pass_begin(0)
+        assert d.n_chunks >= 1 and d.streams == 1
+        with pytest.raises(abi.TbrmError):
+            res.slab_pass_chunk(d.n_chunks)
+        with pytest.raises(abi.TbrmError):
+            res.slab_pass_plane(0, 1)
