@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--light-parallel-reset", action="store_true",
                     help="N>1: the untimed ResetAllLights deals the lights over the ranks and combines the light volumes with "
                          "reduce-scatter + all-gather (SURVEY.md §8e) instead of adding every light on every GPU")
+    ap.add_argument("--slab-illumination", action="store_true",
+                    help="N>1: the timed ChangeDirLight is partitioned over the ranks in light-volume z slabs (plane halo exchange "
+                         "per chunk / z pipeline, slabs.py), followed by an all-gather of the light volume, instead of being "
+                         "computed redundantly on every GPU (BASELINE config 4's decomposition)")
     args = ap.parse_args()
 
     import torch
@@ -163,6 +167,44 @@ def main():
         dist.all_reduce(t)
         total_samples = int(t.item())
 
+    # slab-partitioned light update: this rank owns light-volume slices [z_r, z_r+1)
+    slab_member = slab_fabric = None
+    if args.slab_illumination and dist is not None:
+        from tbraymarcherplugin_amd import slabs
+
+        depth = res.light_dims[2]
+        bounds = slabs.slab_bounds(depth, n_gpus)
+        z_bounds = [b[0] for b in bounds] + [depth]
+        slab_member = slabs.DeviceSlab(res, rank, *bounds[rank])
+        if one_gpu_dry_run:  # gloo: stage through host memory
+            def p2p(ops):
+                res.flush()
+                work = []
+                for kind, t, peer in ops:
+                    if kind == "send":
+                        host = t.cpu()  # kept alive until the send has completed
+                        work.append((dist.isend(host, peer), None, host))
+                    else:
+                        buf = torch.empty(t.shape, dtype=t.dtype)
+                        work.append((dist.irecv(buf, peer), t, buf))
+                for w, t, buf in work:
+                    w.wait()
+                    if t is not None:
+                        t.copy_(buf)
+                torch.cuda.synchronize()
+
+            slab_fabric = slabs.make_fabric(z_bounds, list(range(n_gpus)), rank, p2p, sync_local=False)
+        else:
+            slab_fabric = slabs.dist_fabric(z_bounds, rank, n_gpus)
+
+    def gather_light(full, part):
+        if one_gpu_dry_run:
+            parts = [torch.empty(part.shape, dtype=part.dtype) for _ in range(n_gpus)]
+            dist.all_gather(parts, part.cpu())
+            full.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(full, part)
+
     angle = [0.0] * len(lights)
     ms_illum, ms_ray = [], []
     last = [0]  # buffer index of the most recent frame
@@ -172,7 +214,12 @@ def main():
             li = k % len(lights)
             angle[li] += 5.0
             new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li]), lights[li].light_intensity)
-            res.change_dir_light(lights[li], new, world)
+            if slab_member is not None:
+                with slab_member.stream_context():  # RCCL point-to-point operations ordered with the library's stream
+                    slabs.change_dir_light([slab_member], slab_fabric, lights[li], new, world)
+                    slabs.gather_light_volume([slab_member], slab_fabric, gather_light)
+            else:
+                res.change_dir_light(lights[li], new, world)
             lights[li] = new
         b = k & 1
         if pending[b] is not None:  # the gather that last read outs[b] / wrote gathers[b]
@@ -190,7 +237,7 @@ def main():
                 pending[b] = dist.all_gather_into_tensor(gathers[b], outs[b], async_op=True)
         last[0] = b
         if record:
-            if not args.raymarch_only:
+            if not args.raymarch_only and slab_member is None:
                 ms_illum.append(res.last_gpu_time_ms(0))
             ms_ray.append(res.last_gpu_time_ms(1))
 
@@ -240,6 +287,36 @@ def main():
     torch.cuda.synchronize()
     ray_ms = float(np.mean(ms_ray))
     illum_ms = float(np.mean(ms_illum)) if ms_illum else 0.0
+
+    # ---- slab mode: the partitioned + gathered light volume must equal the unpartitioned operator's (untimed replay) ----
+    slab_ok = None
+    if slab_member is not None and not args.raymarch_only:
+        from tbraymarcherplugin_amd import sharding
+
+        res.flush()
+        got = sharding.device_light_tensor(res).clone()
+        torch.cuda.synchronize()  # the copy runs on torch's stream: it must be complete before the library's stream rewrites the volume
+        replay = [S.light(i) for i in cfg["lights"]]
+        ang = [0.0] * len(replay)
+        res.clear_light_volume(0.0)
+        for l in replay:
+            res.add_dir_light(l, True, world)
+        for k in range(args.warmup + args.steps + max(3, min(args.steps, 10))):
+            li = k % len(replay)
+            ang[li] += 5.0
+            new = abi.DirLightParams(S.rotate_z(light_dirs[li], ang[li]), replay[li].light_intensity)
+            res.change_dir_light(replay[li], new, world)
+            replay[li] = new
+        res.flush()
+        want = sharding.device_light_tensor(res)
+        slab_ok = bool(torch.equal(got, want))
+        if not slab_ok and os.environ.get("TBRM_BENCH_DEBUG"):
+            layers = (res.light_dims[2] + 7) // 8
+            bad = (got != want).view(layers, -1).sum(dim=1).tolist()
+            import hashlib
+            hg, hw = (hashlib.sha1(x.cpu().numpy().tobytes()).hexdigest()[:12] for x in (got, want))
+            print(f"[rank {rank}] light volume sha1: slabs {hg}, unpartitioned replay {hw}; mismatching bytes per 8-slice layer: "
+                  f"{ {i: b for i, b in enumerate(bad) if b} }", flush=True)
 
     # ---- roofline of the dominant kernel (algorithmic bytes) -------------------------------
     b_data = np.dtype(cfg["dtype"]).itemsize
@@ -292,9 +369,11 @@ def main():
                        "parallelism": f"image tiles x{n_gpus} (interleaved 8-row groups), volumes replicated"
                                       if n_gpus > 1 else "single GPU",
                        "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only),
-                       "light_parallel_reset": bool(args.light_parallel_reset and dist is not None)},
+                       "light_parallel_reset": bool(args.light_parallel_reset and dist is not None),
+                       "slab_illumination": slab_member is not None},
             "nominal_samples_per_step": total_samples,
             "gathered_frame_equals_single_gpu_render": gather_ok,
+            "slab_light_volume_equals_unpartitioned": slab_ok,
             "gpu_ms": {"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4), "reset_all_lights_setup": round(reset_ms, 2)},
             "raymarch_only_msamples_per_s": round(my_samples / (ray_ms * 1e-3) / 1e6, 2),
             "roofline": roofline,

@@ -86,13 +86,17 @@ class DeviceSlab:
 
 
 class Fabric:
-    """Moves tensors between slabs: a copy when both live in this process, isend / irecv otherwise."""
+    """Moves tensors between slabs: a copy when both live in this process, point-to-point operations otherwise.
 
-    def __init__(self, owner_of_slab, rank=0, isend=None, irecv=None, sync_local=True):
+    p2p(ops) executes one batch: ops is a list of ("send" | "recv", tensor, peer rank) and the call returns when the
+    operations are complete or ordered with the current stream (torch.distributed.batch_isend_irecv + wait: one RCCL
+    group per exchange, so the sends and receives of a rank cannot block each other)."""
+
+    def __init__(self, owner_of_slab, rank=0, p2p=None, sync_local=True):
         self.owner_of_slab = list(owner_of_slab)
         self.rank = rank
-        self._isend, self._irecv = isend, irecv
-        self._local, self._work = [], []
+        self._p2p = p2p
+        self._local, self._ops = [], []
         self.sync_local = sync_local
         self.bytes_moved = 0
 
@@ -110,14 +114,14 @@ class Fabric:
             self._local.append((src(), dst()))
         elif s_here:
             t = src()
-            self._work.append(self._isend(t, self.owner(dst_slab)))
+            self._ops.append(("send", t, self.owner(dst_slab)))
             self.bytes_moved += t.numel() * t.element_size()
         elif d_here:
-            self._work.append(self._irecv(dst(), self.owner(src_slab)))
+            self._ops.append(("recv", dst(), self.owner(src_slab)))
 
     def complete(self, members):
         """Executes the registered transfers. Local copies between handles of one process are ordered by draining the
-        members' streams (this is the single-GPU emulation, not a fast path); p2p work is waited for."""
+        members' streams (this is the single-GPU emulation, not a fast path)."""
         if self._local:
             if self.sync_local:
                 for m in members:
@@ -130,10 +134,9 @@ class Fabric:
                 import torch
 
                 torch.cuda.synchronize(staged[0].device)
-        for w in self._work:
-            if w is not None:
-                w.wait()
-        self._local, self._work = [], []
+        if self._ops:
+            self._p2p(self._ops)
+        self._local, self._ops = [], []
 
 
 def _run_pass(members, by_index, fabric, index):
@@ -207,10 +210,10 @@ def reset_all_lights(members, fabric, lights, world, clear):
         add_dir_light(members, fabric, light, True, world)
 
 
-def make_fabric(z_bounds, owner_of_slab=None, rank=0, isend=None, irecv=None, sync_local=True):
+def make_fabric(z_bounds, owner_of_slab=None, rank=0, p2p=None, sync_local=True):
     """z_bounds: the n_slabs + 1 slab boundaries. owner_of_slab defaults to everything in this process."""
     n = len(z_bounds) - 1
-    f = Fabric(owner_of_slab if owner_of_slab is not None else [rank] * n, rank, isend, irecv, sync_local)
+    f = Fabric(owner_of_slab if owner_of_slab is not None else [rank] * n, rank, p2p, sync_local)
     f.z_bounds = list(z_bounds)
     return f
 
@@ -253,3 +256,20 @@ def gather_light_volume(members, fabric, all_gather_into=None):
             if dst is not src:
                 tensors[dst.slab_index][lo:hi].copy_(tensors[src.slab_index][lo:hi])
     torch.cuda.synchronize()
+
+
+def dist_fabric(z_bounds, rank, world_size, group=None):
+    """One slab per process: slab k lives on rank k, planes move with torch.distributed point-to-point operations (RCCL
+    over xGMI on GPUs — run the driver inside `member.stream_context()` so that they are ordered with the library's
+    stream without a host synchronisation; gloo on CPU tensors in the tests)."""
+    import torch.distributed as dist
+
+    if len(z_bounds) - 1 != world_size:
+        raise ValueError("one slab per rank")
+
+    def p2p(ops):
+        batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, group) for kind, t, peer in ops]
+        for w in dist.batch_isend_irecv(batch):
+            w.wait()
+
+    return make_fabric(z_bounds, list(range(world_size)), rank, p2p, sync_local=False)

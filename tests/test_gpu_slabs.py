@@ -142,3 +142,53 @@ def test_slab_arguments_are_checked(gpu):
             res.slab_pass_chunk(d.n_chunks)
         with pytest.raises(abi.TbrmError):
             res.slab_pass_plane(0, 1)
+
+
+def test_full_size_slabs_equal_single_handle(gpu):
+    """BASELINE config 3's volume (512^3 UNORM16, UNORM8 light volume) in 2 and 8 slabs: several occlusion spans per pass,
+    16- and 8-slice chunks, sparse work lists — bit-identical to the unpartitioned operator."""
+    import torch
+
+    dims = (512, 512, 512)
+    vol = S.make_volume_torch(dims, np.uint16, S.seed_for_config(3), torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    lut = abi.color_curve_to_lut(S.tf_keys("A"))
+    w = abi.WindowingParams(0.5, 0.9, True, False)
+    world = S.default_world()
+
+    def handle():
+        res = abi.Resources(dims, abi.FMT_G16, False, False, 0)
+        res.upload_volume_device(vol.data_ptr(), vol.numel() * vol.element_size())
+        res.set_tf_lut(lut)
+        res.set_windowing(w)
+        res.clear_light_volume(0.0)
+        return res
+
+    full = handle()
+    ops = [("add", S.light(0)), ("add", S.light(2)), ("change", S.light(0), abi.DirLightParams(S.rotate_z(S.LIGHTS[0][0], 5.0), S.LIGHTS[0][1])),
+           ("change", S.light(2), abi.DirLightParams(S.rotate_z(S.LIGHTS[2][0], 5.0), S.LIGHTS[2][1]))]
+    try:
+        for op in ops:
+            if op[0] == "add":
+                full.add_dir_light(op[1], True, world)
+            else:
+                full.change_dir_light(op[1], op[2], world)
+        ref = full.download_light_volume()
+        for n_slabs in (2, 8):
+            parts = [handle() for _ in range(n_slabs)]
+            try:
+                members, fabric, _ = slab_setup(parts, n_slabs)
+                for op in ops:
+                    if op[0] == "add":
+                        slabs.add_dir_light(members, fabric, op[1], True, world)
+                    else:
+                        slabs.change_dir_light(members, fabric, op[1], op[2], world)
+                for m in members:
+                    got = m.res.download_light_volume()[m.z_begin:m.z_end]
+                    bad = np.count_nonzero(got != ref[m.z_begin:m.z_end])
+                    assert bad == 0, f"{n_slabs} slabs, slab {m.slab_index}: {bad} voxels differ"
+            finally:
+                for p in parts:
+                    p.close()
+    finally:
+        full.close()
