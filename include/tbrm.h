@@ -204,6 +204,16 @@ TBRM_API int tbrm_set_windowing(tbrm_resources* res, const tbrm_windowing_params
 TBRM_API int tbrm_add_dir_light(tbrm_resources* res, const tbrm_dir_light_params* light, int added,
                                 const tbrm_world_params* world, int* light_added, int gpu_sync);
 
+/* Several AddDirLightToSingleVolume calls as one (what ARaymarchVolume::ResetAllLights issues after its clear,
+ * RaymarchVolume.cpp:418-451). Axis passes of different lights that leave the same cube face share one slice loop
+ * (the multi-light optimisation of the Sunden/Ropinski scheme that the reference lists as not done, Readme.md:186-187),
+ * the rest run as in tbrm_add_dir_light. The per-voxel updates happen in a different order than light by light — the
+ * same sum, but an UNORM8 light volume can differ by one code where an fp32 add lands on a rounding tie — so the order
+ * is reported: `schedule` (nullable, room for 8 * n_lights ints) receives 4 ints per entry {light a, pass a, light b,
+ * pass b} (b = -1 -1 for an unpaired pass), entry e's a before its b, entries in order; *n_entries their number. */
+TBRM_API int tbrm_add_dir_lights(tbrm_resources* res, const tbrm_dir_light_params* lights, int32_t n_lights, int added,
+                                 const tbrm_world_params* world, int32_t* schedule, int32_t* n_entries);
+
 /* ChangeDirLightInSingleVolume(Resources, Old, New, WorldParameters, LightAdded). Falls back to
  * remove + add when the two major axes differ (LightingShaders.cpp:192-198). */
 TBRM_API int tbrm_change_dir_light(tbrm_resources* res, const tbrm_dir_light_params* old_light,

@@ -112,6 +112,21 @@ struct URaymarchUtils { // RaymarchUtils.h:33-93; all static, like the Blueprint
         tbrm_add_dir_light(Resources.Handle, &l, Added ? 1 : 0, &w, &flag, bGPUSync ? 1 : 0);
         LightAdded = flag != 0;
     }
+    // Not in the reference: several AddDirLightToSingleVolume calls as one (tbrm_add_dir_lights: passes of different lights
+    // that leave the same cube face share one slice loop). Returns the number of passes that ran paired.
+    static int AddDirLightsToSingleVolume(const FBasicRaymarchRenderingResources& Resources, const std::vector<FDirLightParameters>& Lights,
+                                          const bool Added, const FRaymarchWorldParameters WorldParameters, bool& LightsAdded)
+    {
+        std::vector<tbrm_dir_light_params> l;
+        for (const FDirLightParameters& p : Lights) l.push_back(p.abi());
+        const tbrm_world_params w = WorldParameters.abi();
+        std::vector<int32_t> schedule(8 * l.size() + 8);
+        int32_t entries = 0;
+        LightsAdded = tbrm_add_dir_lights(Resources.Handle, l.data(), (int32_t) l.size(), Added ? 1 : 0, &w, schedule.data(), &entries) == TBRM_OK;
+        int paired = 0;
+        for (int32_t e = 0; e < entries; ++e) paired += schedule[4 * e + 2] >= 0 ? 2 : 0;
+        return paired;
+    }
     static void ChangeDirLightInSingleVolume(FBasicRaymarchRenderingResources& Resources, const FDirLightParameters OldLightParameters,
                                              const FDirLightParameters NewLightParameters, const FRaymarchWorldParameters WorldParameters,
                                              bool& LightAdded, bool bGPUSync = false)
@@ -180,6 +195,7 @@ public:
     int Device = 0;
     int DataAddressMode = TBRM_ADDRESS_WRAP;
     bool bRecordLightsOnReset = false; // see ResetAllLights
+    bool bBatchLightsOnReset = false;  // ResetAllLights adds all lights with one batched call (UNORM8 result may differ by one code at fp32 ties)
 
     struct FStats { int Resets = 0, LightAdds = 0, LightChanges = 0, Frames = 0; } Stats; // what Tick decided (test hook)
 
@@ -273,6 +289,19 @@ public:
         URaymarchUtils::ClearResourceLightVolumes(RaymarchResources, 0);
         ++Stats.Resets;
         bool bResetWasSuccessful = true;
+        if (bBatchLightsOnReset) {
+            std::vector<FDirLightParameters> All;
+            for (ARaymarchLight* Light : LightsArray)
+                if (Light) All.push_back(Light->GetCurrentParameters());
+            URaymarchUtils::AddDirLightsToSingleVolume(RaymarchResources, All, true, WorldParameters, bResetWasSuccessful);
+            Stats.LightAdds += (int) All.size();
+            if (!bResetWasSuccessful) { std::fprintf(stderr, "Error. Could not add the lights.\n"); return; }
+            if (bRecordLightsOnReset)
+                for (ARaymarchLight* Light : LightsArray)
+                    if (Light) LightParametersMap[Light] = Light->GetCurrentParameters();
+            bRequestedRecompute = false;
+            return;
+        }
         for (ARaymarchLight* Light : LightsArray) {
             if (!Light) continue;
             URaymarchUtils::AddDirLightToSingleVolume(RaymarchResources, Light->GetCurrentParameters(), true, WorldParameters, bResetWasSuccessful, bFastShader);

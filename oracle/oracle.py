@@ -61,6 +61,7 @@ def load():
     lib.orc_data_border.restype = f; lib.orc_data_border.argtypes = [P(abi.WindowingParams), C.c_int]
     lib.orc_light_passes.argtypes = [P(abi.DirLightParams), P(abi.WorldParams), P(C.c_int32 * 3), C.c_int, P(abi.LightPass * 2), P(C.c_int)]
     lib.orc_add_dir_light.argtypes = [P(Scene), P(abi.DirLightParams), C.c_int, P(abi.WorldParams)]
+    lib.orc_add_dir_light_pass.argtypes = [P(Scene), P(abi.DirLightParams), C.c_int, P(abi.WorldParams), C.c_int]
     lib.orc_change_dir_light.argtypes = [P(Scene), P(abi.DirLightParams), P(abi.DirLightParams), P(abi.WorldParams)]
     lib.orc_clear_light_volume.argtypes = [P(Scene), f]
     lib.orc_raymarch_lit.argtypes = [P(Scene), P(abi.Camera), P(abi.Tile), P(abi.RaymarchParams), P(abi.WorldParams), vp, vp, P(C.c_uint64)]
@@ -162,6 +163,11 @@ class OracleScene:
     def add_dir_light(self, light, added, world):
         sc = self._scene()
         return self.lib.orc_add_dir_light(C.byref(sc), C.byref(light), int(bool(added)), C.byref(world))
+
+    def add_dir_light_pass(self, light, added, world, index):
+        """only axis pass `index` of the light (replaying the order tbrm_add_dir_lights reports)"""
+        sc = self._scene()
+        return self.lib.orc_add_dir_light_pass(C.byref(sc), C.byref(light), int(bool(added)), C.byref(world), int(index))
 
     def change_dir_light(self, old, new, world):
         sc = self._scene()

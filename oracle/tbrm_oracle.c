@@ -567,6 +567,34 @@ static void clear_buffer(void* b, int fmt, size_t n, float v)
 
 static size_t lv_elem_size(int fmt) { return fmt == TBRM_FMT_G8 ? 1 : 4; }
 
+/* one axis pass of AddDirLightToSingleLightVolume_RenderThread (LightingShaders.cpp:100-158) */
+static void add_light_pass(orc_scene* sc, const tbrm_light_pass* p, int b_added, const float cc[3], const float cd[3], float data_border)
+{
+    const int fmt = sc->light_format;
+    const size_t npx = (size_t) p->td[0] * p->td[1];
+    void* bufs[2] = {malloc(npx * lv_elem_size(fmt)), malloc(npx * lv_elem_size(fmt))};
+    clear_buffer(bufs[0], fmt, npx, p->light_alpha); /* LightingShaders.cpp:76-79 */
+    clear_buffer(bufs[1], fmt, npx, p->light_alpha);
+    for (int j = p->start; j != p->stop; j += p->dir) {
+        const void* rd = (j % 2 == 0) ? bufs[0] : bufs[1]; /* LightingShaders.cpp:149-156 */
+        void* wr = (j % 2 == 0) ? bufs[1] : bufs[0];
+#pragma omp parallel for schedule(static) if (npx >= 65536)
+        for (int py = 0; py < p->td[1]; ++py)
+            for (int px = 0; px < p->td[0]; ++px) {
+                int pos[3];
+                permute(p->axis, px, py, j, pos);
+                const float l = propagate_voxel(sc, p, rd, px, py, pos, cc, cd, data_border, 1);
+                buf_store(wr, fmt, (size_t) py * p->td[0] + px, l); /* AddDirLightShader.usf:120 */
+                if (fabsf(l) > 1e-3f) { /* :123 */
+                    const size_t li = lv_index(sc->light_dims, pos[0], pos[1], pos[2]);
+                    buf_store(sc->light, fmt, li, buf_load(sc->light, fmt, li) + (l * (float) b_added)); /* :126 */
+                }
+            }
+    }
+    free(bufs[0]);
+    free(bufs[1]);
+}
+
 int orc_add_dir_light(orc_scene* sc, const tbrm_dir_light_params* light, int added, const tbrm_world_params* world)
 {
     tbrm_light_pass passes[2];
@@ -575,35 +603,22 @@ int orc_add_dir_light(orc_scene* sc, const tbrm_dir_light_params* light, int add
     float cc[3], cd[3];
     orc_local_clipping(world, cc, cd);
     const float data_border = orc_data_border(&sc->windowing, sc->border_mode);
-    const int fmt = sc->light_format;
-    const int b_added = added ? 1 : -1;
-
-    for (int i = 0; i < n; ++i) {
-        const tbrm_light_pass* p = &passes[i];
-        const size_t npx = (size_t) p->td[0] * p->td[1];
-        void* bufs[2] = {malloc(npx * lv_elem_size(fmt)), malloc(npx * lv_elem_size(fmt))};
-        clear_buffer(bufs[0], fmt, npx, p->light_alpha); /* LightingShaders.cpp:76-79 */
-        clear_buffer(bufs[1], fmt, npx, p->light_alpha);
-        for (int j = p->start; j != p->stop; j += p->dir) {
-            const void* rd = (j % 2 == 0) ? bufs[0] : bufs[1]; /* LightingShaders.cpp:149-156 */
-            void* wr = (j % 2 == 0) ? bufs[1] : bufs[0];
-#pragma omp parallel for schedule(static) if (npx >= 65536)
-            for (int py = 0; py < p->td[1]; ++py)
-                for (int px = 0; px < p->td[0]; ++px) {
-                    int pos[3];
-                    permute(p->axis, px, py, j, pos);
-                    const float l = propagate_voxel(sc, p, rd, px, py, pos, cc, cd, data_border, 1);
-                    buf_store(wr, fmt, (size_t) py * p->td[0] + px, l); /* AddDirLightShader.usf:120 */
-                    if (fabsf(l) > 1e-3f) { /* :123 */
-                        const size_t li = lv_index(sc->light_dims, pos[0], pos[1], pos[2]);
-                        buf_store(sc->light, fmt, li, buf_load(sc->light, fmt, li) + (l * (float) b_added)); /* :126 */
-                    }
-                }
-        }
-        free(bufs[0]);
-        free(bufs[1]);
-    }
+    for (int i = 0; i < n; ++i) add_light_pass(sc, &passes[i], added ? 1 : -1, cc, cd, data_border);
     return n;
+}
+
+/* Only axis pass `pass` of the light (0 or 1): lets a checker replay the pass order of a batched multi-light add
+ * (tbrm_add_dir_lights reports it). Returns 1 when the pass exists and ran, else 0. */
+int orc_add_dir_light_pass(orc_scene* sc, const tbrm_dir_light_params* light, int added, const tbrm_world_params* world, int pass)
+{
+    tbrm_light_pass passes[2];
+    int n = 0;
+    if (orc_light_passes(light, world, sc->light_dims, sc->border_mode, passes, &n)) return 0;
+    if (pass < 0 || pass >= n) return 0;
+    float cc[3], cd[3];
+    orc_local_clipping(world, cc, cd);
+    add_light_pass(sc, &passes[pass], added ? 1 : -1, cc, cd, orc_data_border(&sc->windowing, sc->border_mode));
+    return 1;
 }
 
 int orc_change_dir_light(orc_scene* sc, const tbrm_dir_light_params* old_light, const tbrm_dir_light_params* new_light,

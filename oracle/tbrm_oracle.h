@@ -47,6 +47,7 @@ int orc_light_passes(const tbrm_dir_light_params* light, const tbrm_world_params
 
 /* returns the number of axis passes run (Add), 2 for a fused Change, -1 for the remove+add fallback */
 int orc_add_dir_light(orc_scene* sc, const tbrm_dir_light_params* light, int added, const tbrm_world_params* world);
+int orc_add_dir_light_pass(orc_scene* sc, const tbrm_dir_light_params* light, int added, const tbrm_world_params* world, int pass);
 int orc_change_dir_light(orc_scene* sc, const tbrm_dir_light_params* old_light,
                          const tbrm_dir_light_params* new_light, const tbrm_world_params* world);
 void orc_clear_light_volume(orc_scene* sc, float value);

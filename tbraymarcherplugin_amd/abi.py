@@ -118,7 +118,7 @@ SYMBOLS = [
     "tbrm_resources_create", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
-    "tbrm_add_dir_light", "tbrm_change_dir_light", "tbrm_clear_light_volume",
+    "tbrm_add_dir_light", "tbrm_add_dir_lights", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_slab_light_begin", "tbrm_slab_pass_begin", "tbrm_slab_pass_chunk", "tbrm_slab_pass_plane",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
@@ -166,6 +166,7 @@ def load():
     lib.tbrm_host_bake_tf_lut.argtypes = [vp, vp]
     lib.tbrm_set_windowing.argtypes = [vp, P(WindowingParams)]
     lib.tbrm_add_dir_light.argtypes = [vp, P(DirLightParams), C.c_int, P(WorldParams), P(C.c_int), C.c_int]
+    lib.tbrm_add_dir_lights.argtypes = [vp, vp, C.c_int32, C.c_int, P(WorldParams), vp, P(C.c_int32)]
     lib.tbrm_change_dir_light.argtypes = [vp, P(DirLightParams), P(DirLightParams), P(WorldParams), P(C.c_int)]
     lib.tbrm_clear_light_volume.argtypes = [vp, C.c_float]
     lib.tbrm_slab_light_begin.argtypes = [vp, P(DirLightParams), P(DirLightParams), C.c_int, P(WorldParams), P(Slab), P(C.c_int32)]
@@ -348,6 +349,16 @@ class Resources:
         flag = C.c_int(0)
         check(self.lib.tbrm_add_dir_light(self.handle, C.byref(light), int(bool(added)), C.byref(world), C.byref(flag), int(gpu_sync)))
         return bool(flag.value)
+
+    def add_dir_lights(self, lights, added, world):
+        """Several AddDirLight calls as one (passes of different lights that share a cube face run two at a time). Returns
+        the order the passes ran in: [(light a, pass a, light b, pass b)], b = (-1, -1) for an unpaired pass."""
+        n = len(lights)
+        arr = (DirLightParams * max(n, 1))(*lights)
+        sched = (C.c_int32 * (8 * max(n, 1)))()
+        n_entries = C.c_int32(0)
+        check(self.lib.tbrm_add_dir_lights(self.handle, arr, n, int(bool(added)), C.byref(world), sched, C.byref(n_entries)))
+        return [tuple(sched[4 * e:4 * e + 4]) for e in range(n_entries.value)]
 
     def change_dir_light(self, old, new, world):
         flag = C.c_int(0)

@@ -251,7 +251,8 @@ void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt)
 // exchange the propagated planes between ranks.
 struct PassPlan {
     ChunkParams p{};
-    bool change = false;
+    int mode = PASS_ADD;        // PASS_ADD / PASS_CHANGE / PASS_ADD2
+    bool two_streams() const { return mode != PASS_ADD; }
     int M = 0, S = 0;           // slices per chain chunk / per occlusion span
     int D = 0;                  // slices this handle runs (the whole pass, or its slab's part of a pass along z)
     int start = 0, dir = 1;     // first of them
@@ -268,25 +269,57 @@ struct PassPlan {
 thread_local const char* g_plan_note = "";
 int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; }
 
-// Returns TBRM_ERR_UNSUPPORTED (nothing enqueued) when the pass has to take the slice-per-launch path.
-// slab: the light-volume z range this handle owns (null: everything).
-int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
-              const tbrm_slab* slab, PassPlan& plan)
+// Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
+// 16/8/4 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
+struct ChunkFit { int M = 0; TapRange tx, ty; };
+bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit)
 {
     g_plan_note = "";
-    if (force_slice_kernel()) return declined("TBRM_FORCE_SLICE_KERNEL is set");
-    const bool change = pr != nullptr;
+    if (force_slice_kernel()) return declined("TBRM_FORCE_SLICE_KERNEL is set"), false;
     const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
     TapRange tx = prev_tap_range(W, pa.prev_pixel_offset[0]), ty = prev_tap_range(H, pa.prev_pixel_offset[1]);
-    if (!tx.ok || !ty.ok) return declined("previous-slice offset out of range");
-    if (change) {
+    if (!tx.ok || !ty.ok) return declined("previous-slice offset out of range"), false;
+    if (pr) {
         const TapRange rx = prev_tap_range(W, pr->prev_pixel_offset[0]), ry = prev_tap_range(H, pr->prev_pixel_offset[1]);
-        if (!rx.ok || !ry.ok) return declined("previous-slice offset out of range");
+        if (!rx.ok || !ry.ok) return declined("previous-slice offset out of range"), false;
         tx.lo = std::min(tx.lo, rx.lo); tx.hi = std::max(tx.hi, rx.hi);
         ty.lo = std::min(ty.lo, ry.lo); ty.hi = std::max(ty.hi, ry.hi);
     }
+    // Unsheared windows: a tile keeps its 32x32 pixels for the whole chunk and its window grows towards the light by
+    // the tap range per remaining slice (the range is widened to contain 0 so the window always covers the tile).
+    tx.lo = std::min(tx.lo, 0); tx.hi = std::max(tx.hi, 0);
+    ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
+    ChunkParams p{};
+    p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
+    p.dir = pa.dir;
+    p.j0 = pa.start;
+    const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
+    fit = ChunkFit{};
+    for (int cand : {16, 8, 4}) {
+        if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
+        p.n_steps = std::min(cand, D_pass);
+        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, pr != nullptr, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
+    }
+    if (fit.M <= 0) return declined("the previous-slice taps reach too far for a 4-slice chunk"), false;
+    fit.tx = tx;
+    fit.ty = ty;
+    return true;
+}
+
+// Returns TBRM_ERR_UNSUPPORTED (nothing enqueued) when the pass has to take the slice-per-launch path.
+// slab: the light-volume z range this handle owns (null: everything).
+// pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
+// pr, both added with b_added / b_added2).
+int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+              const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f)
+{
+    g_plan_note = "";
+    ChunkFit fit;
+    if (!chunk_fit(r, pa, pr, fit)) return TBRM_ERR_UNSUPPORTED;
+    const bool change = pr != nullptr;
+    const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
     plan = PassPlan{};
-    plan.change = change;
+    plan.mode = change ? two_stream_mode : PASS_ADD;
     ChunkParams& p = plan.p;
     p.data = base.data;
     p.data_border = base.data_border;
@@ -299,25 +332,12 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     p.axis = pa.axis;
     p.W = W; p.H = H;
     p.dir = pa.dir;
-    // Unsheared windows: a tile keeps its 32x32 pixels for the whole chunk and its window grows towards the light by
-    // the tap range per remaining slice (the range is widened to contain 0 so the window always covers the tile).
-    tx.lo = std::min(tx.lo, 0); tx.hi = std::max(tx.hi, 0);
-    ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
-    p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
+    p.dx_lo = fit.tx.lo; p.dx_hi = fit.tx.hi; p.dy_lo = fit.ty.lo; p.dy_hi = fit.ty.hi;
     p.b_added = b_added;
+    p.b_added2 = b_added2;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
     if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
-
-    // chunk length: the longest of 16/8/4 slices whose window (tile + steps*growth) and staged occlusion fit in LDS
-    const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
-    int M = 0;
-    for (int cand : {16, 8, 4}) {
-        if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
-        p.n_steps = std::min(cand, D_pass);
-        p.j0 = pa.start;
-        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, change, r->lv_fmt) <= 156 * 1024) { M = cand; break; }
-    }
-    if (M <= 0) return declined("the previous-slice taps reach too far for a 4-slice chunk");
+    const int M = fit.M;
     plan.M = M;
 
     // what this handle runs: the whole pass, or (slab-partitioned) its rows of every slice / its slices of a pass along z
@@ -410,7 +430,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
         p.pass_start = plan.start;
         p.pass_slices = D;
         p.chunk_slices = S;
-        HIP_TRY(launch_occ_flags(p, change, plan.n_spans, r->stream));
+        HIP_TRY(launch_occ_flags(p, plan.mode, plan.n_spans, r->stream));
     }
     p.occ_base = r->d_occ;
     p.a.occ_next = r->d_occ + plan.occ_off_a;
@@ -444,7 +464,7 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
         p.occ_list = span_sparse && work_list ? r->d_occ_list + (size_t) sp * plan.flags_per_span : nullptr;
         p.occ_count = span_sparse && work_list ? (const int*) (r->d_occ_list + r->occ_zero_bytes) + sp : nullptr;
         if (span_sparse && !work_list) p.occ_flags = r->d_occ_zero[0] + (size_t) sp * plan.flags_per_span;
-        HIP_TRY(launch_light_occlusion(p, plan.change, r->stream));
+        HIP_TRY(launch_light_occlusion(p, plan.mode, r->stream));
     }
     const int k0 = c * M - s0; // first slice of the chunk within the span
     p.n_steps = std::min(M, D - c * M);
@@ -458,16 +478,16 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
     p.occ_list = nullptr;
     p.occ_count = nullptr;
     p.occ_flags = span_sparse ? r->d_occ_zero[0] + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
-    HIP_TRY(launch_light_chain(p, plan.change, r->lv_fmt, r->stream));
+    HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
     ++r->launches[0];
     return TBRM_OK;
 }
 
 int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr,
-                         float b_added)
+                         float b_added, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f)
 {
     PassPlan plan;
-    if (int e = plan_pass(r, base, pa, pr, b_added, nullptr, plan)) return e;
+    if (int e = plan_pass(r, base, pa, pr, b_added, nullptr, plan, two_stream_mode, b_added2)) return e;
     for (int c = 0; c < plan.n_chunks; ++c)
         if (int e = enqueue_plan_chunk(r, plan, c)) return e;
     return TBRM_OK;
@@ -528,6 +548,73 @@ int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool adde
     const PropParams base = base_prop_params(r, world);
     for (int i = 0; i < n; ++i) // breaks on weight == 0 (:65,:94)
         if (int e = enqueue_pass(r, base, passes[i], nullptr, added ? 1.0f : -1.0f)) return e;
+    return TBRM_OK;
+}
+
+// Several AddDirLightToSingleLightVolume calls as one (the multi-light optimisation of the Sunden/Ropinski
+// scheme the reference left out, Readme.md:166,186-187). The axis passes of all lights are collected; two passes of
+// different lights that leave the same cube face (same axis, same direction) share one slice loop — the data volume's
+// bricks, the plane geometry and the per-chunk overhead are paid once for both (PASS_ADD2: light a's read-modify-write,
+// then light b's on its result, exactly as if pass a and then pass b had run over the volume). Passes are taken in
+// the lights' order; each pairs with the first later pass of the same face. The order of the per-voxel updates thus
+// differs from adding the lights one after the other; `schedule` (4 ints per entry: light and pass of a, light and
+// pass of b or -1 -1) reports it so that a checker can replay it.
+int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
+                      int32_t* schedule, int32_t* n_entries)
+{
+    struct Entry { int light, pass; tbrm_light_pass p; bool done; };
+    std::vector<Entry> all;
+    for (int i = 0; i < n_lights; ++i) {
+        tbrm_light_pass passes[2];
+        int n = 0;
+        if (!host_light_passes(lights[i], world, r->lv_dims, r->desc.border_mode, passes, &n)) continue; // zero direction
+        for (int k = 0; k < n; ++k) all.push_back(Entry{i, k, passes[k], false});
+    }
+    const PropParams base = base_prop_params(r, world);
+    const float b = added ? 1.0f : -1.0f;
+    const bool pairing = !getenv("TBRM_NO_LIGHT_BATCHING");
+    int entries = 0;
+    for (size_t ia = 0; ia < all.size(); ++ia) {
+        Entry& a = all[ia];
+        if (a.done) continue;
+        a.done = true;
+        // Partner: a later pass of the same face whose previous-slice taps fall inside this pass's tap range or the other
+        // way round. Two lights in one slice loop share the per-chunk overhead and the per-slice latency of the chain, but
+        // every window has to cover both lights' taps: measured on MI355X (512^3, all pairs of the 8 config lights), a pair
+        // only pays when the union of the two tap ranges is no wider than the wider of the two — then 0.3 to 0.5 ms per
+        // paired pass (lights 1 and 7: 3.61 -> 2.53 ms for both passes); with diverging directions the wider windows and
+        // shorter chunks cost up to 0.2 ms more than they save.
+        Entry* partner = nullptr;
+        ChunkFit fa;
+        if (pairing && chunk_fit(r, a.p, nullptr, fa)) {
+            int best_area = INT32_MAX;
+            for (size_t ib = ia + 1; ib < all.size(); ++ib) {
+                Entry& b2 = all[ib];
+                ChunkFit fb, fp;
+                if (b2.done || b2.light == a.light || b2.p.face != a.p.face) continue;
+                if (!chunk_fit(r, b2.p, nullptr, fb) || !chunk_fit(r, a.p, &b2.p, fp)) continue;
+                if (getenv("TBRM_LIGHT_BATCHING_FORCE")) { partner = &b2; break; } // diagnostics: pair whatever fits
+                const int sx = fp.tx.hi - fp.tx.lo, sy = fp.ty.hi - fp.ty.lo;
+                const bool contained = sx <= std::max(fa.tx.hi - fa.tx.lo, fb.tx.hi - fb.tx.lo) && sy <= std::max(fa.ty.hi - fa.ty.lo, fb.ty.hi - fb.ty.lo);
+                if (!contained || fp.M < std::min(fa.M, fb.M)) continue;
+                if (sx * sy < best_area) { best_area = sx * sy; partner = &b2; }
+            }
+        }
+        if (schedule) {
+            schedule[4 * entries + 0] = a.light; schedule[4 * entries + 1] = a.pass;
+            schedule[4 * entries + 2] = partner ? partner->light : -1; schedule[4 * entries + 3] = partner ? partner->pass : -1;
+        }
+        ++entries;
+        if (partner) {
+            partner->done = true;
+            const int e = enqueue_pass_chunked(r, base, a.p, &partner->p, b, PASS_ADD2, b);
+            if (e == TBRM_OK) continue;
+            if (e != TBRM_ERR_UNSUPPORTED) return e;
+            if (int e2 = enqueue_pass(r, base, a.p, nullptr, b)) return e2; // the pair does not fit one launch: a, then b
+            if (int e2 = enqueue_pass(r, base, partner->p, nullptr, b)) return e2;
+        } else if (int e = enqueue_pass(r, base, a.p, nullptr, b)) return e;
+    }
+    if (n_entries) *n_entries = entries;
     return TBRM_OK;
 }
 
@@ -871,6 +958,18 @@ int tbrm_add_dir_light(tbrm_resources* r, const tbrm_dir_light_params* light, in
     return end_timed(r, 0);
 }
 
+int tbrm_add_dir_lights(tbrm_resources* r, const tbrm_dir_light_params* lights, int32_t n_lights, int added, const tbrm_world_params* world,
+                        int32_t* schedule, int32_t* n_entries)
+{
+    if (n_entries) *n_entries = 0;
+    if (!r || !world || (n_lights > 0 && !lights) || n_lights < 0) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
+    if (int e = bind(r)) return e;
+    if (int e = begin_timed(r, 0)) return e;
+    if (int e = enqueue_add_batch(r, lights, n_lights, added != 0, *world, schedule, n_entries)) return e;
+    return end_timed(r, 0);
+}
+
 int tbrm_change_dir_light(tbrm_resources* r, const tbrm_dir_light_params* old_light, const tbrm_dir_light_params* new_light,
                           const tbrm_world_params* world, int* light_added)
 {
@@ -943,7 +1042,7 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
     out->axis = pl.p.axis;
     out->dir = pl.dir;
     out->lateral = pl.lateral ? 1 : 0;
-    out->streams = pl.change ? 2 : 1;
+    out->streams = pl.two_streams() ? 2 : 1;
     out->plane_w = pl.p.W;
     out->plane_h = pl.p.H;
     out->chunk_slices = pl.M;
@@ -967,7 +1066,7 @@ int tbrm_slab_pass_plane(tbrm_resources* r, int32_t boundary, int32_t stream, vo
 {
     if (!r || !device_plane || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight");
     const PassPlan& pl = r->slab_op->plan;
-    if (boundary < 0 || boundary > pl.n_chunks || stream < 0 || stream >= (pl.change ? 2 : 1))
+    if (boundary < 0 || boundary > pl.n_chunks || stream < 0 || stream >= (pl.two_streams() ? 2 : 1))
         return fail(TBRM_ERR_INVALID_ARG, "boundary %d / stream %d out of range", boundary, stream);
     *device_plane = plan_plane(r, boundary, stream);
     return TBRM_OK;

@@ -10,6 +10,10 @@ namespace tbrm {
 enum : int { FMT_U8 = 0, FMT_U16 = 1, FMT_F32 = 2 };
 enum : int { ADDR_WRAP = 0, ADDR_CLAMP = 1, ADDR_BORDER = 2 };
 
+// what a chunked propagation pass does with its light stream(s): Add (one light, stream a), Change (a added, r removed,
+// ChangeDirLightShader.usf), or two lights added in one pass (a then r: AddDirLightShader.usf twice, sharing the slice loop)
+enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2 };
+
 constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
 constexpr int kBrickShift = 3;
 
@@ -89,7 +93,8 @@ struct ChunkParams {
     int tile_row0;          // chain: first tile row (slab-partitioned passes run only the rows of their slab; else 0)
     int roi_by0, roi_by1;   // occlusion: block rows [roi_by0, roi_by1) can be read by those tiles; the rest is never computed
     int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch, widened to contain 0
-    float b_added;
+    float b_added;          // Add / two adds: +1 / -1 for stream a
+    float b_added2;         // two adds: the same for stream r
     // empty-block hand-off: k_occ_flags marks, once per pass, every occlusion workgroup (16x16 pixels x 8 slices) whose
     // samples can only touch data bricks that map every value to opacity 0. Such a workgroup exits at once and the chain
     // stages the factor 1 - 0 for its pixels from a page of ones instead of the plane stack.
@@ -194,9 +199,9 @@ hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, 
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
-hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s); // + the work lists
-hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s);
-hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s);
+hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s); // + the work lists
+hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);
+hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);

@@ -264,10 +264,10 @@ size_t occlusion_lds_bytes(const ChunkParams& p)
 // every sample's base tap has its k_brick_empty bit set: the bit vouches for every value the 8 taps of a sample based
 // in that brick can take (the brick plus its +1 apron), so every CurrentSample is exactly 0. Workgroups with taps
 // outside the volume are never flagged (a blend with the sampler's border colour can leave both value ranges).
-template <bool CHANGE, int AXIS>
+template <int MODE, int AXIS>
 __global__ __launch_bounds__(256) void k_occ_flags(const ChunkParams p, int n_chunks)
 {
-    constexpr int NS = CHANGE ? 2 : 1;
+    constexpr int NS = MODE != PASS_ADD ? 2 : 1;
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS;
     const int per_chunk = p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
     const int id = blockIdx.x * 256 + threadIdx.x;
@@ -356,27 +356,27 @@ __global__ __launch_bounds__(1024) void k_occ_compact(const ChunkParams p)
     if (threadIdx.x == NT - 1) p.occ_count_out[c] = s_scan[NT - 1];
 }
 
-template <bool CHANGE>
+template <int MODE>
 static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t s)
 {
     const int total = n_chunks * p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
     const dim3 grid((total + 255) / 256), block(256);
-    if (p.axis == 0) hipLaunchKernelGGL((k_occ_flags<CHANGE, 0>), grid, block, 0, s, p, n_chunks);
-    else if (p.axis == 1) hipLaunchKernelGGL((k_occ_flags<CHANGE, 1>), grid, block, 0, s, p, n_chunks);
-    else hipLaunchKernelGGL((k_occ_flags<CHANGE, 2>), grid, block, 0, s, p, n_chunks);
+    if (p.axis == 0) hipLaunchKernelGGL((k_occ_flags<MODE, 0>), grid, block, 0, s, p, n_chunks);
+    else if (p.axis == 1) hipLaunchKernelGGL((k_occ_flags<MODE, 1>), grid, block, 0, s, p, n_chunks);
+    else hipLaunchKernelGGL((k_occ_flags<MODE, 2>), grid, block, 0, s, p, n_chunks);
     if (p.occ_list_out) hipLaunchKernelGGL(k_occ_compact, dim3(n_chunks), dim3(1024), 0, s, p);
     return hipGetLastError();
 }
-hipError_t launch_occ_flags(const ChunkParams& p, bool change, int n_chunks, hipStream_t s)
+hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s)
 {
-    return change ? launch_flags2<true>(p, n_chunks, s) : launch_flags2<false>(p, n_chunks, s);
+    return mode != PASS_ADD ? launch_flags2<PASS_CHANGE>(p, n_chunks, s) : launch_flags2<PASS_ADD>(p, n_chunks, s); // flags only depend on the stream count
 }
 
-template <int DFMT, bool CHANGE, int AXIS>
+template <int DFMT, int MODE, int AXIS>
 __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NS = CHANGE ? 2 : 1;
+    constexpr int NS = MODE != PASS_ADD ? 2 : 1;
     constexpr int ESZ = DFMT == FMT_U8 ? 1 : (DFMT == FMT_U16 ? 2 : 4);
     __shared__ float s_alpha[256];
     __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                     aw = clip_alpha_weight(c0, c1, c2, p.cc, p.cd, p.lv_dims);
                 }
                 bool inside = true;
-                if constexpr (!CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
+                if constexpr (MODE != PASS_CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
                 float occ = 0.0f;
                 if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
                 out[q * plane_elems] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
@@ -599,12 +599,12 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
 // wave's 8x8 patch fall on disjoint groups of eight banks. Per slice: refill the ring slot read in the previous slice
 // with the slice two ahead, issue every LDS read of the slice, compute, write, and meet ONCE at a barrier.
 
-template <int LFMT, bool CHANGE, int AXIS, int KH, int RS> // KH = halo pixels per thread: ceil((hull area - tile area) / threads)
+template <int LFMT, int MODE, int AXIS, int KH, int RS> // KH = halo pixels per thread: ceil((hull area - tile area) / threads)
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int T = kChunkTile;
-    constexpr int NS = CHANGE ? 2 : 1;
+    constexpr int NS = MODE != PASS_ADD ? 2 : 1;
     constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KS = 1 + KH; // + the owned pixel
     constexpr int PLANE = chain_plane_elems(RS);
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (!st_ok[rd]) continue;
             dma_16(p.a.plane_in + st_src[rd], window(0, 0) + st_dst[rd]);
-            if constexpr (CHANGE) dma_16(p.r.plane_in + st_src[rd], window(0, 1) + st_dst[rd]);
+            if constexpr (NS == 2) dma_16(p.r.plane_in + st_src[rd], window(0, 1) + st_dst[rd]);
         }
     }
     stage_occ(0, 0);
@@ -867,8 +867,14 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if (k == 0) { // the owned pixel: this workgroup writes its light-volume voxel
                 float nv;
                 bool write;
-                if constexpr (!CHANGE) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }           // :123-126
-                else { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }            // Change :152-154
+                if constexpr (MODE == PASS_ADD) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; } // :123-126
+                else if constexpr (MODE == PASS_CHANGE) { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; } // Change :152-154
+                else { // two lights added in one pass: light a's read-modify-write, then light r's on its result (:123-126 twice)
+                    const bool wa = fabsf(lval[0]) > 1e-3f, wb = fabsf(lval[NS - 1]) > 1e-3f;
+                    nv = wa ? through_format<LFMT>(lv_old + lval[0] * p.b_added) : lv_old;
+                    if (wb) nv = nv + lval[NS - 1] * p.b_added2;
+                    write = wa || wb;
+                }
                 if (write) {
                     if constexpr (LV_LDS) lv_tile[vi] = (uint8_t) encode_u8(nv);
                     else store_voxel<LFMT>(p.light, vi, nv);
@@ -920,7 +926,7 @@ static int current_device()
     return dev >= 0 && dev < kMaxDevices ? dev : 0;
 }
 
-template <int DFMT, bool CHANGE, int AXIS>
+template <int DFMT, int MODE, int AXIS>
 static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
 {
     const int blocks = ((p.W + kOccTile - 1) / kOccTile) * ((p.H + kOccTile - 1) / kOccTile) * ((p.n_steps + kOccDepth - 1) / kOccDepth);
@@ -928,71 +934,75 @@ static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
     size_t lds = occlusion_lds_bytes(p);
     if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
     static bool attr[kMaxDevices] = {}; // the attribute is per device
-    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_occlusion<DFMT, CHANGE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr[dev] = true; }
-    hipLaunchKernelGGL((k_light_occlusion<DFMT, CHANGE, AXIS>), grid, block, lds, s, p, (int) lds);
+    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_occlusion<DFMT, MODE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr[dev] = true; }
+    hipLaunchKernelGGL((k_light_occlusion<DFMT, MODE, AXIS>), grid, block, lds, s, p, (int) lds);
     return hipGetLastError();
 }
-template <int DFMT, bool CHANGE>
+template <int DFMT, int MODE>
 static hipError_t launch_occ2(const ChunkParams& p, hipStream_t s)
 {
-    return p.axis == 0 ? launch_occ3<DFMT, CHANGE, 0>(p, s) : (p.axis == 1 ? launch_occ3<DFMT, CHANGE, 1>(p, s) : launch_occ3<DFMT, CHANGE, 2>(p, s));
+    return p.axis == 0 ? launch_occ3<DFMT, MODE, 0>(p, s) : (p.axis == 1 ? launch_occ3<DFMT, MODE, 1>(p, s) : launch_occ3<DFMT, MODE, 2>(p, s));
 }
 template <int DFMT>
-static hipError_t launch_occ1(const ChunkParams& p, bool change, hipStream_t s)
+static hipError_t launch_occ1(const ChunkParams& p, int mode, hipStream_t s)
 {
-    return change ? launch_occ2<DFMT, true>(p, s) : launch_occ2<DFMT, false>(p, s);
+    return mode == PASS_ADD ? launch_occ2<DFMT, PASS_ADD>(p, s) : (mode == PASS_CHANGE ? launch_occ2<DFMT, PASS_CHANGE>(p, s) : launch_occ2<DFMT, PASS_ADD2>(p, s));
 }
 // computes the occlusion of the chunk described by (j0, n_steps) into {a,r}.occ_next
-hipError_t launch_light_occlusion(const ChunkParams& p, bool change, hipStream_t s)
+hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s)
 {
     if (p.n_steps <= 0) return hipSuccess;
     switch (p.data.fmt) {
-        case FMT_U8: return launch_occ1<FMT_U8>(p, change, s);
-        case FMT_U16: return launch_occ1<FMT_U16>(p, change, s);
-        default: return launch_occ1<FMT_F32>(p, change, s);
+        case FMT_U8: return launch_occ1<FMT_U8>(p, mode, s);
+        case FMT_U16: return launch_occ1<FMT_U16>(p, mode, s);
+        default: return launch_occ1<FMT_F32>(p, mode, s);
     }
 }
 
-template <int LFMT, bool CHANGE, int AXIS, int KH, int RS>
+template <int LFMT, int MODE, int AXIS, int KH, int RS>
 static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 {
     static bool attr[kMaxDevices] = {}; // the attribute is per device
-    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, CHANGE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
-    const size_t lds = chunk_lds_bytes(p, CHANGE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, CHANGE, AXIS, KH, RS>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
+    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, MODE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
+    const size_t lds = chunk_lds_bytes(p, MODE != PASS_ADD, LFMT);
+    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
-template <int LFMT, bool CHANGE, int AXIS>
+template <int LFMT, int MODE, int AXIS>
 static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
 {
     const ChunkGeom g = chunk_geometry(p);
     const int halo = g.HX * g.HY - kChunkTile * kChunkTile;
     const int kh = (halo + kChunkThreads - 1) / kChunkThreads; // <= 3 for hulls up to 64 x 64
-    if constexpr (CHANGE) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
-        if (g.RS == 40) return launch_chain4<LFMT, CHANGE, AXIS, 1, 40>(p, s);
+    if constexpr (MODE != PASS_ADD) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
+        if (g.RS == 40) return launch_chain4<LFMT, MODE, AXIS, 1, 40>(p, s);
         if (g.RS == 56) {
-            if (kh <= 1) return launch_chain4<LFMT, CHANGE, AXIS, 1, 56>(p, s);
-            if (kh == 2) return launch_chain4<LFMT, CHANGE, AXIS, 2, 56>(p, s);
-            return launch_chain4<LFMT, CHANGE, AXIS, 3, 56>(p, s);
+            if (kh <= 1) return launch_chain4<LFMT, MODE, AXIS, 1, 56>(p, s);
+            if (kh == 2) return launch_chain4<LFMT, MODE, AXIS, 2, 56>(p, s);
+            return launch_chain4<LFMT, MODE, AXIS, 3, 56>(p, s);
         }
     } else {
-        if (g.RS == 40) return launch_chain4<LFMT, CHANGE, AXIS, 1, 40>(p, s);
-        if (g.RS == 56) return launch_chain4<LFMT, CHANGE, AXIS, 3, 56>(p, s);
-        if (g.RS == 72 && kh <= 3) return launch_chain4<LFMT, CHANGE, AXIS, 3, 72>(p, s);
+        if (g.RS == 40) return launch_chain4<LFMT, MODE, AXIS, 1, 40>(p, s);
+        if (g.RS == 56) return launch_chain4<LFMT, MODE, AXIS, 3, 56>(p, s);
+        if (g.RS == 72 && kh <= 3) return launch_chain4<LFMT, MODE, AXIS, 3, 72>(p, s);
     }
     return hipErrorInvalidConfiguration; // the host's LDS check (chunk_lds_bytes) rules these shapes out
 }
-template <int LFMT, bool CHANGE>
+template <int LFMT, int MODE>
 static hipError_t launch_chain2(const ChunkParams& p, hipStream_t s)
 {
-    return p.axis == 0 ? launch_chain3<LFMT, CHANGE, 0>(p, s) : (p.axis == 1 ? launch_chain3<LFMT, CHANGE, 1>(p, s) : launch_chain3<LFMT, CHANGE, 2>(p, s));
+    return p.axis == 0 ? launch_chain3<LFMT, MODE, 0>(p, s) : (p.axis == 1 ? launch_chain3<LFMT, MODE, 1>(p, s) : launch_chain3<LFMT, MODE, 2>(p, s));
 }
 // advances every tile through the chunk (j0, n_steps), reading the occlusion planes at occ_base + {a,r}.occ_off
-hipError_t launch_light_chain(const ChunkParams& p, bool change, int lv_fmt, hipStream_t s)
+template <int LFMT>
+static hipError_t launch_chain1(const ChunkParams& p, int mode, hipStream_t s)
+{
+    return mode == PASS_ADD ? launch_chain2<LFMT, PASS_ADD>(p, s) : (mode == PASS_CHANGE ? launch_chain2<LFMT, PASS_CHANGE>(p, s) : launch_chain2<LFMT, PASS_ADD2>(p, s));
+}
+hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s)
 {
     if (p.n_steps <= 0 || p.tiles_x <= 0 || p.tiles_y <= 0) return hipSuccess;
-    if (lv_fmt == FMT_U8) return change ? launch_chain2<FMT_U8, true>(p, s) : launch_chain2<FMT_U8, false>(p, s);
-    return change ? launch_chain2<FMT_F32, true>(p, s) : launch_chain2<FMT_F32, false>(p, s);
+    return lv_fmt == FMT_U8 ? launch_chain1<FMT_U8>(p, mode, s) : launch_chain1<FMT_F32>(p, mode, s);
 }
 
 } // namespace tbrm

@@ -92,6 +92,14 @@ int main(int argc, char** argv)
     for (size_t i = 3; i < img.size(); i += 4) oct_a += img[i];
     std::printf("octree mean_alpha=%.6f rebuild_pending=%d\n", oct_a / (64 * 64), volume.bRequestedOctreeRebuild ? 1 : 0);
     volume.SwitchRenderer(tbrm_plugin::ERaymarchMaterial::Lit);
+    // batched reset: all lights through one tbrm_add_dir_lights call; the frame it lights is the same up to UNORM8 rounding ties
+    volume.bBatchLightsOnReset = true;
+    volume.Tick(0.016f); // SwitchRenderer(Lit) requested a recompute
+    std::vector<float> img2((size_t) 64 * 64 * 4);
+    if (!volume.RenderLit(cam, img2.data())) { std::printf("error=%s\n", tbrm_last_error()); return 6; }
+    double sum_b = 0;
+    for (size_t i = 3; i < img2.size(); i += 4) sum_b += img2[i];
+    std::printf("batched_reset resets=%d adds=%d mean_alpha=%.6f\n", volume.Stats.Resets, volume.Stats.LightAdds, sum_b / (64 * 64));
     uint64_t counters[3];
     tbrm_launch_counters(volume.RaymarchResources.Handle, counters);
     std::printf("launches chunk=%llu slice=%llu raymarch=%llu\n", (unsigned long long) counters[0], (unsigned long long) counters[1], (unsigned long long) counters[2]);

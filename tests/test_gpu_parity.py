@@ -425,3 +425,66 @@ def test_random_cameras_windows_and_modes_against_oracle(gpu, oracle_mod, ray_la
             mip = int(rng.integers(0, 4))
             worst = max(worst, float(np.abs(res.raymarch_octree(cam, tile, rp, world, mip) - orc.raymarch_octree(cam, tile, rp, world, mip)).max()))
         assert worst <= TIGHT_TOL
+
+
+# ---- batched multi-light add -------------------------------------------------------------------
+
+@pytest.mark.parametrize("light_32bit", [False, True])
+@pytest.mark.parametrize("dims", [(48, 40, 56), (64, 64, 64)])
+def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, kernel_variant, monkeypatch):
+    """tbrm_add_dir_lights pairs passes of different lights that share a cube face; the oracle replays the reported pass
+    order one pass at a time. UNORM8: bit-exact."""
+    res, orc = make_pair(gpu, oracle_mod, dims, np.uint16, light_32bit, seed=0x5EED0500)
+    world = S.default_world()
+    # the 8 config lights, a bundle of nearly parallel lights (what pairs up: their taps fall inside one another's range),
+    # a zero direction and an axis-aligned light
+    lights = [S.light(i) for i in range(8)] + [abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], a), 0.1) for a in (2.0, -3.0, 4.0)]
+    lights += [abi.DirLightParams((0, 0, 0), 0.3), abi.DirLightParams((0, 0, -1), 0.2), abi.DirLightParams((0.02, 0.01, -1), 0.2)]
+    with res:
+        res.clear_light_volume(0.0)
+        orc.clear_light_volume(0.0)
+        sched = res.add_dir_lights(lights, True, world)
+        n_passes = sum(2 if b >= 0 else 1 for _, _, b, _ in sched)
+        assert n_passes == sum(abi.host_light_passes(l, world, res.light_dims)[1] for l in lights)
+        if kernel_variant == "chunk":
+            assert sum(b >= 0 for _, _, b, _ in sched) >= 2, f"fewer than two pairs: {sched}"
+        else:  # the slice-per-launch kernel has no two-light form
+            assert all(b < 0 for _, _, b, _ in sched)
+        for la, pa, lb, pb in sched:
+            assert orc.add_dir_light_pass(lights[la], True, world, pa) == 1
+            if lb >= 0:
+                assert lb != la and orc.add_dir_light_pass(lights[lb], True, world, pb) == 1
+        assert_light_equal(res, orc)
+        batched = res.download_light_volume()
+        # light by light (the reference's order): the same sum; UNORM8 may differ by one code at fp32 rounding ties
+        res.clear_light_volume(0.0)
+        for l in lights:
+            res.add_dir_light(l, True, world)
+        seq = res.download_light_volume()
+        if light_32bit:
+            np.testing.assert_allclose(batched, seq, rtol=0, atol=1e-5)
+        else:
+            d = np.abs(batched.astype(int) - seq.astype(int))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 2e-3 * d.size, (int(d.max()), int(np.count_nonzero(d)))
+        # the switch that turns pairing off: the reference's order, bit for bit
+        monkeypatch.setenv("TBRM_NO_LIGHT_BATCHING", "1")
+        res.clear_light_volume(0.0)
+        sched = res.add_dir_lights(lights, True, world)
+        assert all(b < 0 for _, _, b, _ in sched)
+        assert np.array_equal(res.download_light_volume(), seq)
+
+
+def test_batched_light_removal_matches_oracle_replay(gpu, oracle_mod):
+    res, orc = make_pair(gpu, oracle_mod, (56, 56, 56), np.uint16, False, seed=0x5EED0501)
+    world = S.default_world()
+    lights = [S.light(i) for i in range(6)]
+    with res:
+        for l in lights:
+            res.add_dir_light(l, True, world)
+            orc.add_dir_light(l, True, world)
+        sched = res.add_dir_lights(lights[1:5], False, world)  # Added = false for a subset
+        for la, pa, lb, pb in sched:
+            orc.add_dir_light_pass(lights[1 + la], False, world, pa)
+            if lb >= 0:
+                orc.add_dir_light_pass(lights[1 + lb], False, world, pb)
+        assert_light_equal(res, orc)

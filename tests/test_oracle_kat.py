@@ -288,3 +288,24 @@ def test_octree_pyramid_known_answers(oracle_mod):
         img = orc.raymarch_octree(cam, abi.Tile(0, 0, 1, 1), abi.RaymarchParams(50.0, -1, False), world, mip)
         assert img[0, 0, 3] == pytest.approx(want_a, abs=2e-5)
         assert img[0, 0, :3] == pytest.approx(np.array([0.25, 0.5, 1.0]) * want_a, abs=2e-5)
+
+
+def test_pass_by_pass_add_equals_add_dir_light(oracle_mod):
+    """orc_add_dir_light_pass (the replay hook for batched multi-light adds) run for pass 0, 1 equals orc_add_dir_light."""
+    from conftest import small_volume
+    from tbraymarcherplugin_amd import abi, synthetic as S
+
+    vol = small_volume((20, 24, 28), np.uint16)
+    scenes = [oracle_mod.OracleScene(vol) for _ in range(2)]
+    lut = abi.color_curve_to_lut(S.tf_keys("A"))
+    for sc in scenes:
+        sc.set_tf_lut(lut)
+        sc.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+    world = S.default_world()
+    for i in range(4):
+        light = S.light(i)
+        n = scenes[0].add_dir_light(light, True, world)
+        ran = [scenes[1].add_dir_light_pass(light, True, world, k) for k in range(3)]
+        assert ran == [1] * n + [0] * (3 - n)
+        assert np.array_equal(scenes[0].light, scenes[1].light)
+    assert scenes[1].add_dir_light_pass(abi.DirLightParams((0, 0, 0), 1.0), True, world, 0) == 0
