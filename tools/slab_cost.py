@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU time of ONE slab's share of a fused ChangeDirLight at BASELINE config 3's size, for 1/2/4/8 slabs, measured on one
+"""GPU time of ONE slab's share of a fused ChangeDirLight at BASELINE config 3's size (or argv[1]^3: 1024 = config 4), for 1/2/4/8 slabs, measured on one
 GPU: the chunks of one member are enqueued back to back (no exchange — the planes' halo rows then hold stale values, which
 changes no timing) and timed with HIP events on the handle's stream. Also prints the bytes a real run exchanges per
 operation (from the emulated run with every slab in one process). Output: a table for DESIGN.md §6."""
@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tbraymarcherplugin_amd import abi, slabs, synthetic as S  # noqa: E402
 
-n = 512
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 dims = (n, n, n)
 dev = torch.device("cuda", 0)
 vol = S.make_volume_torch(dims, np.uint16, S.seed_for_config(3), dev)
