@@ -99,6 +99,7 @@ struct FBasicRaymarchRenderingResources {
     tbrm_resources* Handle = nullptr; // DataVolumeTextureRef + TFTextureRef + LightVolumeRenderTarget + XYZReadWriteBuffers
     bool LightVolumeHalfResolution = false;
     FWindowingParameters WindowingParameters;
+    int SizeX = 0, SizeY = 0, SizeZ = 0; // DataVolumeTextureRef->GetSizeX/Y/Z()
 };
 using FRaymarchResources = FBasicRaymarchRenderingResources;
 
@@ -162,6 +163,35 @@ struct URaymarchUtils { // RaymarchUtils.h:33-93; all static, like the Blueprint
     {
         OutTexture.assign(256 * 4, 0.0f);
         tbrm_make_default_tf_lut(OutTexture.data());
+    }
+    // The Blueprint-pure helpers (RaymarchUtils.cpp:219-252)
+    static void GetVolumeTextureDimensions(const FBasicRaymarchRenderingResources* Resources, int32_t Dimensions[3])
+    {
+        Dimensions[0] = Resources ? Resources->SizeX : 0;
+        Dimensions[1] = Resources ? Resources->SizeY : 0;
+        Dimensions[2] = Resources ? Resources->SizeZ : 0;
+    }
+    // FTransform::ToMatrixWithScale / ToMatrixNoScale: row-vector convention, rows 0-2 = scaled rotation axes, row 3 = translation
+    static void TransformToMatrix(const FTransform& Transform, double OutMatrix[4][4], bool WithScaling)
+    {
+        const FQuat& q = Transform.rotation;
+        const double sx = WithScaling ? Transform.scale3d.x : 1.0, sy = WithScaling ? Transform.scale3d.y : 1.0, sz = WithScaling ? Transform.scale3d.z : 1.0;
+        const double x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+        const double xx = q.x * x2, yy = q.y * y2, zz = q.z * z2, xy = q.x * y2, xz = q.x * z2, yz = q.y * z2, wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+        const double m[4][4] = {{(1.0 - (yy + zz)) * sx, (xy + wz) * sx, (xz - wy) * sx, 0.0},
+                                {(xy - wz) * sy, (1.0 - (xx + zz)) * sy, (yz + wx) * sy, 0.0},
+                                {(xz + wy) * sz, (yz - wx) * sz, (1.0 - (xx + yy)) * sz, 0.0},
+                                {Transform.translation.x, Transform.translation.y, Transform.translation.z, 1.0}};
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) OutMatrix[r][c] = m[r][c];
+    }
+    static void LocalToTextureCoords(FVector LocalCoords, FVector& TextureCoords) // local cube [-1,1]^3 -> texture [0,1]^3
+    {
+        TextureCoords = FVector{LocalCoords.x / 2.0 + 0.5, LocalCoords.y / 2.0 + 0.5, LocalCoords.z / 2.0 + 0.5};
+    }
+    static void TextureToLocalCoords(FVector TextureCoords, FVector& LocalCoords)
+    {
+        LocalCoords = FVector{(TextureCoords.x - 0.5) * 2.0, (TextureCoords.y - 0.5) * 2.0, (TextureCoords.z - 0.5) * 2.0};
     }
 };
 
@@ -399,7 +429,9 @@ private:
         if (tbrm_resources_create(&d, &RaymarchResources.Handle) != TBRM_OK) {
             std::fprintf(stderr, "Tried to initialize Raymarch resources: %s\n", tbrm_last_error());
             RaymarchResources.Handle = nullptr;
+            return;
         }
+        RaymarchResources.SizeX = X; RaymarchResources.SizeY = Y; RaymarchResources.SizeZ = Z;
     }
     void WindowingChanged()
     {

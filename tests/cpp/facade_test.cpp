@@ -100,6 +100,17 @@ int main(int argc, char** argv)
     double sum_b = 0;
     for (size_t i = 3; i < img2.size(); i += 4) sum_b += img2[i];
     std::printf("batched_reset resets=%d adds=%d mean_alpha=%.6f\n", volume.Stats.Resets, volume.Stats.LightAdds, sum_b / (64 * 64));
+    // Blueprint-pure helpers
+    int32_t vd[3];
+    tbrm_plugin::URaymarchUtils::GetVolumeTextureDimensions(&volume.RaymarchResources, vd);
+    FVector tc, lc;
+    tbrm_plugin::URaymarchUtils::LocalToTextureCoords(FVector{-1, 0, 0.5}, tc);
+    tbrm_plugin::URaymarchUtils::TextureToLocalCoords(tc, lc);
+    tbrm_transform tr{{0, 0, std::sin(0.25 * 3.14159265358979323846), std::cos(0.25 * 3.14159265358979323846)}, {1, 2, 3}, {2, 2, 2}}; // 90 deg about z
+    double mtx[4][4];
+    tbrm_plugin::URaymarchUtils::TransformToMatrix(tr, mtx, true);
+    std::printf("helpers dims=%d,%d,%d tex=%.2f,%.2f,%.2f local=%.2f,%.2f,%.2f row0=%.3f,%.3f,%.3f row3=%.0f,%.0f,%.0f\n", vd[0], vd[1], vd[2], tc.x, tc.y, tc.z,
+                lc.x, lc.y, lc.z, mtx[0][0], mtx[0][1], mtx[0][2], mtx[3][0], mtx[3][1], mtx[3][2]);
     uint64_t counters[3];
     tbrm_launch_counters(volume.RaymarchResources.Handle, counters);
     std::printf("launches chunk=%llu slice=%llu raymarch=%llu\n", (unsigned long long) counters[0], (unsigned long long) counters[1], (unsigned long long) counters[2]);

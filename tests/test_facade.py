@@ -38,6 +38,8 @@ def test_facade_tick_policy_on_gpu(tmp_path, gpu):
     assert 0.05 < hit < 1.0 and 0.0 <= grey <= 1.0                       # SwitchRenderer(Intensity): the slice view
     oct_a = float(lines["octree"].split("mean_alpha=")[1].split()[0])
     assert 0.01 < oct_a < 0.95 and "rebuild_pending=0" in lines["octree"]  # SwitchRenderer(Octree): pyramid built, level 1 marched
+    # X axis of a 90 degree rotation about z, scaled by 2 -> (0, 2, 0); translation in row 3
+    assert lines["helpers"] == "dims=32,32,32 tex=0.00,0.50,0.75 local=-1.00,0.00,0.50 row0=0.000,2.000,0.000 row3=1,2,3"
     assert lines["batched_reset"].startswith("resets=4 adds=12 ")          # bBatchLightsOnReset: one tbrm_add_dir_lights call
     assert abs(float(lines["batched_reset"].split("mean_alpha=")[1]) - mean_a) < 1e-6  # alpha does not depend on the light
     assert "slice=0" in lines["launches"] and "raymarch=4" in lines["launches"]  # two lit + one intensity + one octree frame
