@@ -205,6 +205,7 @@ def main():
         else:
             dist.all_gather_into_tensor(full, part)
 
+    lib_stream = torch.cuda.ExternalStream(res.stream(), device=device)  # the library's HIP stream, as torch sees it
     angle = [0.0] * len(lights)
     ms_illum, ms_ray = [], []
     last = [0]  # buffer index of the most recent frame
@@ -222,19 +223,25 @@ def main():
                 res.change_dir_light(lights[li], new, world)
             lights[li] = new
         b = k & 1
-        if pending[b] is not None:  # the gather that last read outs[b] / wrote gathers[b]
-            pending[b].wait()
-            torch.cuda.current_stream().synchronize()
+        # Device-side ordering only, no host synchronisation inside a step: with torch's current stream set to the library's
+        # stream, RCCL waits for the tile through an event on that stream, and wait() makes that stream (not the host) wait
+        # for the gather that last read outs[b] / wrote gathers[b] before the raymarch overwrites the tile.
+        if pending[b] is not None:
+            with torch.cuda.stream(lib_stream):
+                pending[b].wait()
             pending[b] = None
         res.raymarch_lit_device(cam, tile, rp, world, outs[b].data_ptr())
         if dist is not None:
-            res.flush()  # the tile must be complete before RCCL reads it
             if one_gpu_dry_run:
+                res.flush()
                 parts = [torch.empty(outs[b].shape, dtype=outs[b].dtype) for _ in range(n_gpus)]
                 dist.all_gather(parts, outs[b].cpu())
                 gathers[b].copy_(torch.stack(parts))
             else:
-                pending[b] = dist.all_gather_into_tensor(gathers[b], outs[b], async_op=True)
+                if os.environ.get("TBRM_BENCH_HOST_SYNC") == "1":  # A/B: drain the library's stream on the host before the gather
+                    res.flush()
+                with torch.cuda.stream(lib_stream):
+                    pending[b] = dist.all_gather_into_tensor(gathers[b], outs[b], async_op=True)
         last[0] = b
         if record:
             if not args.raymarch_only and slab_member is None:
