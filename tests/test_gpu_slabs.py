@@ -92,6 +92,31 @@ def test_slab_partitioned_lights_equal_single_handle(gpu, n_slabs, dims, half_re
             h.close()
 
 
+@pytest.mark.parametrize("switch", ["TBRM_NO_OCC_LIST", "TBRM_NO_SPARSE_OCC", "TBRM_CHUNK_STEPS=4"])
+def test_slabs_with_the_diagnostic_kernel_paths(gpu, monkeypatch, switch):
+    """the occlusion launch without the work list / without the empty-block flags (block rows outside the slab's reach are
+    then cut inside the kernel), and 4-slice chunks (four times the exchanges)"""
+    name, _, value = switch.partition("=")
+    monkeypatch.setenv(name, value or "1")
+    _, _, _, handles = make_handles(3, (72, 56, 64), np.uint16)
+    full, parts = handles[0], handles[1:]
+    members, fabric, _ = slab_setup(parts, 2)
+    world = S.default_world()
+    try:
+        for i, (d, inten) in enumerate(LIGHTS[:5]):
+            light = abi.DirLightParams(d, inten)
+            full.add_dir_light(light, True, world)
+            slabs.add_dir_light(members, fabric, light, True, world)
+        old = abi.DirLightParams(*LIGHTS[1])
+        new = abi.DirLightParams(S.rotate_z(LIGHTS[1][0], 5.0), LIGHTS[1][1])
+        full.change_dir_light(old, new, world)
+        slabs.change_dir_light(members, fabric, old, new, world)
+        assert_slabs_equal(full, members, switch)
+    finally:
+        for h in handles:
+            h.close()
+
+
 def test_slab_lights_equal_oracle_and_render(gpu, oracle_mod):
     """End to end as config 4 words it: slab-partitioned reset, light-volume gather, frame in image tiles — against the oracle."""
     from tbraymarcherplugin_amd import sharding
