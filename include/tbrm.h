@@ -277,6 +277,19 @@ TBRM_API int tbrm_raymarch_lit_device(tbrm_resources* res, const tbrm_camera* ca
                                       const tbrm_raymarch_params* params, const tbrm_world_params* world,
                                       const float* device_scene_depth, float* device_out_rgba);
 
+/* One stage of a frame marched slab by slab over several GPUs (the raymarch counterpart of tbrm_slab_*): the handle
+ * accumulates, into the per-pixel LightEnergy state of the tile (device_state_rgba, in place, zeros before the first
+ * stage), exactly those samples of every ray whose position lies in its light-volume slices [z_begin, z_end). Along a
+ * ray the slabs come in order, so the stages run in that order: direction > 0 takes the rays that travel towards +z in
+ * volume space (run the handles in ascending slab order), direction < 0 the others (descending order); the state of a
+ * tile passes from handle to handle between stages (16 bytes per pixel). Every sample, its position and the 0.95 early
+ * exit are those of the unpartitioned march: after the last stage of both sweeps the state IS tbrm_raymarch_lit_device's
+ * frame, bit for bit. direction == 0: all rays (a single handle owning everything reproduces the plain march). */
+TBRM_API int tbrm_raymarch_lit_slab_device(tbrm_resources* res, const tbrm_camera* camera, const tbrm_tile* tile,
+                                           const tbrm_raymarch_params* params, const tbrm_world_params* world,
+                                           const float* device_scene_depth, float* device_state_rgba,
+                                           const tbrm_slab* slab, int direction);
+
 /* The Intensity render mode (ERaymarchMaterial::Intensity, SwitchRenderer RaymarchVolume.cpp:786-800):
  * PerformRaymarchCubeSetup + PerformWindowedIntensityRaymarch (WindowedRaymarchMaterials.usf:187-242) — per pixel the
  * windowed intensity (clamped TF position, as RGB with alpha 1) of the first sample the clipping plane does not remove,

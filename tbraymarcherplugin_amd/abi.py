@@ -120,7 +120,7 @@ SYMBOLS = [
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
     "tbrm_add_dir_light", "tbrm_add_dir_lights", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_slab_light_begin", "tbrm_slab_pass_begin", "tbrm_slab_pass_chunk", "tbrm_slab_pass_plane",
-    "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
+    "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_lit_slab_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
@@ -175,6 +175,7 @@ def load():
     lib.tbrm_slab_pass_plane.argtypes = [vp, C.c_int32, C.c_int32, P(vp)]
     lib.tbrm_raymarch_lit.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
     lib.tbrm_raymarch_lit_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
+    lib.tbrm_raymarch_lit_slab_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp, P(Slab), C.c_int]
     lib.tbrm_raymarch_intensity.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp]
     lib.tbrm_raymarch_intensity_device.argtypes = [vp, P(Camera), P(Tile), P(RaymarchParams), P(WorldParams), vp, vp]
     lib.tbrm_generate_octree.argtypes = [vp]
@@ -396,6 +397,11 @@ class Resources:
     def raymarch_lit_device(self, camera, tile, params, world, out_ptr, depth_ptr=None):
         check(self.lib.tbrm_raymarch_lit_device(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
                                                 C.c_void_p(depth_ptr), C.c_void_p(out_ptr)))
+
+    def raymarch_lit_slab_device(self, camera, tile, params, world, state_ptr, slab, direction, depth_ptr=None):
+        """one stage of a frame marched slab by slab: accumulates this slab's samples into the state (tile.h x tile.w x 4 floats)"""
+        check(self.lib.tbrm_raymarch_lit_slab_device(self.handle, C.byref(camera), C.byref(tile), C.byref(params), C.byref(world),
+                                                     depth_ptr, state_ptr, C.byref(slab), int(direction)))
 
     def raymarch_intensity(self, camera, tile, params, world):
         out = np.empty((tile.h, tile.w, 4), dtype=np.float32)

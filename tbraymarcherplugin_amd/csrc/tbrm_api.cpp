@@ -1104,6 +1104,34 @@ int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tb
     return end_timed(r, 1);
 }
 
+int tbrm_raymarch_lit_slab_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
+                                  const tbrm_world_params* world, const float* device_scene_depth, float* device_state_rgba,
+                                  const tbrm_slab* slab, int direction)
+{
+    if (!r || !cam || !tile || !rp || !world || !device_state_rgba || !slab) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
+    if (slab->z_begin < 0 || slab->z_end > r->lv_dims[2] || slab->z_begin >= slab->z_end)
+        return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep", slab->z_begin, slab->z_end, r->lv_dims[2]);
+    if (int e = bind(r)) return e;
+    RayParams p;
+    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
+    p.depth = device_scene_depth;
+    p.out = device_state_rgba;
+    p.slab_on = 1;
+    p.slab_z0 = slab->z_begin;
+    p.slab_z1 = slab->z_end;
+    p.slab_dir = direction > 0 ? 1 : (direction < 0 ? -1 : 0);
+    if (rp->enable_skipping) {
+        if (int e = ensure_skipping(r)) return e;
+        p.empty_bits = r->d_empty;
+        p.skip_dist = r->d_dist[0];
+    }
+    if (int e = begin_timed(r, 1)) return e;
+    HIP_TRY(launch_raymarch(p, r->stream));
+    ++r->launches[2];
+    return end_timed(r, 1);
+}
+
 int tbrm_raymarch_lit(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
                       const tbrm_world_params* world, float* host_out_rgba)
 {

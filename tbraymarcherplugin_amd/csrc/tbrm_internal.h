@@ -142,6 +142,7 @@ struct RayParams {
     const uint8_t* skip_dist;   // per brick: Chebyshev distance (bricks, capped) to the nearest non-empty brick; null when skipping is off
     int bnx, bny, bnz;  // brick grid
     unsigned long long* sample_counter; // count kernel only
+    int slab_on, slab_z0, slab_z1, slab_dir; // slab stage of the lit march: owned light-volume slices, sweep direction (+1 / -1 / 0: all rays)
     const uint16_t* octree;     // octree march only: the level marched (dense, x fastest)
     int oct_dims[3];            // its dimensions
     float oct_depth0;           // depth of octree level 0 (the z coordinate is rescaled by data depth / this)

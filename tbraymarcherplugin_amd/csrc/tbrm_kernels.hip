@@ -143,7 +143,13 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // (colour*alpha, alpha) through LDS and each replays AccumulateLightEnergy over the L samples in ray order, which also
 // decides the early exit exactly where the reference takes it. Arithmetic per sample and per accumulation step is the
 // reference's; a lane reaches its sample position by performing every addition of the ray up to it.
-template <int DFMT, int LFMT, int DMODE, int kRayLanes>
+//
+// SLAB: one stage of a frame marched slab by slab (tbrm_raymarch_lit_slab_device). The handle owns light-volume slices
+// [slab_z0, slab_z1); a sample belongs to the slab its (saturated) z position falls in, and along a ray those slabs come
+// in order. The stage takes the ray's LightEnergy as the slabs before it left it (p.out, in place), accumulates the
+// samples it owns exactly where the unpartitioned loop would, and hands the state on. Positions are still reached by
+// performing every addition of the ray, so every sample, and the early exit, are bit for bit those of the whole march.
+template <int DFMT, int LFMT, int DMODE, int kRayLanes, bool SLAB = false>
 __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6 waves per SIMD (80 VGPRs): measured 3-8 % faster than 5 or 8
 {
     static_assert(kRayLanes == 4 || kRayLanes == 8, "instantiated for 4 and 8 lanes per ray");
@@ -195,6 +201,15 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
 
     float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f; // LightEnergy, replicated in the 8 lanes of the ray
     bool done = n_samples == 0;
+    bool mine = valid; // SLAB: this stage's sweep direction handles the ray (rays with local dz >= 0 go up through the slabs)
+    if constexpr (SLAB) {
+        mine = valid && (p.slab_dir == 0 || (p.slab_dir > 0) == (ray.lcv[2] >= 0.0f));
+        if (mine) {
+            const float4 in = reinterpret_cast<const float4*>(p.out)[(size_t) j * p.tile_w + i];
+            le0 = in.x; le1 = in.y; le2 = in.z; le3 = in.w;
+            done = done || le3 == 1.0f; // the early exit was taken in a slab before this one (it leaves alpha at exactly 1)
+        } else done = true;
+    }
     int adds = 0; // full-step additions this lane has applied to its position
     float4* const xs = s_x + (threadIdx.x & ~(kRayLanes - 1)); // the ray's 8 exchange slots
 
@@ -220,6 +235,10 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         // the sample: everything of the loop body up to AccumulateLightEnergy
         float4 x = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
         bool live = has && idx > safe_until && !(p.clip_mode && is_clipped(q0, q1, q2, p.cc, p.cd));
+        if constexpr (SLAB) { // only the samples of this handle's slab
+            const int zi = min((int) (saturate_(q2) * lnz), p.lv_dims[2] - 1);
+            live = live && zi >= p.slab_z0 && zi < p.slab_z1;
+        }
         int ix = 0, iy = 0, iz = 0;
         float fx = 0.0f, fy = 0.0f, fz = 0.0f;
         if (live) {
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         }
         if (base + kRayLanes >= n_samples) done = true;
     }
-    if (valid && b == 0) reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
+    if ((SLAB ? mine : valid) && b == 0) reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
 }
 
 template <int DFMT, int LFMT, int RL>
@@ -301,6 +320,11 @@ static hipError_t launch_ray3(const RayParams& p, hipStream_t s)
 {
     constexpr int BW = 8, BH = RL == 4 ? 8 : 4; // 4 waves of 4x4 / 4x2 rays
     const dim3 grid((p.tile_w + BW - 1) / BW, (p.tile_h + BH - 1) / BH), block(256);
+    if (p.slab_on) {
+        if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP, RL, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP, RL, true>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
     if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP, RL>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP, RL>), grid, block, 0, s, p);
     return hipGetLastError();

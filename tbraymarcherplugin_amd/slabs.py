@@ -77,6 +77,10 @@ class DeviceSlab:
     def sync(self):
         self.res.flush()
 
+    def render_stage(self, camera, tile, params, world, state, direction):
+        """accumulates this slab's samples of every ray of the sweep into `state` (a [tile.h, tile.w, 4] float32 device tensor)"""
+        self.res.raymarch_lit_slab_device(camera, tile, params, world, state.data_ptr(), self._slab, direction)
+
     def stream_context(self):
         """torch's current stream := the handle's stream, so that torch copies / RCCL operations are ordered with the
         library's kernels without a host synchronisation."""
@@ -208,6 +212,30 @@ def reset_all_lights(members, fabric, lights, world, clear):
         clear(m)
     for light in lights:
         add_dir_light(members, fabric, light, True, world)
+
+
+# ---- the lit frame, slab by slab ---------------------------------------------------------------------------------------
+
+def render_lit(members, fabric, camera, tile, params, world, new_state):
+    """A frame marched slab by slab (tbrm_raymarch_lit_slab_device): every ray's samples are accumulated by the slab they
+    lie in, in ray order — one sweep up through the slabs for the rays that travel towards +z in volume space, one sweep
+    down for the others — and the per-pixel LightEnergy state travels with the sweep (16 bytes per pixel per hop). The
+    result is bit for bit the unpartitioned frame. new_state() -> a zeroed [tile.h, tile.w, 4] float32 tensor on the
+    member's device. Returns the frame on the rank that owns slab 0, None elsewhere."""
+    by_index = {m.slab_index: m for m in members}
+    n = len(fabric.owner_of_slab)
+    states = {m.slab_index: new_state() for m in members}
+    order = [(k, +1) for k in range(n)] + [(k, -1) for k in range(n - 1, -1, -1)]
+    prev = None
+    for k, direction in order:
+        if prev is not None and prev != k:
+            fabric.move(prev, lambda prev=prev: states[prev], k, lambda k=k: states[k])
+            fabric.complete(members)
+        m = by_index.get(k)
+        if m is not None:
+            m.render_stage(camera, tile, params, world, states[k], direction)
+        prev = k
+    return states.get(0)
 
 
 def make_fabric(z_bounds, owner_of_slab=None, rank=0, p2p=None, sync_local=True):

@@ -217,3 +217,63 @@ def test_full_size_slabs_equal_single_handle(gpu):
                     p.close()
     finally:
         full.close()
+
+
+# ---- the lit frame, slab by slab ---------------------------------------------------------------------------------------
+
+def _lit_handles(n_handles, dims, dtype, addr, half_res=False, light_32bit=False):
+    import torch
+
+    vol = small_volume(dims, dtype, 0x5EED0402)
+    lut = abi.color_curve_to_lut(S.tf_keys("A"))
+    out = []
+    for _ in range(n_handles):
+        res = abi.Resources(dims, abi.DTYPE_FMT[np.dtype(dtype)], light_32bit, half_res, 0, addr)
+        res.upload_volume(vol)
+        res.set_tf_lut(lut)
+        res.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+        res.clear_light_volume(0.0)
+        for i in range(3):
+            res.add_dir_light(S.light(i), True, S.default_world())
+        out.append(res)
+    return out
+
+
+@pytest.mark.parametrize("addr", [abi.ADDRESS_WRAP, abi.ADDRESS_CLAMP])
+@pytest.mark.parametrize("n_slabs,dims,half_res", [(2, (72, 56, 64), False), (4, (48, 64, 128), False), (2, (64, 64, 128), True)])
+def test_frame_marched_slab_by_slab_is_the_plain_frame(gpu, addr, n_slabs, dims, half_res, ray_lanes_env):
+    """tbrm_raymarch_lit_slab_device: each handle accumulates only its slab's samples, the state travels up and down
+    through the slabs — bit-identical to tbrm_raymarch_lit for cameras outside, inside and grazing the volume, with a clip
+    plane, jitter, tiles, skipping on and off."""
+    import torch
+
+    handles = _lit_handles(n_slabs, dims, np.uint16, addr, half_res)
+    members, fabric, _ = slab_setup(handles, n_slabs)
+    dev = torch.device("cuda", 0)
+    try:
+        eyes = [(-145, -95, 80), (130, 40, -160), (10, -5, 190), (0.001, 300, 2), (20, -10, 15), (-60, -60, -60)]
+        worlds = [S.default_world(), abi.make_world(abi.identity_transform(100.0, (5, -3, 2), (0.1, 0.2, -0.1, 0.97)), (10, 0, 5), (0.3, 0.2, -0.93))]
+        case = 0
+        for eye in eyes:
+            for world in worlds:
+                case += 1
+                w, h = (72, 48) if case % 2 else (64, 64)
+                cam = abi.look_at_camera(np.array(eye, dtype=float), (3.0, -2.0, 1.0), (0.0, 0.0, 1.0), 50.0, w, h)
+                rp = abi.RaymarchParams(float(40 + 23 * case), (case % 3) - 1, bool(case % 2))
+                tile = abi.Tile(0, 0, w, h, 1) if case % 3 else abi.Tile(8, 8, w - 16, 16, 2)
+                want = handles[0].raymarch_lit(cam, tile, rp, world)
+                got = slabs.render_lit(members, fabric, cam, tile, rp, world,
+                                       lambda: torch.zeros((tile.h, tile.w, 4), dtype=torch.float32, device=dev))
+                torch.cuda.synchronize()
+                got = got.cpu().numpy()
+                assert np.array_equal(got, want), f"eye {eye} case {case}: max |d| = {np.abs(got - want).max()}"
+                assert want[..., 3].max() > 0.0 or case > 0
+    finally:
+        for hd in handles:
+            hd.close()
+
+
+@pytest.fixture(params=["4", "8"])
+def ray_lanes_env(request, monkeypatch):
+    monkeypatch.setenv("TBRM_RAY_LANES", request.param)
+    return request.param
