@@ -114,6 +114,12 @@ class ToyMember:
     def sync(self):
         pass
 
+    def render_stage(self, camera, tile, params, world, state, direction):
+        """stand-in for a slab's stage of the lit march: even columns belong to the upward sweep, odd ones to the downward
+        sweep; a stage appends its slab number as a decimal digit, so the final value spells the order of the stages"""
+        cols = slice(0, None, 2) if direction > 0 else slice(1, None, 2)
+        state[:, cols, :] = state[:, cols, :] * 10.0 + (self.slab_index + 1)
+
 
 PASSES = {"passes": [{"axis": 0, "dir": 1, "du": -1, "dv": 1}, {"axis": 2, "dir": -1, "du": 1, "dv": -1},
                      {"axis": 1, "dir": -1, "du": 0, "dv": -1}, {"axis": 2, "dir": 1, "du": -1, "dv": 0}]}
@@ -174,6 +180,8 @@ def _worker(rank, world_size, port, out_dir):
     slabs.light_operation([me], fabric, T.PASSES, T.PASSES, True, None)
     got = me.light[me.z_begin:me.z_end]
     ok = bool(torch.isfinite(got).all()) and torch.equal(got, want[me.z_begin:me.z_end]) and fabric.bytes_moved > 0
+    frame = slabs.render_lit([me], fabric, None, None, None, None, lambda: torch.zeros(4, 6, 4))
+    ok = ok and ((frame is not None and torch.equal(frame, T.expected_frame(world_size))) if rank == 0 else frame is None)
     dist.barrier()
     dist.destroy_process_group()
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
@@ -190,6 +198,24 @@ def test_one_slab_per_gloo_rank(tmp_path, world_size):
     mp.spawn(_worker, args=(world_size, port, str(tmp_path)), nprocs=world_size, join=True)
     for r in range(world_size):
         assert open(tmp_path / f"rank{r}.txt").read() == "ok"
+
+
+def expected_frame(n_slabs, h=4, w=6):
+    up = float("".join(str(k + 1) for k in range(n_slabs)))
+    down = float("".join(str(k + 1) for k in reversed(range(n_slabs))))
+    f = torch.zeros(h, w, 4)
+    f[:, 0::2, :] = up
+    f[:, 1::2, :] = down
+    return f
+
+
+def test_frame_state_travels_up_then_down_in_one_process():
+    occ = toy_occlusion(7)
+    bounds = slabs.slab_bounds(DIMS[2], 4, unit=8)
+    members = [ToyMember(k, *bounds[k], occ) for k in range(4)]
+    fabric = slabs.make_fabric([b[0] for b in bounds] + [DIMS[2]])
+    frame = slabs.render_lit(members, fabric, None, None, None, None, lambda: torch.zeros(4, 6, 4))
+    assert torch.equal(frame, expected_frame(4))
 
 
 def test_slab_bounds():
