@@ -263,6 +263,26 @@ TBRM_API int tbrm_slab_pass_chunk(tbrm_resources* res, int32_t chunk);
  * last chunk): plane_w * plane_h floats, row-major, valid in this handle's rows (lateral) or everywhere (along z). */
 TBRM_API int tbrm_slab_pass_plane(tbrm_resources* res, int32_t boundary, int32_t stream, void** device_plane);
 
+/* ---- slab-resident handles: a GPU that holds only its part of the two volumes -------------------------------------
+ * tbrm_resources_create_slab(desc, owned, &res): desc describes the WHOLE volume; the handle owns light-volume slices
+ * [owned.z_begin, owned.z_end) and allocates only the brick layers (8 slices) it can touch: of the light volume the owned
+ * layers, one layer either side, and a copy of the layer that wrap addressing reaches across the volume's ends; of the
+ * data volume the layers the occlusion of its rows and the raymarch of its samples read (tbrm_slab_resident_slices
+ * reports both ranges: {first slice, end slice, first slice of the wrap copy or -1}). Such a handle runs tbrm_slab_*
+ * (its own slab only) and tbrm_raymarch_lit_slab_device; the whole-volume operators return TBRM_ERR_UNSUPPORTED. After
+ * light operations and before a frame, neighbouring handles exchange their boundary light-volume layers
+ * (tbrm_slab_light_halo: the layer to send to, and the layer to receive from, the neighbour on that side; the
+ * neighbours form a ring, because the light volume is sampled with wrap addressing). */
+TBRM_API int tbrm_resources_create_slab(const tbrm_resources_desc* desc, const tbrm_slab* owned, tbrm_resources** out);
+TBRM_API int tbrm_slab_resident_slices(const tbrm_resources* res, int32_t data[3], int32_t light[3]);
+/* Dense x-fastest slices [z_begin, z_begin + z_count) of the data volume (whole brick layers; any resident layer, the
+ * wrap copy's source included). */
+TBRM_API int tbrm_upload_volume_slices(tbrm_resources* res, int32_t z_begin, int32_t z_count, const void* host_voxels,
+                                       size_t n_bytes);
+TBRM_API int tbrm_download_light_slices(tbrm_resources* res, int32_t z_begin, int32_t z_count, void* host_out, size_t n_bytes);
+/* side 0: the neighbour towards z = 0, side 1: the other. *recv_layer is NULL when the handle owns the whole depth. */
+TBRM_API int tbrm_slab_light_halo(tbrm_resources* res, int32_t side, void** send_layer, void** recv_layer, size_t* layer_bytes);
+
 /* ClearResourceLightVolumes(Resources, ClearValue) (RaymarchUtils.cpp:104-111). */
 TBRM_API int tbrm_clear_light_volume(tbrm_resources* res, float clear_value);
 

@@ -115,11 +115,12 @@ class SlabPass(C.Structure):  # tbrm_slab_pass
 # every symbol include/tbrm.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
     "tbrm_version", "tbrm_last_error", "tbrm_device_count",
-    "tbrm_resources_create", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
+    "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
     "tbrm_add_dir_light", "tbrm_add_dir_lights", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_slab_light_begin", "tbrm_slab_pass_begin", "tbrm_slab_pass_chunk", "tbrm_slab_pass_plane",
+    "tbrm_slab_resident_slices", "tbrm_upload_volume_slices", "tbrm_download_light_slices", "tbrm_slab_light_halo",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_lit_slab_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
@@ -155,6 +156,11 @@ def load():
     vp = C.c_void_p
     lib.tbrm_device_count.argtypes = [P(C.c_int)]
     lib.tbrm_resources_create.argtypes = [P(ResourcesDesc), P(vp)]
+    lib.tbrm_resources_create_slab.argtypes = [P(ResourcesDesc), P(Slab), P(vp)]
+    lib.tbrm_slab_resident_slices.argtypes = [vp, P(C.c_int32 * 3), P(C.c_int32 * 3)]
+    lib.tbrm_upload_volume_slices.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_size_t]
+    lib.tbrm_download_light_slices.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_size_t]
+    lib.tbrm_slab_light_halo.argtypes = [vp, C.c_int32, P(vp), P(vp), P(C.c_size_t)]
     lib.tbrm_resources_destroy.argtypes = [vp]
     lib.tbrm_resources_light_volume_dims.argtypes = [vp, P(C.c_int32 * 3)]
     lib.tbrm_resources_is_initialized.argtypes = [vp]
@@ -300,12 +306,17 @@ class Resources:
     """Owns one tbrm_resources handle (FBasicRaymarchRenderingResources)."""
 
     def __init__(self, dims, data_format, light_32bit=False, half_res=False, device=0,
-                 data_address_mode=ADDRESS_WRAP, border_mode=BORDER_ENGINE_8BIT):
+                 data_address_mode=ADDRESS_WRAP, border_mode=BORDER_ENGINE_8BIT, owned=None):
+        """owned: a Slab -> a slab-resident handle (tbrm_resources_create_slab) that holds only its part of the volumes"""
         self.lib = load()
         self.desc = ResourcesDesc(int(dims[0]), int(dims[1]), int(dims[2]), int(data_format), int(bool(light_32bit)),
                                   int(bool(half_res)), int(device), int(data_address_mode), int(border_mode), 0)
         self.handle = C.c_void_p()
-        check(self.lib.tbrm_resources_create(C.byref(self.desc), C.byref(self.handle)))
+        self.owned = owned
+        if owned is None:
+            check(self.lib.tbrm_resources_create(C.byref(self.desc), C.byref(self.handle)))
+        else:
+            check(self.lib.tbrm_resources_create_slab(C.byref(self.desc), C.byref(owned), C.byref(self.handle)))
         d = (C.c_int32 * 3)()
         check(self.lib.tbrm_resources_light_volume_dims(self.handle, C.byref(d)))
         self.light_dims = tuple(d[:])
@@ -368,6 +379,36 @@ class Resources:
 
     def clear_light_volume(self, value=0.0):
         check(self.lib.tbrm_clear_light_volume(self.handle, float(value)))
+
+    # slab-resident handles
+    def resident_slices(self):
+        """({first, end, wrap copy's first or -1} of the data volume, the same of the light volume), in slices"""
+        d, l = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+        check(self.lib.tbrm_slab_resident_slices(self.handle, C.byref(d), C.byref(l)))
+        return tuple(d[:]), tuple(l[:])
+
+    def upload_volume_slices(self, z_begin, slices):
+        slices = np.ascontiguousarray(slices)
+        assert DTYPE_FMT[slices.dtype] == self.desc.data_format and slices.shape[1:] == (self.desc.dim_y, self.desc.dim_x)
+        check(self.lib.tbrm_upload_volume_slices(self.handle, int(z_begin), int(slices.shape[0]), slices.ctypes.data, slices.nbytes))
+
+    def upload_resident_part(self, vol):
+        """uploads, from the whole volume `vol` [z, y, x], the layers this slab-resident handle holds"""
+        (lo, hi, wrap), _ = self.resident_slices()
+        self.upload_volume_slices(lo, vol[lo:hi])
+        if wrap >= 0:
+            self.upload_volume_slices(wrap, vol[wrap:wrap + 8])
+
+    def download_light_slices(self, z_begin, z_count):
+        out = np.empty((int(z_count), self.light_dims[1], self.light_dims[0]), dtype=self.light_dtype)
+        check(self.lib.tbrm_download_light_slices(self.handle, int(z_begin), int(z_count), out.ctypes.data, out.nbytes))
+        return out
+
+    def slab_light_halo(self, side):
+        """(device address of the layer to send, of the layer to receive into or None, bytes) for the neighbour on `side`"""
+        snd, rcv, n = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        check(self.lib.tbrm_slab_light_halo(self.handle, int(side), C.byref(snd), C.byref(rcv), C.byref(n)))
+        return snd.value, rcv.value, n.value
 
     # slab-partitioned illumination (tbrm.h "slabs"; driver: slabs.py)
     def slab_light_begin(self, removed, light, added, world, slab):

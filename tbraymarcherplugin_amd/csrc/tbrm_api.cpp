@@ -59,9 +59,18 @@ struct tbrm_resources {
     int lv_fmt = FMT_U8;
     hipStream_t stream = nullptr;
 
-    void* d_data = nullptr;
+    void* d_data = nullptr;        // bricked data volume; slab-resident handles: rebased so that global brick offsets apply
     size_t data_bytes = 0;
     bool has_volume = false;
+
+    // Slab-resident handles (tbrm_resources_create_slab) hold only some z brick layers of the two volumes: layers
+    // [lo, hi) contiguously, then one more layer holding a copy of layer `wrap_src` (what wrap addressing reaches from the
+    // first / last slice; -1: none). d_data / d_light point lo * layer_bytes BEFORE the allocation, so a kernel that only
+    // touches resident layers addresses them with the global brick offsets, unchanged.
+    struct Residency { int lo = 0, hi = 0, wrap_src = -1; size_t layer_bytes = 0; void* alloc = nullptr; };
+    bool resident = false;
+    tbrm_slab owned{};
+    Residency res_data, res_light;
 
     float4* d_tf = nullptr;
     float tf_host[1024]{};
@@ -119,7 +128,9 @@ bool initialized(const tbrm_resources* r) { return r && r->has_volume && r->has_
 
 VolumeDev data_view(const tbrm_resources* r)
 {
-    return VolumeDev{r->d_data, r->desc.dim_x, r->desc.dim_y, r->desc.dim_z, r->desc.data_format, r->dbn[0], r->dbn[0] * r->dbn[1]};
+    const tbrm_resources::Residency& q = r->res_data;
+    return VolumeDev{r->d_data, r->desc.dim_x, r->desc.dim_y, r->desc.dim_z, r->desc.data_format, r->dbn[0], r->dbn[0] * r->dbn[1],
+                     q.wrap_src, (q.hi - q.wrap_src) * 8};
 }
 WindowDev window_dev(const tbrm_resources* r)
 {
@@ -371,6 +382,31 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
             p.roi_by1 = std::min(ceil_div(slab->z_end + kChunkTile, 16), p.occ_blocks_y);
         }
     }
+    if (r->resident) {
+        if (!slab || slab->z_begin != r->owned.z_begin || slab->z_end != r->owned.z_end)
+            return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle runs its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
+        // every data texel the occlusion of this handle's rows / slices can sample has to be resident: z range of the taps of
+        // light-volume slices [za, zb), with the kernel's own arithmetic (GetUVW + UVWOffset, texel split)
+        const int za = plan.lateral ? std::max(slab->z_begin - kChunkTile, 0) : slab->z_begin;
+        const int zb = plan.lateral ? std::min(slab->z_end + kChunkTile, r->lv_dims[2]) : slab->z_end;
+        int lo = INT32_MAX, hi = INT32_MIN;
+        for (const tbrm_light_pass* q : {&pa, pr}) {
+            if (!q) continue;
+            for (int z : {za, zb - 1}) {
+                const float w = (((float) (uint32_t) z + 0.5f) / (float) (uint32_t) r->lv_dims[2]) + q->uvw_offset[2];
+                float x = w * (float) r->desc.dim_z - 0.5f;
+                x = std::fmin(std::fmax(x, -0x1p30f), 0x1p30f);
+                const int i0 = (int) std::floor(x);
+                lo = std::min(lo, i0);
+                hi = std::max(hi, i0 + 1);
+            }
+        }
+        lo = clamp_int(lo, 0, r->desc.dim_z - 1);
+        hi = clamp_int(hi, 0, r->desc.dim_z - 1);
+        if ((lo >> 3) < r->res_data.lo || (hi >> 3) >= r->res_data.hi)
+            return fail(TBRM_ERR_UNSUPPORTED, "this pass samples data slices %d..%d, the handle holds %d..%d", lo, hi, r->res_data.lo * 8,
+                        r->res_data.hi * 8 - 1);
+    }
     const int D = plan.D;
     plan.n_chunks = ceil_div(D, M);
 
@@ -403,7 +439,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
     // workgroup of the whole pass, computed up front, and per span the ascending list of the workgroups with work
-    plan.sparse = !getenv("TBRM_NO_SPARSE_OCC");
+    plan.sparse = !getenv("TBRM_NO_SPARSE_OCC") && !r->resident; // (the per-brick value ranges are not kept for partly resident volumes)
     plan.work_list = plan.sparse && !getenv("TBRM_NO_OCC_LIST");
     p.occ_groups = ceil_div(S, kOccSlices);
     plan.flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
@@ -713,6 +749,8 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     p.lv_bnx = r->lbn[0];
     p.lv_bnxy = r->lbn[0] * r->lbn[1];
     p.lv_fmt = r->lv_fmt;
+    p.lv_wrap_layer = r->res_light.wrap_src;
+    p.lv_wrap_shift = (r->res_light.hi - r->res_light.wrap_src) * 8;
     const tbrm_vec3d* v[4] = {&cam->position, &cam->forward, &cam->right, &cam->up};
     float* dst[4] = {p.cam_pos, p.fwd, p.right, p.up};
     for (int k = 0; k < 4; ++k) {
@@ -726,7 +764,7 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     host_local_clipping(*world, p.cc, p.cd);
     p.clip_mode = raymarch_clip_mode(p.cc, p.cd);
     p.share_grid = (r->lv_dims[0] == r->desc.dim_x && r->lv_dims[1] == r->desc.dim_y && r->lv_dims[2] == r->desc.dim_z &&
-                    !getenv("TBRM_NO_SHARE_GRID")) ? 1 : 0;
+                    !r->resident && !getenv("TBRM_NO_SHARE_GRID")) ? 1 : 0; // (the two volumes of a slab-resident handle relocate different layers)
     p.tile_x0 = tile->x0; p.tile_y0 = tile->y0; p.tile_w = tile->w; p.tile_h = tile->h;
     p.row_group_step = tile->row_group_step > 0 ? tile->row_group_step : 1;
     p.steps = rp->steps;
@@ -755,7 +793,15 @@ int tbrm_device_count(int* out_count)
     return TBRM_OK;
 }
 
-int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
+static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, tbrm_resources** out);
+int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out) { return create_impl(desc, nullptr, out); }
+int tbrm_resources_create_slab(const tbrm_resources_desc* desc, const tbrm_slab* owned, tbrm_resources** out)
+{
+    if (!owned) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    return create_impl(desc, owned, out);
+}
+
+static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, tbrm_resources** out)
 {
     if (!desc || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
@@ -789,6 +835,36 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     }
     r->data_bricked_bytes = data_bricks * 512 * format_bytes(desc->data_format);
     r->light_bricked_bytes = light_bricks * 512 * lv_elem;
+    r->res_data.layer_bytes = (size_t) r->dbn[0] * r->dbn[1] * 512 * format_bytes(desc->data_format);
+    r->res_light.layer_bytes = (size_t) r->lbn[0] * r->lbn[1] * 512 * lv_elem;
+    r->res_data.hi = r->dbn[2];
+    r->res_light.hi = r->lbn[2];
+    if (owned) { // slab-resident: which brick layers this handle keeps
+        const int lz = r->lv_dims[2], dz = desc->dim_z;
+        if (owned->z_begin < 0 || owned->z_end > lz || owned->z_begin >= owned->z_end || owned->z_begin % kChunkTile || owned->z_end % kChunkTile ||
+            lz % kChunkTile) {
+            delete r;
+            return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep: bounds and depth must be multiples of %d",
+                        owned->z_begin, owned->z_end, lz, kChunkTile);
+        }
+        r->resident = true;
+        r->owned = *owned;
+        // light volume: the owned slices and one brick layer either side (the raymarch's taps); wrap addressing reaches
+        // the far end of the volume from its first / last slice
+        auto set = [](tbrm_resources::Residency& q, int lo, int hi, int layers) {
+            q.lo = std::max(lo, 0);
+            q.hi = std::min(hi, layers);
+            q.wrap_src = (q.lo == 0 && q.hi < layers) ? layers - 1 : ((q.hi == layers && q.lo > 0) ? 0 : -1);
+        };
+        set(r->res_light, owned->z_begin / 8 - 1, owned->z_end / 8 + 1, r->lbn[2]);
+        // data volume: what the occlusion of the slab's rows and of the 32 rows either side can sample (lateral passes,
+        // tbrm_slab_*: taps reach UVWOffset + 1 texel beyond a row's own position), in data texels
+        const double ratio = (double) dz / (double) lz;
+        const int halo = (int) std::ceil(ratio * (kChunkTile + 8)) + 8;
+        const int d0 = (int) std::floor(owned->z_begin * ratio) - halo, d1 = (int) std::ceil(owned->z_end * ratio) + halo;
+        set(r->res_data, floor_div(d0, 8), ceil_div(d1, 8), r->dbn[2]);
+        if (desc->data_address_mode == TBRM_ADDRESS_CLAMP) r->res_data.wrap_src = -1;
+    }
     const size_t nb = (size_t) r->bn[0] * r->bn[1] * r->bn[2];
     const size_t nb_pad = (nb + 255) / 256 * 256;
 
@@ -805,9 +881,17 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
 
     CREATE_TRY(hipSetDevice(desc->device));
     CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-    CREATE_TRY(hipMalloc(&r->d_data, r->data_bricked_bytes));
+    {
+        tbrm_resources::Residency& q = r->res_data;
+        CREATE_TRY(hipMalloc(&q.alloc, (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0)) * q.layer_bytes));
+        r->d_data = (char*) q.alloc - (size_t) q.lo * q.layer_bytes;
+    }
     CREATE_TRY(hipMalloc((void**) &r->d_tf, 256 * sizeof(float4)));
-    CREATE_TRY(hipMalloc(&r->d_light, r->light_bricked_bytes));
+    {
+        tbrm_resources::Residency& q = r->res_light;
+        CREATE_TRY(hipMalloc(&q.alloc, (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0)) * q.layer_bytes));
+        r->d_light = (char*) q.alloc - (size_t) q.lo * q.layer_bytes;
+    }
     // XYZReadWriteBuffers: 4 buffers per axis in the light volume's format (RaymarchVolume.cpp:864-866,:889-891)
     const size_t buf_px[3] = {(size_t) r->lv_dims[1] * r->lv_dims[2], (size_t) r->lv_dims[0] * r->lv_dims[2],
         (size_t) r->lv_dims[0] * r->lv_dims[1]};
@@ -823,7 +907,7 @@ int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out)
     for (int k = 0; k < 2; ++k)
         for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));
     // the light volume render target starts cleared
-    CREATE_TRY(hipMemsetAsync(r->d_light, 0, r->light_bricked_bytes, r->stream));
+    CREATE_TRY(hipMemsetAsync(r->res_light.alloc, 0, (size_t) (r->res_light.hi - r->res_light.lo + (r->res_light.wrap_src >= 0 ? 1 : 0)) * r->res_light.layer_bytes, r->stream));
 #undef CREATE_TRY
     *out = r;
     return TBRM_OK;
@@ -834,9 +918,9 @@ int tbrm_resources_destroy(tbrm_resources* r)
     if (!r) return TBRM_OK;
     (void) hipSetDevice(r->desc.device);
     if (r->stream) (void) hipStreamSynchronize(r->stream);
-    (void) hipFree(r->d_data);
+    (void) hipFree(r->res_data.alloc);
     (void) hipFree(r->d_tf);
-    (void) hipFree(r->d_light);
+    (void) hipFree(r->res_light.alloc);
     for (auto& axis : r->d_buf)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
@@ -870,6 +954,7 @@ int tbrm_resources_is_initialized(const tbrm_resources* r) { return initialized(
 
 int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_bytes)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: upload its layers with tbrm_upload_volume_slices");
     if (!r || !host_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
     if (int e = bind(r)) return e;
@@ -889,6 +974,7 @@ int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_byte
 
 int tbrm_upload_volume_device(tbrm_resources* r, const void* device_voxels, size_t n_bytes)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: upload its layers with tbrm_upload_volume_slices");
     if (!r || !device_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
     if (int e = bind(r)) return e;
@@ -947,6 +1033,7 @@ int tbrm_set_windowing(tbrm_resources* r, const tbrm_windowing_params* w)
 int tbrm_add_dir_light(tbrm_resources* r, const tbrm_dir_light_params* light, int added, const tbrm_world_params* world,
                        int* light_added, int gpu_sync)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: light operators run through tbrm_slab_*");
     (void) gpu_sync; // accepted and ignored (RaymarchUtils.cpp:51-59)
     if (light_added) *light_added = 0;
     if (!r || !light || !world) return fail(TBRM_ERR_INVALID_ARG, "null argument");
@@ -961,6 +1048,7 @@ int tbrm_add_dir_light(tbrm_resources* r, const tbrm_dir_light_params* light, in
 int tbrm_add_dir_lights(tbrm_resources* r, const tbrm_dir_light_params* lights, int32_t n_lights, int added, const tbrm_world_params* world,
                         int32_t* schedule, int32_t* n_entries)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: light operators run through tbrm_slab_*");
     if (n_entries) *n_entries = 0;
     if (!r || !world || (n_lights > 0 && !lights) || n_lights < 0) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
@@ -973,6 +1061,7 @@ int tbrm_add_dir_lights(tbrm_resources* r, const tbrm_dir_light_params* lights, 
 int tbrm_change_dir_light(tbrm_resources* r, const tbrm_dir_light_params* old_light, const tbrm_dir_light_params* new_light,
                           const tbrm_world_params* world, int* light_added)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: light operators run through tbrm_slab_*");
     if (light_added) *light_added = 0;
     if (!r || !old_light || !new_light || !world) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function"); // :74-80
@@ -1072,20 +1161,120 @@ int tbrm_slab_pass_plane(tbrm_resources* r, int32_t boundary, int32_t stream, vo
     return TBRM_OK;
 }
 
+// ---- slab-resident handles: moving their layers in and out -------------------------------------------------------------
+
+namespace {
+// where brick layer `layer` of a volume lives, or null when the handle does not hold it
+char* layer_address(const tbrm_resources::Residency& q, int layer)
+{
+    if (layer >= q.lo && layer < q.hi) return (char*) q.alloc + (size_t) (layer - q.lo) * q.layer_bytes;
+    if (layer == q.wrap_src) return (char*) q.alloc + (size_t) (q.hi - q.lo) * q.layer_bytes;
+    return nullptr;
+}
+} // namespace
+
+int tbrm_slab_resident_slices(const tbrm_resources* r, int32_t data[3], int32_t light[3])
+{
+    if (!r || !data || !light) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    const tbrm_resources::Residency* q[2] = {&r->res_data, &r->res_light};
+    const int depth[2] = {r->desc.dim_z, r->lv_dims[2]};
+    int32_t* out[2] = {data, light};
+    for (int k = 0; k < 2; ++k) {
+        out[k][0] = q[k]->lo * 8;
+        out[k][1] = std::min(q[k]->hi * 8, depth[k]);
+        out[k][2] = q[k]->wrap_src >= 0 ? q[k]->wrap_src * 8 : -1;
+    }
+    return TBRM_OK;
+}
+
+int tbrm_upload_volume_slices(tbrm_resources* r, int32_t z_begin, int32_t z_count, const void* host_voxels, size_t n_bytes)
+{
+    if (!r || !host_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    const int nz = r->desc.dim_z;
+    const size_t esz = format_bytes(r->desc.data_format), slice = (size_t) r->desc.dim_x * r->desc.dim_y * esz;
+    if (z_begin < 0 || z_count <= 0 || z_begin + z_count > nz || z_begin % 8 || ((z_begin + z_count) % 8 && z_begin + z_count != nz))
+        return fail(TBRM_ERR_INVALID_ARG, "slices [%d, %d): whole brick layers (multiples of 8) of a volume %d deep", z_begin, z_begin + z_count, nz);
+    if (n_bytes != slice * (size_t) z_count) return fail(TBRM_ERR_INVALID_ARG, "%d slices are %zu bytes, got %zu", z_count, slice * (size_t) z_count, n_bytes);
+    if (int e = bind(r)) return e;
+    void* staging = nullptr;
+    HIP_TRY(hipMalloc(&staging, n_bytes));
+    hipError_t e1 = hipMemcpyAsync(staging, host_voxels, n_bytes, hipMemcpyHostToDevice, r->stream);
+    int code = TBRM_OK;
+    for (int layer = z_begin / 8; e1 == hipSuccess && layer < ceil_div(z_begin + z_count, 8); ++layer) { // layer by layer: the wrap copy lives elsewhere
+        char* dst = layer_address(r->res_data, layer);
+        if (!dst) { code = fail(TBRM_ERR_INVALID_ARG, "data slices %d.. are not resident on this handle", layer * 8); break; }
+        const int lz = std::min(8, nz - layer * 8);
+        const int dims[3] = {r->desc.dim_x, r->desc.dim_y, lz}, bn[3] = {r->dbn[0], r->dbn[1], 1};
+        e1 = launch_relayout(relayout_params((const char*) staging + (size_t) (layer * 8 - z_begin) * slice, dst, dims, bn, esz, true), r->stream);
+    }
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
+    (void) hipFree(staging);
+    if (code != TBRM_OK) return code;
+    HIP_TRY(e1);
+    r->has_volume = true;
+    return TBRM_OK;
+}
+
+int tbrm_download_light_slices(tbrm_resources* r, int32_t z_begin, int32_t z_count, void* host_out, size_t n_bytes)
+{
+    if (!r || !host_out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    const int nz = r->lv_dims[2];
+    const size_t esz = r->lv_fmt == FMT_U8 ? 1 : 4, slice = (size_t) r->lv_dims[0] * r->lv_dims[1] * esz;
+    if (z_begin < 0 || z_count <= 0 || z_begin + z_count > nz || z_begin % 8 || ((z_begin + z_count) % 8 && z_begin + z_count != nz))
+        return fail(TBRM_ERR_INVALID_ARG, "slices [%d, %d): whole brick layers (multiples of 8) of a light volume %d deep", z_begin, z_begin + z_count, nz);
+    if (n_bytes != slice * (size_t) z_count) return fail(TBRM_ERR_INVALID_ARG, "%d slices are %zu bytes, got %zu", z_count, slice * (size_t) z_count, n_bytes);
+    if (int e = bind(r)) return e;
+    void* staging = nullptr;
+    HIP_TRY(hipMalloc(&staging, n_bytes));
+    hipError_t e1 = hipSuccess;
+    int code = TBRM_OK;
+    for (int layer = z_begin / 8; e1 == hipSuccess && layer < ceil_div(z_begin + z_count, 8); ++layer) {
+        const tbrm_resources::Residency& q = r->res_light;
+        char* src = (layer >= q.lo && layer < q.hi) ? layer_address(q, layer) : nullptr; // the layer itself, not a wrap copy of it
+        if (!src) { code = fail(TBRM_ERR_INVALID_ARG, "light-volume slices %d.. are not resident on this handle", layer * 8); break; }
+        const int lz = std::min(8, nz - layer * 8);
+        const int dims[3] = {r->lv_dims[0], r->lv_dims[1], lz}, bn[3] = {r->lbn[0], r->lbn[1], 1};
+        e1 = launch_relayout(relayout_params(src, (char*) staging + (size_t) (layer * 8 - z_begin) * slice, dims, bn, esz, false), r->stream);
+    }
+    if (e1 == hipSuccess && code == TBRM_OK) e1 = hipMemcpyAsync(host_out, staging, n_bytes, hipMemcpyDeviceToHost, r->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
+    (void) hipFree(staging);
+    if (code != TBRM_OK) return code;
+    HIP_TRY(e1);
+    return TBRM_OK;
+}
+
+int tbrm_slab_light_halo(tbrm_resources* r, int32_t side, void** send_layer, void** recv_layer, size_t* layer_bytes)
+{
+    if (!r || !send_layer || !recv_layer || !layer_bytes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!r->resident) return fail(TBRM_ERR_INVALID_ARG, "not a slab-resident handle");
+    if (side != 0 && side != 1) return fail(TBRM_ERR_INVALID_ARG, "side is 0 (towards z = 0) or 1");
+    const tbrm_resources::Residency& q = r->res_light;
+    const int first = r->owned.z_begin / 8, last = r->owned.z_end / 8 - 1, layers = r->lbn[2];
+    const int send = side == 0 ? first : last;
+    const int recv = side == 0 ? (first == 0 ? layers - 1 : first - 1) : (last == layers - 1 ? 0 : last + 1); // across the ends: the wrap copy
+    *send_layer = layer_address(q, send);
+    *recv_layer = (recv >= first && recv <= last) ? nullptr : layer_address(q, recv); // a handle that owns everything has no halo
+    *layer_bytes = q.layer_bytes;
+    return TBRM_OK;
+}
+
 int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)
 {
     if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!r->d_light) return TBRM_OK; // RaymarchUtils.cpp:106-109
     if (int e = bind(r)) return e;
     if (int e = begin_timed(r, 0)) return e;
-    const size_t n = (size_t) r->lbn[0] * r->lbn[1] * r->lbn[2] * 512; // padding voxels are never sampled
-    HIP_TRY(launch_fill(r->d_light, r->lv_fmt, n, clear_value, r->stream));
+    const tbrm_resources::Residency& q = r->res_light; // (all layers of an ordinary handle); padding voxels are never sampled
+    const size_t n = (size_t) r->lbn[0] * r->lbn[1] * 512 * (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0));
+    HIP_TRY(launch_fill(q.alloc, r->lv_fmt, n, clear_value, r->stream));
     return end_timed(r, 0);
 }
 
 int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
                              const tbrm_world_params* world, const float* device_scene_depth, float* device_out_rgba)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: frames are marched with tbrm_raymarch_lit_slab_device");
     if (!r || !cam || !tile || !rp || !world || !device_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
     if (int e = bind(r)) return e;
@@ -1121,7 +1310,9 @@ int tbrm_raymarch_lit_slab_device(tbrm_resources* r, const tbrm_camera* cam, con
     p.slab_z0 = slab->z_begin;
     p.slab_z1 = slab->z_end;
     p.slab_dir = direction > 0 ? 1 : (direction < 0 ? -1 : 0);
-    if (rp->enable_skipping) {
+    if (r->resident && (slab->z_begin != r->owned.z_begin || slab->z_end != r->owned.z_end))
+        return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle marches its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
+    if (rp->enable_skipping && !r->resident) {
         if (int e = ensure_skipping(r)) return e;
         p.empty_bits = r->d_empty;
         p.skip_dist = r->d_dist[0];
@@ -1157,6 +1348,7 @@ int tbrm_raymarch_lit(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile
 int tbrm_raymarch_intensity_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
                                    const tbrm_world_params* world, const float* device_scene_depth, float* device_out_rgba)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: only the lit march has a slab form");
     if (!r || !cam || !tile || !rp || !world || !device_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!r->has_volume) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume");
     if (int e = bind(r)) return e;
@@ -1206,6 +1398,7 @@ int tbrm_octree_mip_dims(const tbrm_resources* r, int mip, int32_t out_dims[3])
 
 int tbrm_generate_octree(tbrm_resources* r)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: only the lit march has a slab form");
     if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!r->has_volume) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume");
     if (int e = bind(r)) return e;
@@ -1298,6 +1491,7 @@ int tbrm_count_nominal_samples(tbrm_resources* r, const tbrm_camera* cam, const 
 
 int tbrm_download_light_volume(tbrm_resources* r, void* host_out, size_t n_bytes)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: read its slices with tbrm_download_light_slices");
     if (!r || !host_out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->light_bytes) return fail(TBRM_ERR_INVALID_ARG, "light volume is %zu bytes, got %zu", r->light_bytes, n_bytes);
     if (int e = bind(r)) return e;
@@ -1314,6 +1508,7 @@ int tbrm_download_light_volume(tbrm_resources* r, void* host_out, size_t n_bytes
 
 int tbrm_upload_light_volume(tbrm_resources* r, const void* host_in, size_t n_bytes)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: the light volume is written by tbrm_slab_* only");
     if (!r || !host_in) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->light_bytes) return fail(TBRM_ERR_INVALID_ARG, "light volume is %zu bytes, got %zu", r->light_bytes, n_bytes);
     if (int e = bind(r)) return e;
@@ -1330,6 +1525,7 @@ int tbrm_upload_light_volume(tbrm_resources* r, const void* host_in, size_t n_by
 
 int tbrm_light_volume_device_ptr(tbrm_resources* r, void** out_ptr, size_t* out_bytes)
 {
+    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: exchange its boundary layers with tbrm_slab_light_halo");
     if (!r || !out_ptr) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     *out_ptr = r->d_light; // bricked layout (DESIGN.md "Data layout")
     if (out_bytes) *out_bytes = r->light_bricked_bytes;

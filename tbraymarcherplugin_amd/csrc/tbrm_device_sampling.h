@@ -82,17 +82,22 @@ struct TapOffsets {
     uint32_t x0, x1, y0, y1, z0, z1;
 };
 
-template <int MODE>
+template <int MODE, bool RELOCATE = false> // RELOCATE: slab-resident volume (VolumeDev::wrap_layer)
 __device__ __forceinline__ TapOffsets tap_offsets(const VolumeDev& v, int ix, int iy, int iz)
 {
     // the +1 tap of an in-range base tap needs no general wrap: it is either base+1 or the first/last texel
-    const int x0 = address<MODE>(ix, v.nx), y0 = address<MODE>(iy, v.ny), z0 = address<MODE>(iz, v.nz);
+    const int x0 = address<MODE>(ix, v.nx), y0 = address<MODE>(iy, v.ny);
+    int z0 = address<MODE>(iz, v.nz);
     int x1 = x0 + 1, y1 = y0 + 1, z1 = z0 + 1;
     if constexpr (MODE == ADDR_WRAP) { x1 = x1 == v.nx ? 0 : x1; y1 = y1 == v.ny ? 0 : y1; z1 = z1 == v.nz ? 0 : z1; }
     else { // clamp: the +1 tap clamps on its own (a base tap of -1 and its +1 tap are BOTH texel 0)
         x1 = clamp_index(ix + 1, v.nx);
         y1 = clamp_index(iy + 1, v.ny);
         z1 = clamp_index(iz + 1, v.nz);
+    }
+    if constexpr (RELOCATE) {
+        if ((z0 >> 3) == v.wrap_layer) z0 += v.wrap_shift;
+        if ((z1 >> 3) == v.wrap_layer) z1 += v.wrap_shift;
     }
     TapOffsets t;
     t.x0 = brick_off_x(x0); t.x1 = brick_off_x(x1);

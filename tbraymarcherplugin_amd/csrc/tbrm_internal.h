@@ -23,6 +23,8 @@ struct VolumeDev {
     int fmt;
     int bnx;          // bricks along x
     int bnxy;         // bricks per z-layer of bricks (bnx * bny)
+    int wrap_layer;   // slab-resident volumes: the z brick layer that is not at its own place but at `wrap_shift` voxels
+    int wrap_shift;   // further along z (the copy that wrap addressing reaches from the other end); wrap_layer < 0: none
 };
 
 struct WindowDev { // WindowingParameters float4 (VolumeInfo.h:49-52)
@@ -142,6 +144,7 @@ struct RayParams {
     const uint8_t* skip_dist;   // per brick: Chebyshev distance (bricks, capped) to the nearest non-empty brick; null when skipping is off
     int bnx, bny, bnz;  // brick grid
     unsigned long long* sample_counter; // count kernel only
+    int lv_wrap_layer, lv_wrap_shift; // VolumeDev::wrap_layer / wrap_shift of the light volume
     int slab_on, slab_z0, slab_z1, slab_dir; // slab stage of the lit march: owned light-volume slices, sweep direction (+1 / -1 / 0: all rays)
     const uint16_t* octree;     // octree march only: the level marched (dense, x fastest)
     int oct_dims[3];            // its dimensions

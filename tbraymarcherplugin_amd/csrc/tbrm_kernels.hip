@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
 
     const float nx = (float) p.data.nx, ny = (float) p.data.ny, nz = (float) p.data.nz;
     const float lnx = (float) p.lv_dims[0], lny = (float) p.lv_dims[1], lnz = (float) p.lv_dims[2];
-    const VolumeDev lightv{p.light, p.lv_dims[0], p.lv_dims[1], p.lv_dims[2], LFMT, p.lv_bnx, p.lv_bnxy};
+    const VolumeDev lightv{p.light, p.lv_dims[0], p.lv_dims[1], p.lv_dims[2], LFMT, p.lv_bnx, p.lv_bnxy, p.lv_wrap_layer, p.lv_wrap_shift};
     // the light volume shares the data volume's footprint when it has the same size and the position is inside the
     // cube (saturate(CurPos) == CurPos): same texel split, same wrapped indices, same brick offsets
     const bool same_grid = DMODE == ADDR_WRAP && p.share_grid;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
             RawTaps<DFMT> dtaps;
             RawTaps<LFMT> ltaps;
             float gx, gy, gz;
-            const TapOffsets dt = tap_offsets<DMODE>(p.data, ix, iy, iz);
+            const TapOffsets dt = tap_offsets<DMODE, SLAB>(p.data, ix, iy, iz);
             dtaps.issue(p.data.data, dt);
             // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
             const float sp0 = saturate_(q0), sp1 = saturate_(q1), sp2 = saturate_(q2);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 texel_split(sp0, lnx, lx, gx);
                 texel_split(sp1, lny, ly, gy);
                 texel_split(sp2, lnz, lz, gz);
-                ltaps.issue(p.light, tap_offsets<ADDR_WRAP>(lightv, lx, ly, lz));
+                ltaps.issue(p.light, tap_offsets<ADDR_WRAP, SLAB>(lightv, lx, ly, lz));
             }
             const float v = dtaps.filter(fx, fy, fz);
             // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)

@@ -214,6 +214,38 @@ def reset_all_lights(members, fabric, lights, world, clear):
         add_dir_light(members, fabric, light, True, world)
 
 
+# ---- light-volume halo exchange (slab-resident handles) ------------------------------------------------------------------
+
+def exchange_light_halos(members, fabric):
+    """After light operations and before a frame: every slab-resident handle receives its two neighbours' boundary brick
+    layers of the light volume (what the raymarch's taps reach beyond the slab). The neighbours form a ring — the light
+    volume is sampled with wrap addressing, so slab 0's lower neighbour is the last slab. One exchange, two layers each."""
+    import torch
+
+    by_index = {m.slab_index: m for m in members}
+    n = len(fabric.owner_of_slab)
+    if n == 1:
+        return
+
+    def layer(m, side, which):
+        snd, rcv, nbytes = m.res.slab_light_halo(side)
+        ptr = snd if which == "send" else rcv
+
+        class _Alias:
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        return torch.as_tensor(_Alias(), device=torch.device("cuda", m.res.device))
+
+    for m in members:
+        m.sync()
+    for k in range(n):
+        up = (k + 1) % n  # slab k's last layer -> the lower halo of slab k+1; slab k+1's first layer -> the upper halo of slab k
+        a, b = by_index.get(k), by_index.get(up)
+        fabric.move(k, lambda a=a: layer(a, 1, "send"), up, lambda b=b: layer(b, 0, "recv"))
+        fabric.move(up, lambda b=b: layer(b, 0, "send"), k, lambda a=a: layer(a, 1, "recv"))
+    fabric.complete(members)
+
+
 # ---- the lit frame, slab by slab ---------------------------------------------------------------------------------------
 
 def render_lit(members, fabric, camera, tile, params, world, new_state):

@@ -277,3 +277,75 @@ def test_frame_marched_slab_by_slab_is_the_plain_frame(gpu, addr, n_slabs, dims,
 def ray_lanes_env(request, monkeypatch):
     monkeypatch.setenv("TBRM_RAY_LANES", request.param)
     return request.param
+
+
+# ---- slab-resident handles: each GPU holds only its part of the two volumes ------------------------------------------------
+
+@pytest.mark.parametrize("addr", [abi.ADDRESS_WRAP, abi.ADDRESS_CLAMP])
+@pytest.mark.parametrize("n_slabs,dims,half_res,light_32bit", [(2, (72, 56, 64), False, False), (4, (48, 64, 128), False, False),
+                                                              (2, (64, 64, 128), True, False), (2, (56, 72, 64), False, True)])
+def test_slab_resident_handles_light_and_render_like_one_handle(gpu, addr, n_slabs, dims, half_res, light_32bit):
+    """Handles that hold only their slab of the data and light volumes (plus halos): slab-partitioned light operators,
+    light-volume halo exchange, frame marched slab by slab — light volume and frame bit-identical to one whole handle."""
+    import torch
+
+    vol = small_volume(dims, np.uint16, 0x5EED0403)
+    lut = abi.color_curve_to_lut(S.tf_keys("A"))
+    w = abi.WindowingParams(0.5, 0.9, True, False)
+    fmt = abi.FMT_G16
+    full = abi.Resources(dims, fmt, light_32bit, half_res, 0, addr)
+    full.upload_volume(vol)
+    depth = full.light_dims[2]
+    bounds = slabs.slab_bounds(depth, n_slabs)
+    parts = [abi.Resources(dims, fmt, light_32bit, half_res, 0, addr, owned=abi.Slab(*bounds[k])) for k in range(n_slabs)]
+    handles = [full] + parts
+    dev = torch.device("cuda", 0)
+    try:
+        for res in handles:
+            res.set_tf_lut(lut)
+            res.set_windowing(w)
+        resident_fraction = []
+        for res in parts:
+            res.upload_resident_part(vol)
+            (dlo, dhi, dwrap), (llo, lhi, lwrap) = res.resident_slices()
+            resident_fraction.append((dhi - dlo) / dims[2])
+            assert llo <= res.owned.z_begin and lhi >= res.owned.z_end
+            res.clear_light_volume(0.0)
+        full.clear_light_volume(0.0)
+        if n_slabs == 4:
+            assert min(resident_fraction) < 1.0  # a middle slab really holds less than the volume
+        members = [slabs.DeviceSlab(res, k, *bounds[k]) for k, res in enumerate(parts)]
+        fabric = slabs.make_fabric([b[0] for b in bounds] + [depth])
+        world = S.default_world()
+        for d, inten in LIGHTS[:6]:
+            light = abi.DirLightParams(d, inten)
+            full.add_dir_light(light, True, world)
+            slabs.add_dir_light(members, fabric, light, True, world)
+        old = abi.DirLightParams(*LIGHTS[1])
+        new = abi.DirLightParams(S.rotate_z(LIGHTS[1][0], 5.0), LIGHTS[1][1])
+        full.change_dir_light(old, new, world)
+        slabs.change_dir_light(members, fabric, old, new, world)
+        ref = full.download_light_volume()
+        for m in members:
+            got = m.res.download_light_slices(m.z_begin, m.z_end - m.z_begin)
+            assert np.array_equal(got, ref[m.z_begin:m.z_end]), f"light volume of slab {m.slab_index}"
+        slabs.exchange_light_halos(members, fabric)
+        for case, eye in enumerate([(-145, -95, 80), (10, -5, 190), (0.001, 300, 2), (20, -10, 15), (30, 20, -170)]):
+            cam = abi.look_at_camera(np.array(eye, dtype=float), (3.0, -2.0, 1.0), (0.0, 0.0, 1.0), 50.0, 64, 48)
+            rp = abi.RaymarchParams(float(50 + 31 * case), (case % 3) - 1, True)
+            tile = abi.Tile(0, 0, 64, 48, 1)
+            want = full.raymarch_lit(cam, tile, rp, world)
+            got = slabs.render_lit(members, fabric, cam, tile, rp, world, lambda: torch.zeros((48, 64, 4), dtype=torch.float32, device=dev))
+            torch.cuda.synchronize()
+            got = got.cpu().numpy()
+            assert np.array_equal(got, want), f"eye {eye}: max |d| = {np.abs(got - want).max()}"
+        # the whole-volume operators refuse a handle that does not hold the whole volume
+        with pytest.raises(abi.TbrmError):
+            parts[0].add_dir_light(abi.DirLightParams((1, 0, 0), 0.1), True, world)
+        with pytest.raises(abi.TbrmError):
+            parts[0].raymarch_lit(cam, tile, rp, world)
+        with pytest.raises(abi.TbrmError):
+            parts[0].download_light_volume()
+    finally:
+        for res in handles:
+            res.close()
