@@ -61,6 +61,10 @@ def main():
                     help="N>1: the timed ChangeDirLight is partitioned over the ranks in light-volume z slabs (plane halo exchange "
                          "per chunk / z pipeline, slabs.py), followed by an all-gather of the light volume, instead of being "
                          "computed redundantly on every GPU (BASELINE config 4's decomposition)")
+    ap.add_argument("--slab-resident", action="store_true",
+                    help="N>1, BASELINE config 4's decomposition taken literally: every GPU holds only its z slab of the data and "
+                         "light volumes (tbrm_resources_create_slab); a step = slab-partitioned ChangeDirLight + light-volume halo "
+                         "exchange + the frame marched slab by slab (strong scaling: one frame of the config's size)")
     args = ap.parse_args()
 
     import torch
@@ -93,6 +97,10 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     abi.load()
+    if args.slab_resident:
+        if dist is None:
+            raise SystemExit("--slab-resident needs --gpus N > 1 (or TBRM_BENCH_FORCE_DIST=1)")
+        return slab_resident_bench(args, torch, dist, S, abi, rank, local_rank, n_gpus, device, one_gpu_dry_run)
 
     cfg = S.CONFIGS[args.config]
     n = cfg["n"]
@@ -390,6 +398,138 @@ def main():
     res.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def slab_resident_bench(args, torch, dist, S, abi, rank, local_rank, n_gpus, device, one_gpu_dry_run):
+    """bench.py --slab-resident: no GPU holds the whole volume. See the flag's help and DESIGN.md 7."""
+    from tbraymarcherplugin_amd import slabs
+
+    cfg = S.CONFIGS[args.config]
+    n = cfg["n"]
+    dims = (n, n, n)
+    fb = cfg["fb"]
+    steps = float(cfg["steps"])
+    fmt = abi.DTYPE_FMT[np.dtype(cfg["dtype"])]
+    bounds = slabs.slab_bounds(n, n_gpus)
+    z_bounds = [b[0] for b in bounds] + [n]
+    res = abi.Resources(dims, fmt, cfg["light_32bit"], False, local_rank, owned=abi.Slab(*bounds[rank]))
+    (dlo, dhi, dwrap), (llo, lhi, lwrap) = res.resident_slices()
+    # synthetic volume: generated whole on the device (the generator has no slice form), only this handle's layers are kept
+    vol_dev = S.make_volume_torch(dims, cfg["dtype"], S.seed_for_config(args.config), device)
+    torch.cuda.synchronize()
+    res.upload_volume_slices(dlo, vol_dev[dlo:dhi].cpu().numpy())
+    if dwrap >= 0:
+        res.upload_volume_slices(dwrap, vol_dev[dwrap:dwrap + 8].cpu().numpy())
+    keep_whole = rank == 0  # rank 0 keeps the whole volume for the untimed check at the end
+    if not keep_whole:
+        del vol_dev
+    lut = abi.color_curve_to_lut(S.tf_keys(cfg["tf"]))
+    win = abi.WindowingParams(*cfg["window"])
+    res.set_tf_lut(lut)
+    res.set_windowing(win)
+    world = S.default_world()
+    cam = S.default_camera(fb, fb)
+    tile = abi.Tile(0, 0, fb, fb, 1)
+    rp = abi.RaymarchParams(steps, -1, False)
+    member = slabs.DeviceSlab(res, rank, *bounds[rank])
+    if one_gpu_dry_run:  # gloo: stage through host memory
+        def p2p(ops):
+            res.flush()
+            work = []
+            for kind, t, peer in ops:
+                if kind == "send":
+                    host = t.cpu()
+                    work.append((dist.isend(host, peer), None, host))
+                else:
+                    buf = torch.empty(t.shape, dtype=t.dtype)
+                    work.append((dist.irecv(buf, peer), t, buf))
+            for w, t, buf in work:
+                w.wait()
+                if t is not None:
+                    t.copy_(buf)
+            torch.cuda.synchronize()
+
+        fabric = slabs.make_fabric(z_bounds, list(range(n_gpus)), rank, p2p, sync_local=False)
+    else:
+        fabric = slabs.dist_fabric(z_bounds, rank, n_gpus)
+    lights = [S.light(i) for i in cfg["lights"]]
+    light_dirs = [S.LIGHTS[i][0] for i in cfg["lights"]]
+    angle = [0.0] * len(lights)
+    frame = [None]
+
+    def new_state():
+        return torch.zeros((fb, fb, 4), dtype=torch.float32, device=device)
+
+    with member.stream_context():
+        slabs.reset_all_lights([member], fabric, lights, world, lambda m: m.res.clear_light_volume(0.0))
+    total_samples = res.count_nominal_samples(cam, tile, rp, world)
+
+    def one_step(k):
+        li = k % len(lights)
+        angle[li] += 5.0
+        new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li]), lights[li].light_intensity)
+        with member.stream_context():  # torch's zero fill and the point-to-point operations are ordered with the library's stream
+            slabs.change_dir_light([member], fabric, lights[li], new, world)
+            slabs.exchange_light_halos([member], fabric)
+            frame[0] = slabs.render_lit([member], fabric, cam, tile, rp, world, new_state)
+        lights[li] = new
+
+    for k in range(args.warmup):
+        one_step(k)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    res.flush()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    red_device = torch.device("cpu") if one_gpu_dry_run else device
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # untimed check on rank 0: one whole handle replays the lights and renders the last frame
+    ok = None
+    if rank == 0:
+        whole = abi.Resources(dims, fmt, cfg["light_32bit"], False, local_rank)
+        whole.upload_volume_device(vol_dev.data_ptr(), vol_dev.numel() * vol_dev.element_size())
+        whole.set_tf_lut(lut)
+        whole.set_windowing(win)
+        replay = [S.light(i) for i in cfg["lights"]]
+        ang = [0.0] * len(replay)
+        whole.clear_light_volume(0.0)
+        for l in replay:
+            whole.add_dir_light(l, True, world)
+        for k in range(args.warmup + args.steps):
+            li = k % len(replay)
+            ang[li] += 5.0
+            new = abi.DirLightParams(S.rotate_z(light_dirs[li], ang[li]), replay[li].light_intensity)
+            whole.change_dir_light(replay[li], new, world)
+            replay[li] = new
+        want = torch.empty((fb, fb, 4), dtype=torch.float32, device=device)
+        whole.raymarch_lit_device(cam, tile, rp, world, want.data_ptr())
+        whole.flush()
+        own = res.download_light_slices(bounds[0][0], bounds[0][1] - bounds[0][0])
+        ok = bool(torch.equal(frame[0], want)) and bool(np.array_equal(own, whole.download_light_volume()[bounds[0][0]:bounds[0][1]]))
+        whole.close()
+        value = total_samples * args.steps / elapsed / 1e6
+        print(json.dumps({
+            "metric": "volume Msamples/s (rays x steps) at 512^3, 1024^2 view; % HBM roofline",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: {n}^3 {np.dtype(cfg['dtype']).name} volume in {n_gpus} z slabs (no GPU holds the "
+                                   f"whole volume), {fb}x{fb} frame marched slab by slab, {int(steps)} steps, {len(lights)} dir lights, 1 "
+                                   "slab-partitioned ChangeDirLight + light-volume halo exchange + 1 frame per step",
+                       "volume": list(dims), "framebuffer": [fb, fb], "steps": int(steps), "lights": len(lights),
+                       "parallelism": f"light-volume z slabs x{n_gpus}, slab-resident volumes",
+                       "resident_data_slices": [dlo, dhi], "resident_light_slices": [llo, lhi]},
+            "nominal_samples_per_step": total_samples,
+            "slab_frame_and_light_volume_equal_one_whole_handle": ok,
+            "roofline": None, "cpu_baseline": None}))
+    res.close()
 
 
 def cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, light_old, light_new):
