@@ -224,7 +224,7 @@ TBRM_API int tbrm_change_dir_light(tbrm_resources* res, const tbrm_dir_light_par
  * The reference has no multi-GPU path; this is the same AddDirLight / ChangeDirLight arithmetic, partitioned. Every
  * handle holds the whole data volume (it is read-only and 288 GB hold any volume the plugin loads); the LIGHT volume's
  * z range is dealt out in slabs and each handle computes, and owns, only its slab [z_begin, z_end). An axis pass is
- * cut into chunks of 16/8/4 slices; between chunks the host exchanges the propagated-light planes:
+ * cut into chunks of 16/8/4/2 slices; between chunks the host exchanges the propagated-light planes:
  *   - pass along x or y ("lateral", z is the row axis of the slice plane): every handle runs every chunk on its rows;
  *     after each chunk it needs halo_rows rows of its two z neighbours' planes (what a chunk's bilinear taps can reach);
  *   - pass along z: the slabs are a pipeline; a handle imports the planes of the handle before it in propagation order,

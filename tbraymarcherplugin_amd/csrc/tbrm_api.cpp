@@ -281,7 +281,7 @@ thread_local const char* g_plan_note = "";
 int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; }
 
 // Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
-// 16/8/4 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
+// 16/8/4/2 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
 struct ChunkFit { int M = 0; TapRange tx, ty; };
 bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit)
 {
@@ -306,12 +306,12 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
     p.j0 = pa.start;
     const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
     fit = ChunkFit{};
-    for (int cand : {16, 8, 4}) {
+    for (int cand : {16, 8, 4, 2}) { // 2: steep secondary passes (taps up to 16 texels from the pixel), still 5x the slice kernel
         if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
         p.n_steps = std::min(cand, D_pass);
         if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, pr != nullptr, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
     }
-    if (fit.M <= 0) return declined("the previous-slice taps reach too far for a 4-slice chunk"), false;
+    if (fit.M <= 0) return declined("the previous-slice taps reach too far for a 2-slice chunk"), false;
     fit.tx = tx;
     fit.ty = ty;
     return true;

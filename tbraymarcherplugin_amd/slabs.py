@@ -3,7 +3,7 @@ C-ABI's tbrm_slab_* entry points.
 
 The light volume's z range is dealt out in slabs; slab k computes and owns light-volume slices [z_k, z_k+1). Every GPU
 keeps the whole (read-only) data volume — 288 GB of HBM hold any volume the plugin loads, so the data is replicated and
-the WORK is what gets partitioned. An axis pass is a sequence of chunks (16 / 8 / 4 slices), and the only
+the WORK is what gets partitioned. An axis pass is a sequence of chunks (16 / 8 / 4 / 2 slices), and the only
 thing one slab needs from another is propagated-light plane content at chunk boundaries:
 
   * pass along x or y ("lateral": z is the row axis of the slice plane) — all slabs run chunk c at the same time on

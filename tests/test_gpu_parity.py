@@ -427,6 +427,27 @@ def test_random_cameras_windows_and_modes_against_oracle(gpu, oracle_mod, ray_la
         assert worst <= TIGHT_TOL
 
 
+def test_steep_secondary_passes(gpu, oracle_mod, kernel_variant):
+    """Lights that barely leave their major axis: the second pass runs along an axis the light hardly travels, so its taps
+    sit up to a dozen texels from the pixel — 2-slice chunks (Add), the slice kernel beyond that and for the fused Change."""
+    res, orc = make_pair(gpu, oracle_mod, (64, 56, 72), np.uint16, False, seed=0x5EED0600)
+    world = S.default_world()
+    with res:
+        for d, inten in [((1, 0.02, -0.09), 0.5), ((0.07, -1, 0.03), 0.4), ((-0.02, 0.12, 1), 0.6), ((1, 0.01, -0.03), 0.3)]:
+            light = abi.DirLightParams(d, inten)
+            res.add_dir_light(light, True, world)
+            orc.add_dir_light(light, True, world)
+            assert_light_equal(res, orc)
+        old = abi.DirLightParams((1, 0.02, -0.09), 0.5)
+        new = abi.DirLightParams((1, 0.03, -0.1), 0.5)
+        res.change_dir_light(old, new, world)
+        orc.change_dir_light(old, new, world)
+        assert_light_equal(res, orc)
+        counters = res.launch_counters()
+        if kernel_variant == "chunk":
+            assert counters["chunk"] > 0, counters
+
+
 # ---- batched multi-light add (SURVEY.md §8f N4) -------------------------------------------------------------------
 
 @pytest.mark.parametrize("light_32bit", [False, True])
