@@ -439,7 +439,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
     // workgroup of the whole pass, computed up front, and per span the ascending list of the workgroups with work
-    plan.sparse = !getenv("TBRM_NO_SPARSE_OCC") && !r->resident; // (the per-brick value ranges are not kept for partly resident volumes)
+    plan.sparse = !getenv("TBRM_NO_SPARSE_OCC");
     plan.work_list = plan.sparse && !getenv("TBRM_NO_OCC_LIST");
     p.occ_groups = ceil_div(S, kOccSlices);
     plan.flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
@@ -704,8 +704,12 @@ int ensure_skipping(tbrm_resources* r)
 {
     const int nb = r->bn[0] * r->bn[1] * r->bn[2];
     if (!r->minmax_valid) {
-        BrickParams bp{data_view(r), r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP,
-            r->bn[0], r->bn[1], r->bn[2], r->d_minmax};
+        // a brick's range covers its +1 apron: of a slab-resident volume the last resident layer has none (unless it is the
+        // volume's last layer and the apron clamps onto it, or wraps onto a resident layer 0)
+        const tbrm_resources::Residency& q = r->res_data;
+        const bool clamp = r->desc.data_address_mode == TBRM_ADDRESS_CLAMP;
+        const int bz1 = (q.hi == r->bn[2] && (clamp || q.lo == 0)) ? q.hi : q.hi - 1;
+        BrickParams bp{data_view(r), clamp ? ADDR_CLAMP : ADDR_WRAP, r->bn[0], r->bn[1], r->bn[2], r->d_minmax, q.lo, bz1};
         HIP_TRY(launch_brick_minmax(bp, r->stream));
         r->minmax_valid = true;
         r->empty_valid = false;
@@ -1212,6 +1216,7 @@ int tbrm_upload_volume_slices(tbrm_resources* r, int32_t z_begin, int32_t z_coun
     if (code != TBRM_OK) return code;
     HIP_TRY(e1);
     r->has_volume = true;
+    r->minmax_valid = false;
     return TBRM_OK;
 }
 
@@ -1312,7 +1317,7 @@ int tbrm_raymarch_lit_slab_device(tbrm_resources* r, const tbrm_camera* cam, con
     p.slab_dir = direction > 0 ? 1 : (direction < 0 ? -1 : 0);
     if (r->resident && (slab->z_begin != r->owned.z_begin || slab->z_end != r->owned.z_end))
         return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle marches its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
-    if (rp->enable_skipping && !r->resident) {
+    if (rp->enable_skipping) {
         if (int e = ensure_skipping(r)) return e;
         p.empty_bits = r->d_empty;
         p.skip_dist = r->d_dist[0];

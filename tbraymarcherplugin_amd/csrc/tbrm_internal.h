@@ -156,6 +156,7 @@ struct BrickParams {
     int addr_mode;
     int bnx, bny, bnz;
     float2* minmax;
+    int bz0, bz1;     // brick layers whose voxels (and +1 apron) may be read; the others get the range [-inf, +inf] (never empty)
 };
 
 struct EmptyParams {

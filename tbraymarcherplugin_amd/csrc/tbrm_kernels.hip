@@ -563,6 +563,10 @@ __global__ __launch_bounds__(64) void k_brick_minmax(const BrickParams p)
 {
     const int b = blockIdx.x;
     const int bx = b % p.bnx, by = (b / p.bnx) % p.bny, bz = b / (p.bnx * p.bny);
+    if (bz < p.bz0 || bz >= p.bz1) { // slab-resident volumes: not held here
+        if (threadIdx.x == 0) p.minmax[b] = make_float2(-__builtin_inff(), __builtin_inff());
+        return;
+    }
     float mn = __builtin_inff(), mx = -__builtin_inff();
     bool nan = false;
     for (int t = threadIdx.x; t < 9 * 9 * 9; t += 64) {
