@@ -43,3 +43,27 @@ def test_facade_tick_policy_on_gpu(tmp_path, gpu):
     assert lines["batched_reset"].startswith("resets=4 adds=12 ")          # bBatchLightsOnReset: one tbrm_add_dir_lights call
     assert abs(float(lines["batched_reset"].split("mean_alpha=")[1]) - mean_a) < 1e-6  # alpha does not depend on the light
     assert "slice=0" in lines["launches"] and "raymarch=4" in lines["launches"]  # two lit + one intensity + one octree frame
+
+
+SLABS_SRC = os.path.join(ROOT, "tests", "cpp", "slabs_test.cpp")
+
+
+def build_slabs(tmp_path):
+    exe = str(tmp_path / "slabs_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                    SLABS_SRC, "-o", exe, "-L", LIB_DIR, "-ltbrm", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{LIB_DIR}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_slab_driver_compiles_and_links_with_gxx(tmp_path, abi_mod):
+    """include/tbrm_slabs.hpp (FSlabGroup: the single-process C++ driver of the slab-partitioned operators)"""
+    assert os.path.exists(build_slabs(tmp_path))
+
+
+@pytest.mark.gpu
+def test_slab_driver_on_gpu(tmp_path, gpu):
+    """two slab-resident handles driven from C++: light volume and frame bit-identical to one whole handle"""
+    p = subprocess.run([build_slabs(tmp_path)], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
+    assert "light volume: 0 voxels differ" in p.stdout and "frame: identical" in p.stdout
