@@ -164,6 +164,13 @@ struct URaymarchUtils { // RaymarchUtils.h:33-93; all static, like the Blueprint
         OutTexture.assign(256 * 4, 0.0f);
         tbrm_make_default_tf_lut(OutTexture.data());
     }
+    // CreateBufferTextures / ReleaseOneAxisReadWriteBufferResources (RaymarchUtils.cpp:176-217): the four read/write
+    // buffers per axis belong to the tbrm handle (created with it, released with it: tbrm_resources_create / _destroy), so
+    // a host has nothing to create or release; the names are kept so that call sites compile unchanged.
+    struct OneAxisReadWriteBufferResources {}; // RaymarchTypes.h:75-81
+    static void CreateBufferTextures(int /*SizeX*/, int /*SizeY*/, int /*PixelFormat*/, OneAxisReadWriteBufferResources& /*RWBuffers*/) {}
+    static void ReleaseOneAxisReadWriteBufferResources(OneAxisReadWriteBufferResources& /*Buffer*/) {}
+
     // The Blueprint-pure helpers (RaymarchUtils.cpp:219-252)
     static void GetVolumeTextureDimensions(const FBasicRaymarchRenderingResources* Resources, int32_t Dimensions[3])
     {
