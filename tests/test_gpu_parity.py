@@ -509,3 +509,78 @@ def test_batched_light_removal_matches_oracle_replay(gpu, oracle_mod):
             if lb >= 0:
                 orc.add_dir_light_pass(lights[1 + lb], False, world, pb)
         assert_light_equal(res, orc)
+
+
+# ---- randomized sweep of the light operators --------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_light_operator_sequences_against_oracle(gpu, oracle_mod, seed):
+    """Seeded random scenes — ragged dimensions, data / light formats, half-resolution light volume, border modes, transfer
+    functions and windows, rotated and non-uniformly scaled volumes, clip planes — and random sequences of Add / Remove /
+    Change / batched adds with random, near-axis and near-diagonal light directions. UNORM8 light volumes bit-exact."""
+    rng = np.random.default_rng(0x5EED0700 + seed)
+    dims = tuple(int(v) for v in rng.integers(17, 61, size=3))
+    dtype = [np.uint8, np.uint16, np.float32][seed % 3]
+    light_32bit = bool(rng.integers(0, 2)) if seed % 4 == 3 else False
+    half_res = bool(seed % 5 == 2)
+    border = abi.BORDER_EXACT_FLOAT if seed % 4 == 1 else abi.BORDER_ENGINE_8BIT
+    window = (float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.4, 1.2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    res, orc = make_pair(gpu, oracle_mod, dims, dtype, light_32bit, half_res, abi.ADDRESS_WRAP, border, "AB"[seed % 2], window,
+                         seed=0x5EED0710 + seed)
+    if seed % 2:
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        scale = tuple(float(v) for v in rng.uniform(60, 140, size=3))
+        tr = abi.identity_transform(scale, tuple(float(v) for v in rng.uniform(-20, 20, size=3)), tuple(float(v) for v in q))
+        cd = rng.normal(size=3)
+        world = abi.make_world(tr, tuple(float(v) for v in rng.uniform(-30, 30, size=3)), tuple(float(v) for v in cd / np.linalg.norm(cd)))
+    else:
+        world = S.default_world()
+
+    def random_light():
+        kind = rng.integers(0, 4)
+        if kind == 0:    # anywhere
+            d = rng.normal(size=3)
+        elif kind == 1:  # nearly along an axis
+            d = rng.normal(size=3) * 0.08
+            d[rng.integers(0, 3)] = rng.choice([-1.0, 1.0])
+        elif kind == 2:  # nearly on a face diagonal (two weights close to each other)
+            d = rng.normal(size=3) * 0.05
+            a, b = rng.choice(3, size=2, replace=False)
+            d[a] = rng.choice([-1.0, 1.0])
+            d[b] = d[a] * rng.choice([-1.0, 1.0]) * rng.uniform(0.97, 1.03)
+        else:            # exactly axis-aligned
+            d = np.zeros(3)
+            d[rng.integers(0, 3)] = rng.choice([-1.0, 1.0])
+        return abi.DirLightParams(tuple(float(v) for v in d), float(rng.uniform(0.1, 0.7)))
+
+    with res:
+        present = []
+        for step in range(7):
+            op = rng.integers(0, 4) if present else 0
+            if op == 0 or len(present) < 2:
+                l = random_light()
+                res.add_dir_light(l, True, world)
+                orc.add_dir_light(l, True, world)
+                present.append(l)
+            elif op == 1:
+                l = present.pop(int(rng.integers(0, len(present))))
+                res.add_dir_light(l, False, world)
+                orc.add_dir_light(l, False, world)
+            elif op == 2:
+                i = int(rng.integers(0, len(present)))
+                old = present[i]
+                d = np.array([old.light_direction.x, old.light_direction.y, old.light_direction.z])
+                new_d = d + rng.normal(size=3) * (0.05 if rng.integers(0, 2) else 0.8) * max(np.linalg.norm(d), 1e-3)
+                new = abi.DirLightParams(tuple(float(v) for v in new_d), float(rng.uniform(0.1, 0.7)))
+                res.change_dir_light(old, new, world)
+                orc.change_dir_light(old, new, world)
+                present[i] = new
+            else:
+                batch = [random_light() for _ in range(3)]
+                for la, pa, lb, pb in res.add_dir_lights(batch, True, world):
+                    orc.add_dir_light_pass(batch[la], True, world, pa)
+                    if lb >= 0:
+                        orc.add_dir_light_pass(batch[lb], True, world, pb)
+                present += batch
+            assert_light_equal(res, orc)
