@@ -513,13 +513,14 @@ def test_batched_light_removal_matches_oracle_replay(gpu, oracle_mod):
 
 # ---- randomized sweep of the light operators --------------------------------------------------------------------------
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + [100, 101, 102, 103])
 def test_random_light_operator_sequences_against_oracle(gpu, oracle_mod, seed):
     """Seeded random scenes — ragged dimensions, data / light formats, half-resolution light volume, border modes, transfer
     functions and windows, rotated and non-uniformly scaled volumes, clip planes — and random sequences of Add / Remove /
     Change / batched adds with random, near-axis and near-diagonal light directions. UNORM8 light volumes bit-exact."""
     rng = np.random.default_rng(0x5EED0700 + seed)
-    dims = tuple(int(v) for v in rng.integers(17, 61, size=3))
+    big = seed >= 100  # several tiles per plane, several occlusion spans per pass (seconds of oracle time per operator)
+    dims = tuple(int(v) for v in (rng.integers(130, 201, size=3) if big else rng.integers(17, 61, size=3)))
     dtype = [np.uint8, np.uint16, np.float32][seed % 3]
     light_32bit = bool(rng.integers(0, 2)) if seed % 4 == 3 else False
     half_res = bool(seed % 5 == 2)
@@ -556,7 +557,7 @@ def test_random_light_operator_sequences_against_oracle(gpu, oracle_mod, seed):
 
     with res:
         present = []
-        for step in range(7):
+        for step in range(4 if big else 7):
             op = rng.integers(0, 4) if present else 0
             if op == 0 or len(present) < 2:
                 l = random_light()
