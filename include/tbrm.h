@@ -33,7 +33,8 @@ enum {
     TBRM_ERR_NOT_INITIALIZED = 2, /* a resource the reference null-checks is missing -> light_added=false */
     TBRM_ERR_NO_DEVICE = 3,     /* no HIP device / HIP runtime error (message via tbrm_last_error) */
     TBRM_ERR_OUT_OF_MEMORY = 4,
-    TBRM_ERR_UNSUPPORTED = 5
+    TBRM_ERR_UNSUPPORTED = 5,
+    TBRM_ERR_AXES_DIFFER = 6    /* tbrm_slab_light_begin: a Change across major axes; run remove + add (nothing was enqueued) */
 };
 
 /* ---- pixel formats of UVolumeTexture-shaped buffers (VolumeInfo.cpp:96-119) ---- */
@@ -250,8 +251,10 @@ typedef struct tbrm_slab_pass {
 } tbrm_slab_pass;
 
 /* Takes the operation apart: removed == NULL: AddDirLight(light, added); else ChangeDirLight(removed -> light), which
- * returns TBRM_ERR_UNSUPPORTED when the major axes differ (run remove + add, as LightingShaders.cpp:192-198 does).
- * *n_passes = axis passes to run (0..2), in order. Nothing is enqueued. */
+ * returns TBRM_ERR_AXES_DIFFER when the major axes differ (run remove + add, as LightingShaders.cpp:192-198 does).
+ * *n_passes = axis passes to run (0..2), in order. Nothing is enqueued; every pass is checked first, so an operation
+ * either runs completely or not at all: TBRM_ERR_UNSUPPORTED when one of its passes needs the slice-per-launch kernel
+ * (taps more than 16 texels from the pixel, 12 for a Change), which has no slab form. */
 TBRM_API int tbrm_slab_light_begin(tbrm_resources* res, const tbrm_dir_light_params* removed,
                                    const tbrm_dir_light_params* light, int added, const tbrm_world_params* world,
                                    const tbrm_slab* slab, int32_t* n_passes);

@@ -155,7 +155,7 @@ private:
         for (int k = 0; k < N; ++k) {
             const tbrm_slab S = Slab(k);
             const int Code = tbrm_slab_light_begin(Handles[k], Removed, &Light, bAdded ? 1 : 0, &World, &S, &NumPasses);
-            if (Code == TBRM_ERR_UNSUPPORTED && Removed) return false;
+            if (Code == TBRM_ERR_AXES_DIFFER && Removed) return false;
             Check(Code, "tbrm_slab_light_begin");
         }
         for (int32_t Pass = 0; Pass < NumPasses; ++Pass) {

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TBRM_LIB_PATH") or os.path.join(HERE, "lib", "libtbrm.so")  # override: A/B a second build
 
 # enums (include/tbrm.h)
-OK, ERR_INVALID_ARG, ERR_NOT_INITIALIZED, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED = range(6)
+OK, ERR_INVALID_ARG, ERR_NOT_INITIALIZED, ERR_NO_DEVICE, ERR_OUT_OF_MEMORY, ERR_UNSUPPORTED, ERR_AXES_DIFFER = range(7)
 FMT_G8, FMT_G16, FMT_R32_FLOAT = 0, 1, 2
 ADDRESS_WRAP, ADDRESS_CLAMP = 0, 1
 BORDER_ENGINE_8BIT, BORDER_EXACT_FLOAT = 0, 1

@@ -1103,7 +1103,7 @@ int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* remove
         const bool a_ok = host_light_passes(*light, *world, r->lv_dims, r->desc.border_mode, ap, &an);
         if (!r_ok || !a_ok) return TBRM_OK;
         if (rp[0].face != ap[0].face || rp[1].face != ap[1].face)
-            return fail(TBRM_ERR_UNSUPPORTED, "the two lights' major axes differ: remove the old light and add the new one "
+            return fail(TBRM_ERR_AXES_DIFFER, "the two lights' major axes differ: remove the old light and add the new one "
                                               "(LightingShaders.cpp:192-198)");
         for (int i = 0; i < 2; ++i) {
             if (rp[i].light_alpha == 0.0f && ap[i].light_alpha == 0.0f && rp[i].border_light == 0.0f && ap[i].border_light == 0.0f)
@@ -1113,6 +1113,15 @@ int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* remove
             ++op.n;
         }
         op.b_added = 0.0f;
+    }
+    for (int i = 0; i < op.n; ++i) { // all or nothing: every pass has to have a chunked (slab-capable) form
+        ChunkFit fit;
+        if (!chunk_fit(r, op.a[i], op.change ? &op.r[i] : nullptr, fit)) {
+            const int n = op.n;
+            op.n = 0;
+            return fail(TBRM_ERR_UNSUPPORTED, "pass %d of %d (axis %d) needs the slice-per-launch kernel, which has no slab-partitioned form: %s",
+                        i, n, (int) op.a[i].axis, g_plan_note);
+        }
     }
     *n_passes = op.n;
     return TBRM_OK;

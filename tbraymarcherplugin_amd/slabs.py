@@ -187,7 +187,7 @@ def light_operation(members, fabric, removed, light, added, world):
     try:
         counts = [m.light_begin(removed, light, added, world) for m in members]
     except abi.TbrmError as e:
-        if e.code == abi.ERR_UNSUPPORTED and removed is not None:
+        if e.code == abi.ERR_AXES_DIFFER and removed is not None:
             return False
         raise
     for i in range(counts[0] if counts else 0):

@@ -349,3 +349,103 @@ def test_slab_resident_handles_light_and_render_like_one_handle(gpu, addr, n_sla
     finally:
         for res in handles:
             res.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_slab_resident_scenes_against_one_handle(gpu, seed):
+    """Seeded random scenes on slab-resident handles: ragged x / y sizes, 2-4 slabs, formats, rotated and scaled volumes with
+    clip planes, random light sequences, random cameras — light volume and frame bit-identical to one whole handle. A light
+    whose pass only the slice kernel can run (no slab form) is skipped on both sides."""
+    import torch
+
+    rng = np.random.default_rng(0x5EED0800 + seed)
+    depth = int(rng.choice([64, 96, 128]))
+    n_slabs = int(rng.choice([s for s in (2, 3, 4) if depth % (32 * s) == 0]))
+    dims = (int(rng.integers(40, 150)), int(rng.integers(40, 150)), depth)
+    dtype = [np.uint8, np.uint16, np.float32][seed % 3]
+    light_32bit = seed % 4 == 3
+    addr = abi.ADDRESS_CLAMP if seed % 2 else abi.ADDRESS_WRAP
+    vol = small_volume(dims, dtype, 0x5EED0810 + seed)
+    lut = abi.color_curve_to_lut(S.tf_keys("AB"[seed % 2]))
+    w = abi.WindowingParams(float(rng.uniform(0.35, 0.65)), float(rng.uniform(0.5, 1.1)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+    fmt = abi.DTYPE_FMT[np.dtype(dtype)]
+    full = abi.Resources(dims, fmt, light_32bit, False, 0, addr)
+    full.upload_volume(vol)
+    bounds = slabs.slab_bounds(depth, n_slabs)
+    parts = [abi.Resources(dims, fmt, light_32bit, False, 0, addr, owned=abi.Slab(*bounds[k])) for k in range(n_slabs)]
+    dev = torch.device("cuda", 0)
+    if seed % 2:
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        tr = abi.identity_transform(tuple(float(v) for v in rng.uniform(70, 130, size=3)), tuple(float(v) for v in rng.uniform(-15, 15, size=3)),
+                                    tuple(float(v) for v in q))
+        cd = rng.normal(size=3)
+        world = abi.make_world(tr, tuple(float(v) for v in rng.uniform(-25, 25, size=3)), tuple(float(v) for v in cd / np.linalg.norm(cd)))
+    else:
+        world = S.default_world()
+    try:
+        for res in [full] + parts:
+            res.set_tf_lut(lut)
+            res.set_windowing(w)
+            res.clear_light_volume(0.0)
+        for res in parts:
+            res.upload_resident_part(vol)
+        members = [slabs.DeviceSlab(res, k, *bounds[k]) for k, res in enumerate(parts)]
+        fabric = slabs.make_fabric([b[0] for b in bounds] + [depth])
+        present, ran = [], 0
+        for step in range(6):
+            d = rng.normal(size=3)
+            if step % 3 == 2:
+                d *= 0.1
+                d[rng.integers(0, 3)] = rng.choice([-1.0, 1.0])
+            light = abi.DirLightParams(tuple(float(v) for v in d), float(rng.uniform(0.15, 0.6)))
+            def unsupported(fn):
+                """runs fn; True when the slab form declined the operation (checked before anything is enqueued)"""
+                try:
+                    fn()
+                    return False
+                except abi.TbrmError as e:
+                    assert e.code == abi.ERR_UNSUPPORTED, e
+                    return True
+
+            if present and step % 2:
+                old = present[int(rng.integers(0, len(present)))]
+                fused = [None]
+                if unsupported(lambda: fused.__setitem__(0, slabs.light_operation(members, fabric, old, light, True, world))):
+                    continue
+                if fused[0]:
+                    full.change_dir_light(old, light, world)
+                    present[present.index(old)] = light
+                else:  # across faces: remove, then add — each all or nothing
+                    if unsupported(lambda: slabs.add_dir_light(members, fabric, old, False, world)):
+                        continue
+                    full.add_dir_light(old, False, world)
+                    present.remove(old)
+                    if not unsupported(lambda: slabs.add_dir_light(members, fabric, light, True, world)):
+                        full.add_dir_light(light, True, world)
+                        present.append(light)
+            else:
+                if unsupported(lambda: slabs.add_dir_light(members, fabric, light, True, world)):
+                    continue
+                full.add_dir_light(light, True, world)
+                present.append(light)
+            ran += 1
+        assert ran > 0
+        ref = full.download_light_volume()
+        for m in members:
+            got = m.res.download_light_slices(m.z_begin, m.z_end - m.z_begin)
+            assert np.array_equal(got, ref[m.z_begin:m.z_end]), f"scene {seed}: light volume of slab {m.slab_index}"
+        slabs.exchange_light_halos(members, fabric)
+        for case in range(3):
+            eye = rng.normal(size=3)
+            eye = eye / np.linalg.norm(eye) * float(rng.choice([30.0, 120.0, 260.0]))
+            cam = abi.look_at_camera(eye, tuple(float(v) for v in rng.uniform(-10, 10, size=3)), (0.0, 0.0, 1.0), 55.0, 56, 40)
+            rp = abi.RaymarchParams(float(rng.integers(30, 200)), int(rng.integers(-1, 8)), bool(case % 2))
+            tile = abi.Tile(0, 0, 56, 40, 1)
+            want = full.raymarch_lit(cam, tile, rp, world)
+            got = slabs.render_lit(members, fabric, cam, tile, rp, world, lambda: torch.zeros((40, 56, 4), dtype=torch.float32, device=dev))
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want), f"scene {seed} camera {case}"
+    finally:
+        for res in [full] + parts:
+            res.close()
