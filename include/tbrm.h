@@ -248,13 +248,16 @@ typedef struct tbrm_slab_pass {
     int32_t first_chunk;       /* this handle runs chunks [first_chunk, first_chunk + n_chunks) of them */
     int32_t n_chunks;
     int32_t halo_rows;         /* lateral: rows each z neighbour has to supply after every chunk (else 0) */
+    int32_t plane_elem_bytes;  /* 4 (float planes of the chunk kernels), or the light volume's element size when a steep pass
+                                  runs one slice per chunk on the reference's read / write buffers (chunk_slices == 1) */
 } tbrm_slab_pass;
 
 /* Takes the operation apart: removed == NULL: AddDirLight(light, added); else ChangeDirLight(removed -> light), which
  * returns TBRM_ERR_AXES_DIFFER when the major axes differ (run remove + add, as LightingShaders.cpp:192-198 does).
  * *n_passes = axis passes to run (0..2), in order. Nothing is enqueued; every pass is checked first, so an operation
- * either runs completely or not at all: TBRM_ERR_UNSUPPORTED when one of its passes needs the slice-per-launch kernel
- * (taps more than 16 texels from the pixel, 12 for a Change), which has no slab form. */
+ * either runs completely or not at all. A pass whose taps lie more than 16 texels from the pixel (12 for a Change) runs
+ * one slice per chunk (tbrm_slab_pass: chunk_slices == 1, halo_rows == the taps' reach); TBRM_ERR_UNSUPPORTED only when
+ * that reach exceeds the slab's own depth. */
 TBRM_API int tbrm_slab_light_begin(tbrm_resources* res, const tbrm_dir_light_params* removed,
                                    const tbrm_dir_light_params* light, int added, const tbrm_world_params* world,
                                    const tbrm_slab* slab, int32_t* n_passes);
@@ -263,7 +266,8 @@ TBRM_API int tbrm_slab_pass_begin(tbrm_resources* res, int32_t pass, tbrm_slab_p
 /* Enqueues this handle's chunk `chunk` (0 .. n_chunks-1) on the handle's stream. */
 TBRM_API int tbrm_slab_pass_chunk(tbrm_resources* res, int32_t chunk);
 /* Device address of the plane of `stream` holding the state BEFORE chunk `boundary` (boundary == n_chunks: after the
- * last chunk): plane_w * plane_h floats, row-major, valid in this handle's rows (lateral) or everywhere (along z). */
+ * last chunk): plane_w * plane_h elements of plane_elem_bytes, row-major, valid in this handle's rows (lateral) or
+ * everywhere (along z). */
 TBRM_API int tbrm_slab_pass_plane(tbrm_resources* res, int32_t boundary, int32_t stream, void** device_plane);
 
 /* ---- slab-resident handles: a GPU that holds only its part of the two volumes -------------------------------------

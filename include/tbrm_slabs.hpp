@@ -161,7 +161,7 @@ private:
         for (int32_t Pass = 0; Pass < NumPasses; ++Pass) {
             std::vector<tbrm_slab_pass> Desc(N);
             for (int k = 0; k < N; ++k) Check(tbrm_slab_pass_begin(Handles[k], Pass, &Desc[k]), "tbrm_slab_pass_begin");
-            const size_t RowBytes = (size_t) Desc[0].plane_w * sizeof(float);
+            const size_t RowBytes = (size_t) Desc[0].plane_w * (size_t) Desc[0].plane_elem_bytes;
             if (Desc[0].lateral) { // every slab runs every chunk on its rows; halo rows cross the slab boundaries after each
                 for (int32_t c = 0; c < Desc[0].n_chunks; ++c) {
                     for (int k = 0; k < N; ++k) Check(tbrm_slab_pass_chunk(Handles[k], c), "tbrm_slab_pass_chunk");

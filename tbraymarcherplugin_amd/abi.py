@@ -109,7 +109,7 @@ class Slab(C.Structure):  # tbrm_slab: the light-volume z range a handle owns
 class SlabPass(C.Structure):  # tbrm_slab_pass
     _fields_ = [("axis", C.c_int32), ("dir", C.c_int32), ("lateral", C.c_int32), ("streams", C.c_int32),
                 ("plane_w", C.c_int32), ("plane_h", C.c_int32), ("chunk_slices", C.c_int32), ("chunks_of_pass", C.c_int32),
-                ("first_chunk", C.c_int32), ("n_chunks", C.c_int32), ("halo_rows", C.c_int32)]
+                ("first_chunk", C.c_int32), ("n_chunks", C.c_int32), ("halo_rows", C.c_int32), ("plane_elem_bytes", C.c_int32)]
 
 
 # every symbol include/tbrm.h declares (tests/test_abi.py checks the header against this list and the .so)

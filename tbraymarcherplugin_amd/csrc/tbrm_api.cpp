@@ -274,6 +274,11 @@ struct PassPlan {
     // slab-partitioned passes
     bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
     int first_chunk_of_pass = 0, chunks_of_pass = 0;
+    // a slab-partitioned pass whose taps reach too far for the chunk kernels: one slice per "chunk" with the reference's
+    // kernel structure (k_propagate_slice) on the read / write buffers, which then are the planes the host exchanges
+    bool sliced = false;
+    PropParams slice_params{};
+    int halo_rows = 0;          // lateral: rows a slice's taps can reach beyond a slab
 };
 
 // why plan_pass last declined a pass (diagnostics of the slab entry points, which have no fallback)
@@ -319,6 +324,94 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
 
 // Returns TBRM_ERR_UNSUPPORTED (nothing enqueued) when the pass has to take the slice-per-launch path.
 // slab: the light-volume z range this handle owns (null: everything).
+// Rows of the slice plane (z, when the pass runs along x or y) a slice's previous-slice taps can lie from the pixel:
+// what a slab has to fetch from its neighbours after every slice of a slice-per-launch pass. < 0: offsets out of range.
+int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr)
+{
+    int reach = 0;
+    for (const tbrm_light_pass* q : {&pa, pr}) {
+        if (!q) continue;
+        const TapRange t = prev_tap_range(q->td[1], q->prev_pixel_offset[1]);
+        if (!t.ok || !prev_tap_range(q->td[0], q->prev_pixel_offset[0]).ok) return -1;
+        reach = std::max({reach, -t.lo, t.hi});
+    }
+    return reach;
+}
+
+// A slab-partitioned pass with the reference's one-slice-per-launch structure (the chunk kernels declined it): "chunk" c is
+// slice c of what this handle runs, the planes are the pass's read / write buffers in the light volume's format.
+int plan_pass_sliced(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+                     const tbrm_slab& slab, PassPlan& plan)
+{
+    const int nz = r->lv_dims[2], D_pass = pa.td[2];
+    if (slab.z_begin < 0 || slab.z_end > nz || slab.z_begin >= slab.z_end || slab.z_begin % kChunkTile || slab.z_end % kChunkTile || nz % kChunkTile)
+        return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep: bounds and depth must be multiples of %d", slab.z_begin,
+                    slab.z_end, nz, kChunkTile);
+    const int reach = slice_tap_reach(pa, pr);
+    if (reach < 0) return declined("previous-slice offset out of range");
+    plan = PassPlan{};
+    plan.sliced = true;
+    plan.mode = pr ? PASS_CHANGE : PASS_ADD;
+    plan.M = 1;
+    plan.p.W = pa.td[0];
+    plan.p.H = pa.td[1];
+    plan.p.axis = pa.axis;
+    plan.dir = pa.dir;
+    plan.D = D_pass;
+    plan.start = pa.start;
+    plan.chunks_of_pass = D_pass;
+    PropParams& p = plan.slice_params;
+    p = base;
+    p.b_added = b_added;
+    p.axis = pa.axis;
+    for (int c = 0; c < 3; ++c) p.td[c] = pa.td[c];
+    fill_stream(p.a, pa);
+    if (pr) fill_stream(p.r, *pr);
+    p.row_block0 = 0;
+    p.row_blocks = 0;
+    if (pa.axis == 2) {
+        plan.D = slab.z_end - slab.z_begin;
+        plan.start = pa.dir > 0 ? slab.z_begin : slab.z_end - 1;
+        plan.first_chunk_of_pass = pa.dir > 0 ? slab.z_begin : nz - slab.z_end;
+        plan.pass_begins_here = plan.first_chunk_of_pass == 0;
+    } else {
+        if (reach > slab.z_end - slab.z_begin) return declined("a slice's taps reach beyond the neighbouring slab");
+        plan.lateral = true;
+        plan.halo_rows = reach;
+        p.row_block0 = slab.z_begin / 16;
+        p.row_blocks = (slab.z_end - slab.z_begin) / 16;
+    }
+    plan.n_chunks = plan.D;
+    if (r->resident) {
+        if (slab.z_begin != r->owned.z_begin || slab.z_end != r->owned.z_end)
+            return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle runs its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
+    }
+    if (plan.pass_begins_here) { // the buffers start from the light's initial value (LightingShaders.cpp:74-79)
+        const size_t npx = (size_t) pa.td[0] * pa.td[1];
+        const int ax = pa.axis;
+        if (!pr) {
+            HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pa.light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        } else {
+            HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pr->light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pr->light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][2], r->lv_fmt, npx, pa.light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][3], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        }
+    }
+    return TBRM_OK;
+}
+
+// the read buffer of stream si (0: a, 1: r) before this handle's slice number `boundary` (== n_chunks: what its last slice wrote)
+void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si)
+{
+    const int j = plan.start + boundary * plan.dir;
+    const int e = (j % 2 == 0) ? 0 : 1; // LightingShaders.cpp:149-156
+    const int ax = plan.p.axis;
+    if (plan.mode == PASS_ADD) return r->d_buf[ax][e];
+    return si == 0 ? r->d_buf[ax][2 + e] : r->d_buf[ax][e];
+}
+
 // pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
 // pr, both added with b_added / b_added2).
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
@@ -326,7 +419,10 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 {
     g_plan_note = "";
     ChunkFit fit;
-    if (!chunk_fit(r, pa, pr, fit)) return TBRM_ERR_UNSUPPORTED;
+    if (!chunk_fit(r, pa, pr, fit)) {
+        if (!slab || two_stream_mode == PASS_ADD2) return TBRM_ERR_UNSUPPORTED;
+        return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
+    }
     const bool change = pr != nullptr;
     const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
     plan = PassPlan{};
@@ -481,6 +577,24 @@ float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_p
 // Enqueues chunk c of the plan: the occlusion of its span first if the span starts here, then the chain.
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
 {
+    if (plan.sliced) {
+        PropParams sp = plan.slice_params;
+        const int j = plan.start + c * plan.dir;
+        const int e = (j % 2 == 0) ? 0 : 1, ax = plan.p.axis;
+        sp.loop = j;
+        if (plan.mode == PASS_ADD) {
+            sp.a.read = r->d_buf[ax][e];
+            sp.a.write = r->d_buf[ax][1 - e];
+        } else {
+            sp.r.read = r->d_buf[ax][e];
+            sp.r.write = r->d_buf[ax][1 - e];
+            sp.a.read = r->d_buf[ax][2 + e];
+            sp.a.write = r->d_buf[ax][3 - e];
+        }
+        HIP_TRY(launch_propagate_slice(sp, plan.mode != PASS_ADD, r->stream));
+        ++r->launches[1];
+        return TBRM_OK;
+    }
     ChunkParams p = plan.p;
     const int M = plan.M, S = plan.S, D = plan.D, W = p.W, H = p.H;
     const int sp = (c * M) / S;
@@ -1116,11 +1230,14 @@ int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* remove
     }
     for (int i = 0; i < op.n; ++i) { // all or nothing: every pass has to have a chunked (slab-capable) form
         ChunkFit fit;
-        if (!chunk_fit(r, op.a[i], op.change ? &op.r[i] : nullptr, fit)) {
+        const tbrm_light_pass* pr_i = op.change ? &op.r[i] : nullptr;
+        const int reach = slice_tap_reach(op.a[i], pr_i);
+        const bool slice_form = reach >= 0 && (op.a[i].axis == 2 || reach <= slab->z_end - slab->z_begin); // one slice per step
+        if (!chunk_fit(r, op.a[i], pr_i, fit) && !slice_form) {
             const int n = op.n;
             op.n = 0;
-            return fail(TBRM_ERR_UNSUPPORTED, "pass %d of %d (axis %d) needs the slice-per-launch kernel, which has no slab-partitioned form: %s",
-                        i, n, (int) op.a[i].axis, g_plan_note);
+            return fail(TBRM_ERR_UNSUPPORTED, "pass %d of %d (axis %d) has no slab-partitioned form: its taps reach %d rows from the pixel (%s)",
+                        i, n, (int) op.a[i].axis, reach, g_plan_note);
         }
     }
     *n_passes = op.n;
@@ -1136,8 +1253,7 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
     op.current = -1;
     const int e = plan_pass(r, op.base, op.a[pass], op.change ? &op.r[pass] : nullptr, op.b_added, &op.slab, op.plan);
     if (e == TBRM_ERR_UNSUPPORTED)
-        return fail(e, "pass %d (axis %d) needs the slice-per-launch kernel, which has no slab-partitioned form: %s", (int) pass,
-                    (int) op.a[pass].axis, g_plan_note);
+        return fail(e, "pass %d (axis %d) has no slab-partitioned form: %s", (int) pass, (int) op.a[pass].axis, g_plan_note);
     if (e) return e;
     op.current = pass;
     const PassPlan& pl = op.plan;
@@ -1151,7 +1267,8 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
     out->chunks_of_pass = pl.chunks_of_pass;
     out->first_chunk = pl.first_chunk_of_pass;
     out->n_chunks = pl.n_chunks;
-    out->halo_rows = pl.lateral ? kChunkTile : 0;
+    out->halo_rows = pl.lateral ? (pl.sliced ? pl.halo_rows : kChunkTile) : 0;
+    out->plane_elem_bytes = pl.sliced ? (r->lv_fmt == FMT_U8 ? 1 : 4) : 4;
     return TBRM_OK;
 }
 
@@ -1170,7 +1287,7 @@ int tbrm_slab_pass_plane(tbrm_resources* r, int32_t boundary, int32_t stream, vo
     const PassPlan& pl = r->slab_op->plan;
     if (boundary < 0 || boundary > pl.n_chunks || stream < 0 || stream >= (pl.two_streams() ? 2 : 1))
         return fail(TBRM_ERR_INVALID_ARG, "boundary %d / stream %d out of range", boundary, stream);
-    *device_plane = plan_plane(r, boundary, stream);
+    *device_plane = pl.sliced ? sliced_plane(r, pl, boundary, stream) : (void*) plan_plane(r, boundary, stream);
     return TBRM_OK;
 }
 

@@ -55,6 +55,7 @@ struct PropParams {
     int axis;          // 0,1,2: permutation (LightingShaderUtils.cpp:227-249)
     int td[3];         // TransposedDimensions
     int loop;          // Loop (slice index along the axis)
+    int row_block0, row_blocks; // 16-row blocks of the slice plane this launch covers (slab-partitioned passes; else all)
     float b_added;     // +1 / -1 (Add only)
     PropStream a;      // the added light (Add: the only stream)
     PropStream r;      // the removed light (Change only)

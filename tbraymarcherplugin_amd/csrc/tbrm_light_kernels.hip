@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_propagate_slice(const PropParams p)
     s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
     __syncthreads();
     const int px = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int py = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int py = (blockIdx.y + p.row_block0) * 16 + (threadIdx.x >> 4);
     if (px >= p.td[0] || py >= p.td[1]) return; // D3D drops the overhanging threads' writes
     int pos[3];
     if (p.axis == 0) { pos[0] = p.loop; pos[1] = px; pos[2] = py; }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_propagate_slice(const PropParams p)
 template <int DFMT, int LFMT>
 static hipError_t launch_prop2(const PropParams& p, bool change, hipStream_t s)
 {
-    const dim3 grid((p.td[0] + 15) / 16, (p.td[1] + 15) / 16), block(256);
+    const dim3 grid((p.td[0] + 15) / 16, p.row_blocks > 0 ? p.row_blocks : (p.td[1] + 15) / 16), block(256);
     if (change) hipLaunchKernelGGL((k_propagate_slice<DFMT, LFMT, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((k_propagate_slice<DFMT, LFMT, false>), grid, block, 0, s, p);
     return hipGetLastError();

@@ -68,9 +68,10 @@ class DeviceSlab:
 
         ptr = self.res.slab_pass_plane(boundary, stream)
         h, w = self._pass.plane_h, self._pass.plane_w
+        typestr = "<f4" if self._pass.plane_elem_bytes == 4 else "|u1"  # float planes; UNORM8 read / write buffers of a sliced pass
 
         class _Alias:
-            __cuda_array_interface__ = {"shape": (h, w), "typestr": "<f4", "data": (ptr, False), "version": 2}
+            __cuda_array_interface__ = {"shape": (h, w), "typestr": typestr, "data": (ptr, False), "version": 2}
 
         return torch.as_tensor(_Alias(), device=torch.device("cuda", self.res.device))
 

@@ -449,3 +449,35 @@ def test_random_slab_resident_scenes_against_one_handle(gpu, seed):
     finally:
         for res in [full] + parts:
             res.close()
+
+
+@pytest.mark.parametrize("light_32bit", [False, True])
+@pytest.mark.parametrize("dims,steep", [((32, 120, 128), (-0.15, 0.05, 1)), ((128, 120, 64), (1, 0.05, -0.12))])  # lateral / along z
+def test_slabs_run_steep_passes_slice_by_slice(gpu, dims, steep, light_32bit):
+    """Anisotropic volumes: a light close to an axis makes its second pass fetch the previous slice dozens of texels away —
+    beyond the chunk kernels. In slab form such a pass runs one slice per step on the reference's read / write buffers
+    (UNORM8 or float), halo rows = the taps' reach; bit-identical to the unpartitioned operator (which uses the same kernel)."""
+    _, _, _, handles = make_handles(3, dims, np.uint16, light_32bit)
+    full, parts = handles[0], handles[1:]
+    members, fabric, _ = slab_setup(parts, 2)
+    world = S.default_world()
+    try:
+        a = abi.DirLightParams(steep, 0.5)
+        full.add_dir_light(a, True, world)
+        slabs.add_dir_light(members, fabric, a, True, world)
+        assert_slabs_equal(full, members, "steep add")
+        assert full.launch_counters()["slice"] > 0 and parts[0].launch_counters()["slice"] > 0, "the test is meant to reach the slice kernel"
+        b = abi.DirLightParams(tuple(v * (1.0 + 0.1 * i) for i, v in enumerate(steep)), 0.4)  # same faces: fused Change, slice by slice
+        full.change_dir_light(a, b, world)
+        slabs.change_dir_light(members, fabric, a, b, world)
+        assert_slabs_equal(full, members, "steep fused change")
+        c = abi.DirLightParams((0.3, 0.5, -0.8), 0.3)
+        full.change_dir_light(b, c, world)
+        slabs.change_dir_light(members, fabric, b, c, world)
+        assert_slabs_equal(full, members, "change across faces")
+        full.add_dir_light(c, False, world)
+        slabs.add_dir_light(members, fabric, c, False, world)
+        assert_slabs_equal(full, members, "remove")
+    finally:
+        for h in handles:
+            h.close()
