@@ -585,3 +585,68 @@ def test_random_light_operator_sequences_against_oracle(gpu, oracle_mod, seed):
                         orc.add_dir_light_pass(batch[lb], True, world, pb)
                 present += batch
             assert_light_equal(res, orc)
+
+
+# ---- degenerate sizes and values -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dims", [(1, 1, 1), (3, 1, 9), (9, 17, 2), (8, 8, 8), (2, 33, 1)])
+def test_tiny_and_flat_volumes(gpu, oracle_mod, dims):
+    res, orc = make_pair(gpu, oracle_mod, dims, np.uint16, False, seed=0x5EED0900)
+    world = S.default_world()
+    with res:
+        for d, inten in [((1, .35, -.5), 0.5), ((0, 0, -1), 0.4), ((-.4, 1, -.3), 0.3)]:
+            light = abi.DirLightParams(d, inten)
+            res.add_dir_light(light, True, world)
+            orc.add_dir_light(light, True, world)
+            assert_light_equal(res, orc)
+        old, new = abi.DirLightParams((-.4, 1, -.3), 0.3), abi.DirLightParams((-.45, 1, -.2), 0.35)
+        res.change_dir_light(old, new, world)
+        orc.change_dir_light(old, new, world)
+        assert_light_equal(res, orc)
+        cam = S.default_camera(24, 16)
+        for steps in (0.4, 1.0, 7.5, 300.0):
+            rp = abi.RaymarchParams(steps, -1, True)
+            got = res.raymarch_lit(cam, abi.Tile(0, 0, 24, 16, 1), rp, world)
+            want, _ = orc.raymarch_lit(cam, abi.Tile(0, 0, 24, 16, 1), rp, world)
+            np.testing.assert_allclose(got, want, rtol=0, atol=TIGHT_TOL, err_msg=f"steps {steps}")
+        assert res.raymarch_lit(cam, abi.Tile(0, 0, 0, 0, 1), rp, world).size == 0  # an empty tile is a no-op
+
+
+def test_non_finite_voxels_and_degenerate_windows(gpu, oracle_mod):
+    """float data with NaN / Inf voxels, and windows of width 0 and below: whatever the arithmetic spec yields, both sides
+    yield it (NaN light values store as 0 in UNORM8, D3D's rule)."""
+    dims = (20, 18, 22)
+    vol = small_volume(dims, np.float32, 0x5EED0901)
+    vol[3, 4, 5] = np.nan
+    vol[10, 9, 8] = np.inf
+    vol[15, 2, 17] = -np.inf
+    vol[7, :, 3] = 2.5   # outside [0, 1]
+    vol[8, 6, :] = -1.0
+    world = S.default_world()
+    cam = S.default_camera(32, 24)
+    for light_32bit in (False, True):
+        for window in [(0.5, 0.9, True, False), (0.5, 0.0, True, True), (0.4, -0.3, False, False), (0.5, 1e-30, False, True)]:
+            res = abi.Resources(dims, abi.FMT_R32_FLOAT, light_32bit, False, 0)
+            orc = oracle_mod.OracleScene(vol, light_32bit, False, abi.ADDRESS_WRAP, abi.BORDER_ENGINE_8BIT)
+            lut = abi.color_curve_to_lut(S.tf_keys("A"))
+            w = abi.WindowingParams(*window)
+            with res:
+                res.upload_volume(vol)
+                res.set_tf_lut(lut)
+                res.set_windowing(w)
+                orc.set_tf_lut(lut)
+                orc.set_windowing(w)
+                res.clear_light_volume(0.0)
+                for d, inten in [((1, .35, -.5), 0.5), ((.2, -.3, -1), 0.4)]:
+                    light = abi.DirLightParams(d, inten)
+                    res.add_dir_light(light, True, world)
+                    orc.add_dir_light(light, True, world)
+                got = res.download_light_volume()
+                if light_32bit:
+                    np.testing.assert_allclose(got, orc.light, rtol=0, atol=TIGHT_TOL, equal_nan=True, err_msg=str(window))
+                else:
+                    assert np.array_equal(got, orc.light), window
+                rp = abi.RaymarchParams(48.0, -1, True)
+                frame = res.raymarch_lit(cam, abi.Tile(0, 0, 32, 24, 1), rp, world)
+                want, _ = orc.raymarch_lit(cam, abi.Tile(0, 0, 32, 24, 1), rp, world)
+                np.testing.assert_allclose(frame, want, rtol=0, atol=TIGHT_TOL, equal_nan=True, err_msg=str(window))
