@@ -57,6 +57,7 @@ struct tbrm_resources {
     tbrm_resources_desc desc{};
     int32_t lv_dims[3]{};
     int lv_fmt = FMT_U8;
+    int n_cus = 256;               // compute units of the device (chunk length heuristics)
     hipStream_t stream = nullptr;
 
     void* d_data = nullptr;        // bricked data volume; slab-resident handles: rebased so that global brick offsets apply
@@ -311,8 +312,14 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
     p.j0 = pa.start;
     const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
     fit = ChunkFit{};
+    // With more tiles than CUs every CU works through several tiles per launch: the per-chunk overhead is paid once per
+    // round of tiles while the halo work of a long chunk (windows 1.56x the tile on average at 16 slices, 1.27x at 8) is
+    // paid by every tile, and 8-slice chunks win — measured for a fused Change: 640^3 5.2 -> 4.9 ms, 1024^3 16.7 -> 15.6,
+    // 1536^3 55.3 -> 49.7; at 512^3 (one tile per CU) 16 and 8 tie and 16 halves the launches.
+    const bool many_tiles = ceil_div(W, kChunkTile) * ceil_div(H, kChunkTile) > r->n_cus;
     for (int cand : {16, 8, 4, 2}) { // 2: steep secondary passes (taps up to 16 texels from the pixel), still 5x the slice kernel
         if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
+        if (cand == 16 && many_tiles && chunk_steps_override() == 0) continue;
         p.n_steps = std::min(cand, D_pass);
         if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, pr != nullptr, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
     }
@@ -999,6 +1006,7 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
 
     CREATE_TRY(hipSetDevice(desc->device));
     CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    if (hipDeviceGetAttribute(&r->n_cus, hipDeviceAttributeMultiprocessorCount, desc->device) != hipSuccess || r->n_cus <= 0) r->n_cus = 256;
     {
         tbrm_resources::Residency& q = r->res_data;
         CREATE_TRY(hipMalloc(&q.alloc, (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0)) * q.layer_bytes));
