@@ -333,12 +333,15 @@ template <int DFMT, int LFMT>
 static hipError_t launch_ray2(const RayParams& p, hipStream_t s)
 {
     // Lanes per ray, measured on MI355X (ms per frame; 2 lanes: 0.85 / 0.64 / 0.27, 16 lanes: 0.80 / 1.50 / 0.15):
-    //                     config 3 (1024^2 rays)   config 5 (2048^2)   config 2 (512^2)
-    //   4 lanes per ray          0.57                    0.68                0.18
-    //   8 lanes per ray          0.61                    0.95                0.14
-    // More lanes per ray shorten the serial chain, fewer keep more rays (and their setup) per wave: small frames want 8.
+    //                     config 3 (1024^2 rays,   config 5 (2048^2,   config 2 (512^2,   config 4 (1024^2,
+    //                               512 steps)              512 steps)         256 steps)        1024 steps)
+    //   4 lanes per ray          0.57                    0.68                0.18               1.28
+    //   8 lanes per ray          0.61                    0.95                0.14               1.17
+    // More lanes per ray shorten the serial chain, fewer keep more rays (and their setup) per wave: few rays or long rays
+    // want 8. The rule: rays x (512 / steps) <= 700 k.
     const char* e = getenv("TBRM_RAY_LANES");
-    const int rl = e ? atoi(e) : ((long long) p.tile_w * p.tile_h <= 300000 ? 8 : 4);
+    const double load = (double) p.tile_w * (double) p.tile_h * 512.0 / (double) (p.steps > 1.0f ? p.steps : 1.0f);
+    const int rl = e ? atoi(e) : (load <= 700000.0 ? 8 : 4);
     return rl == 8 ? launch_ray3<DFMT, LFMT, 8>(p, s) : launch_ray3<DFMT, LFMT, 4>(p, s);
 }
 template <int DFMT>
