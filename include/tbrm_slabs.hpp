@@ -30,12 +30,30 @@ public:
     {
         if (Handles.empty() || Bounds.size() != Handles.size() + 1 || Devices.size() != Handles.size())
             throw std::invalid_argument("FSlabGroup: one device and one [begin, end) per handle");
-        for (tbrm_resources* H : Handles) {
+        for (size_t k = 0; k < Handles.size(); ++k) {
             void* S = nullptr;
-            Check(tbrm_stream(H, &S), "tbrm_stream");
+            Check(tbrm_stream(Handles[k], &S), "tbrm_stream");
             Streams.push_back((hipStream_t) S);
+            Hip(hipSetDevice(Devices[k]), "hipSetDevice");
+            hipEvent_t A = nullptr, B = nullptr;
+            Hip(hipEventCreateWithFlags(&A, hipEventDisableTiming), "hipEventCreateWithFlags");
+            Hip(hipEventCreateWithFlags(&B, hipEventDisableTiming), "hipEventCreateWithFlags");
+            Done.push_back(A);
+            CopiesDone.push_back(B);
         }
     }
+    ~FSlabGroup()
+    {
+        for (hipEvent_t E : Done) (void) hipEventDestroy(E);
+        for (hipEvent_t E : CopiesDone) (void) hipEventDestroy(E);
+    }
+    FSlabGroup(const FSlabGroup&) = delete;
+    FSlabGroup& operator=(const FSlabGroup&) = delete;
+
+    // Ordering between the handles' streams: by default with events only (hipStreamWaitEvent) — the host never waits inside
+    // an operation, a handle's stream runs ahead as far as its neighbours' data allows. true: drain every stream around
+    // every exchange instead (the simple, slow form; kept for A/B checks).
+    bool bHostSynchronise = false;
 
     int Num() const { return (int) Handles.size(); }
     tbrm_slab Slab(int k) const { return tbrm_slab{Bounds[k], Bounds[k + 1]}; }
@@ -66,7 +84,9 @@ public:
     {
         const int N = Num();
         if (N == 1) return;
-        Drain();
+        if (bHostSynchronise) Drain();
+        else
+            for (int k = 0; k < N; ++k) Mark(k); // the light operations so far
         struct FSide { void* Send; void* Recv; size_t Bytes; };
         std::vector<FSide> Lower(N), Upper(N);
         for (int k = 0; k < N; ++k) {
@@ -74,11 +94,11 @@ public:
             Check(tbrm_slab_light_halo(Handles[k], 1, &Upper[k].Send, &Upper[k].Recv, &Upper[k].Bytes), "tbrm_slab_light_halo");
         }
         for (int k = 0; k < N; ++k) {
-            const int Up = (k + 1) % N;
+            const int Up = this->Up(k);
             Copy(Lower[Up].Recv, Up, Upper[k].Send, k, Upper[k].Bytes);  // slab k's last layer -> the lower halo of the slab above
             Copy(Upper[k].Recv, k, Lower[Up].Send, Up, Lower[Up].Bytes); // that slab's first layer -> the upper halo of slab k
         }
-        Drain();
+        if (bHostSynchronise) Drain();
     }
 
     // The lit frame, slab by slab (tbrm_raymarch_lit_slab_device): the per-pixel state sweeps up through the slabs for the
@@ -97,21 +117,23 @@ public:
         }
         Hip(hipSetDevice(Devices[0]), "hipSetDevice");
         Hip(hipMemsetAsync(State[0], 0, Bytes, Streams[0]), "hipMemsetAsync");
+        Mark(0);
         int Prev = 0;
         for (int Stage = 0; Stage < 2 * N; ++Stage) {
             const int k = Stage < N ? Stage : 2 * N - 1 - Stage;
             const int Direction = Stage < N ? +1 : -1;
             if (k != Prev) {
-                Hip(hipStreamSynchronize(Streams[Prev]), "hipStreamSynchronize");
+                if (bHostSynchronise) Hip(hipStreamSynchronize(Streams[Prev]), "hipStreamSynchronize");
                 Copy(State[k], k, State[Prev], Prev, Bytes);
             }
             const tbrm_slab S = Slab(k);
             Check(tbrm_raymarch_lit_slab_device(Handles[k], &Camera, &Tile, &Params, &World, nullptr, (float*) State[k], &S, Direction),
                   "tbrm_raymarch_lit_slab_device");
+            Mark(k);
             Prev = k;
         }
+        Drain(); // the last stage depends on every stage and copy before it; drained here before the state buffers go
         Hip(hipSetDevice(Devices[0]), "hipSetDevice");
-        Hip(hipStreamSynchronize(Streams[0]), "hipStreamSynchronize");
         Hip(hipMemcpy(HostOutRGBA, State[0], Bytes, hipMemcpyDeviceToHost), "hipMemcpy");
         for (int k = 0; k < N; ++k) {
             Hip(hipSetDevice(Devices[k]), "hipSetDevice");
@@ -124,6 +146,23 @@ private:
     std::vector<int32_t> Bounds;
     std::vector<int> Devices;
     std::vector<hipStream_t> Streams;
+    std::vector<hipEvent_t> Done;       // on stream k: its latest chunk / stage / copy-in has been enqueued up to here
+    std::vector<hipEvent_t> CopiesDone; // on stream k: the copies it performed (reading a neighbour's memory) up to here
+
+    int Up(int k) const { return (k + 1) % Num(); }
+    int Down(int k) const { return (k + Num() - 1) % Num(); }
+    void Mark(int k)
+    {
+        if (!bHostSynchronise) Hip(hipEventRecord(Done[k], Streams[k]), "hipEventRecord");
+    }
+    // Before handle k overwrites memory its neighbours copy from (planes, buffers, boundary light-volume layers): their
+    // copies so far must have been performed.
+    void WaitReaders(int k)
+    {
+        if (bHostSynchronise || Num() == 1) return;
+        Hip(hipStreamWaitEvent(Streams[k], CopiesDone[Down(k)], 0), "hipStreamWaitEvent");
+        Hip(hipStreamWaitEvent(Streams[k], CopiesDone[Up(k)], 0), "hipStreamWaitEvent");
+    }
 
     static void Check(int Code, const char* What)
     {
@@ -137,13 +176,15 @@ private:
     {
         for (tbrm_resources* H : Handles) Check(tbrm_flush(H), "tbrm_flush");
     }
-    // Dst on handle DstK <- Src on handle SrcK, enqueued on the destination's stream; the source must be complete (Drain /
-    // a stream synchronise precedes every call).
+    // Dst on handle DstK <- Src on handle SrcK, enqueued on the destination's stream once the source handle's work up to
+    // its last Mark() is done (host-synchronised mode: the caller has drained the streams).
     void Copy(void* Dst, int DstK, const void* Src, int SrcK, size_t Bytes)
     {
         if (!Dst || !Src || Bytes == 0) return;
         Hip(hipSetDevice(Devices[DstK]), "hipSetDevice");
+        if (!bHostSynchronise) Hip(hipStreamWaitEvent(Streams[DstK], Done[SrcK], 0), "hipStreamWaitEvent");
         Hip(hipMemcpyPeerAsync(Dst, Devices[DstK], Src, Devices[SrcK], Bytes, Streams[DstK]), "hipMemcpyPeerAsync");
+        if (!bHostSynchronise) Hip(hipEventRecord(CopiesDone[DstK], Streams[DstK]), "hipEventRecord");
         BytesMoved += Bytes;
     }
 
@@ -160,13 +201,20 @@ private:
         }
         for (int32_t Pass = 0; Pass < NumPasses; ++Pass) {
             std::vector<tbrm_slab_pass> Desc(N);
-            for (int k = 0; k < N; ++k) Check(tbrm_slab_pass_begin(Handles[k], Pass, &Desc[k]), "tbrm_slab_pass_begin");
+            for (int k = 0; k < N; ++k) {
+                WaitReaders(k); // the set-up of a pass may already write its buffers
+                Check(tbrm_slab_pass_begin(Handles[k], Pass, &Desc[k]), "tbrm_slab_pass_begin");
+            }
             const size_t RowBytes = (size_t) Desc[0].plane_w * (size_t) Desc[0].plane_elem_bytes;
             if (Desc[0].lateral) { // every slab runs every chunk on its rows; halo rows cross the slab boundaries after each
                 for (int32_t c = 0; c < Desc[0].n_chunks; ++c) {
-                    for (int k = 0; k < N; ++k) Check(tbrm_slab_pass_chunk(Handles[k], c), "tbrm_slab_pass_chunk");
+                    for (int k = 0; k < N; ++k) {
+                        WaitReaders(k); // chunk c overwrites the plane the neighbours fetched rows of two chunks ago
+                        Check(tbrm_slab_pass_chunk(Handles[k], c), "tbrm_slab_pass_chunk");
+                        Mark(k);
+                    }
                     if (c + 1 == Desc[0].n_chunks) break;
-                    Drain();
+                    if (bHostSynchronise) Drain();
                     const int32_t Halo = Desc[0].halo_rows;
                     for (int k = 0; k + 1 < N; ++k) {
                         const int32_t z = Bounds[k + 1];
@@ -176,18 +224,19 @@ private:
                             Copy(Lo + (size_t) z * RowBytes, k, Hi + (size_t) z * RowBytes, k + 1, (size_t) Halo * RowBytes);
                         }
                     }
-                    Drain();
+                    if (bHostSynchronise) Drain();
                 }
             } else { // a pipeline along z, in propagation order
                 for (int Pos = 0; Pos < N; ++Pos) {
                     const int k = Desc[0].dir > 0 ? Pos : N - 1 - Pos;
                     if (Pos > 0) {
                         const int Before = Desc[0].dir > 0 ? k - 1 : k + 1;
-                        Check(tbrm_flush(Handles[Before]), "tbrm_flush");
+                        if (bHostSynchronise) Check(tbrm_flush(Handles[Before]), "tbrm_flush");
                         for (int32_t s = 0; s < Desc[0].streams; ++s)
                             Copy(Plane(k, 0, s), k, Plane(Before, Desc[Before].n_chunks, s), Before, (size_t) Desc[0].plane_h * RowBytes);
                     }
                     for (int32_t c = 0; c < Desc[k].n_chunks; ++c) Check(tbrm_slab_pass_chunk(Handles[k], c), "tbrm_slab_pass_chunk");
+                    Mark(k);
                 }
             }
         }

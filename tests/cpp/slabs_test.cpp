@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,9 +38,11 @@ static std::vector<uint16_t> make_volume(int nx, int ny, int nz)
         }                                                                       \
     } while (0)
 
-int main()
+int main(int argc, char** argv)
 {
-    const int nx = 72, ny = 56, nz = 64, n_slabs = 2;
+    const int n_slabs = argc > 1 ? std::atoi(argv[1]) : 2;
+    const bool host_sync = argc > 2 && std::atoi(argv[2]) != 0;
+    const int nx = 72, ny = 56, nz = 32 * n_slabs;
     const std::vector<uint16_t> vol = make_volume(nx, ny, nz);
     tbrm_resources_desc desc{};
     desc.dim_x = nx; desc.dim_y = ny; desc.dim_z = nz;
@@ -84,6 +87,7 @@ int main()
     const tbrm_dir_light_params lights[4] = {{{1, .35, -.5}, 0.5f, 0}, {{-.4, 1, -.3}, 0.4f, 0}, {{.2, -.3, -1}, 0.4f, 0}, {{.1, .45, 1}, 0.3f, 0}};
     try {
         FSlabGroup group(parts, bounds, std::vector<int>(n_slabs, 0));
+        group.bHostSynchronise = host_sync;
         int flag = 0;
         std::vector<tbrm_dir_light_params> all(lights, lights + 4);
         group.ResetAllLights(all, world);
@@ -93,6 +97,13 @@ int main()
         TRY(tbrm_change_dir_light(whole, &lights[1], &moved, &world, &flag));
         group.ChangeDirLight(lights[2], turned, world);  // across faces: remove + add
         TRY(tbrm_change_dir_light(whole, &lights[2], &turned, &world, &flag));
+        for (int rep = 0; rep < 6; ++rep) { // back-to-back operations: the handles' streams run ahead of each other
+            const tbrm_dir_light_params a{{0.3 + 0.1 * rep, -0.8, 0.4 - 0.15 * rep}, 0.2f, 0}, b{{0.35 + 0.1 * rep, -0.8, 0.45 - 0.15 * rep}, 0.25f, 0};
+            group.AddDirLight(a, true, world);
+            TRY(tbrm_add_dir_light(whole, &a, 1, &world, &flag, 0));
+            group.ChangeDirLight(a, b, world);
+            TRY(tbrm_change_dir_light(whole, &a, &b, &world, &flag));
+        }
 
         std::vector<uint8_t> ref((size_t) nx * ny * nz), got((size_t) nx * ny * nz / n_slabs);
         TRY(tbrm_download_light_volume(whole, ref.data(), ref.size()));

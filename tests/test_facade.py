@@ -62,9 +62,11 @@ def test_slab_driver_compiles_and_links_with_gxx(tmp_path, abi_mod):
 
 
 @pytest.mark.gpu
-def test_slab_driver_on_gpu(tmp_path, gpu):
-    """two slab-resident handles driven from C++: light volume and frame bit-identical to one whole handle"""
-    p = subprocess.run([build_slabs(tmp_path)], capture_output=True, text=True)
+@pytest.mark.parametrize("n_slabs,host_sync", [(2, 0), (4, 0), (3, 0), (4, 1)])
+def test_slab_driver_on_gpu(tmp_path, gpu, n_slabs, host_sync):
+    """slab-resident handles driven from C++, their streams ordered by events only (host_sync 0) or drained around every
+    exchange (1): light volume and frame bit-identical to one whole handle"""
+    p = subprocess.run([build_slabs(tmp_path), str(n_slabs), str(host_sync)], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
     assert "light volume: 0 voxels differ" in p.stdout and "frame: identical" in p.stdout
 
