@@ -650,3 +650,62 @@ def test_non_finite_voxels_and_degenerate_windows(gpu, oracle_mod):
                 frame = res.raymarch_lit(cam, abi.Tile(0, 0, 32, 24, 1), rp, world)
                 want, _ = orc.raymarch_lit(cam, abi.Tile(0, 0, 32, 24, 1), rp, world)
                 np.testing.assert_allclose(frame, want, rtol=0, atol=TIGHT_TOL, equal_nan=True, err_msg=str(window))
+
+
+# ---- randomized sweep of the render modes --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_render_scenes_against_oracle(gpu, oracle_mod, seed):
+    """Seeded random scenes for the three render modes: ragged sizes, data / light formats, half-resolution light volume,
+    wrap / clamp, transfer functions, windows, rotated and non-uniformly scaled volumes with clip planes, cameras anywhere
+    (inside, far, grazing), fields of view, step counts from a fraction of a step to hundreds, jitter frames, odd tiles with
+    interleaved row groups, skipping on / off (identical), both lane layouts."""
+    rng = np.random.default_rng(0x5EED0B00 + seed)
+    dims = tuple(int(v) for v in rng.integers(9, 70, size=3))
+    dtype = [np.uint8, np.uint16, np.float32][seed % 3]
+    addr = abi.ADDRESS_CLAMP if seed % 4 == 1 else abi.ADDRESS_WRAP
+    res, orc = make_pair(gpu, oracle_mod, dims, dtype, light_32bit=bool(seed % 5 == 3), half_res=bool(seed % 3 == 2), addr=addr, tf="AB"[seed % 2],
+                         window=(float(rng.uniform(0.3, 0.7)), float(rng.uniform(0.3, 1.2)), bool(rng.integers(2)), bool(rng.integers(2))),
+                         seed=0x5EED0B10 + seed)
+    if seed % 2:
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        tr = abi.identity_transform(tuple(float(v) for v in rng.uniform(60, 140, size=3)), tuple(float(v) for v in rng.uniform(-20, 20, size=3)),
+                                    tuple(float(v) for v in q))
+        cd = rng.normal(size=3)
+        world = abi.make_world(tr, tuple(float(v) for v in rng.uniform(-30, 30, size=3)), tuple(float(v) for v in cd / np.linalg.norm(cd)))
+    else:
+        world = S.default_world()
+    with res:
+        for _ in range(2):
+            light = abi.DirLightParams(tuple(float(v) for v in rng.normal(size=3)), float(rng.uniform(0.2, 0.7)))
+            res.add_dir_light(light, True, world)
+            orc.add_dir_light(light, True, world)
+        orc.generate_octree()
+        res.generate_octree()
+        worst = 0.0
+        for case in range(5):
+            eye = rng.normal(size=3)
+            eye = eye / np.linalg.norm(eye) * float(rng.choice([5.0, 45.0, 52.0, 130.0, 400.0]))
+            target = tuple(float(v) for v in rng.uniform(-25, 25, size=3))
+            w, h = int(rng.integers(17, 57)), int(rng.integers(16, 49))
+            cam = abi.look_at_camera(eye, target, (0.0, 0.0, 1.0), float(rng.choice([15.0, 50.0, 100.0])), w, h)
+            step = int(rng.choice([1, 1, 2]))
+            th = int(rng.integers(1, max(2, (h - 8) // step)))
+            tile = abi.Tile(int(rng.integers(0, 6)), int(rng.integers(0, 6)), int(rng.integers(1, w - 6)), th, step)
+            steps = float(rng.choice([0.5, 3.0, 17.25, 64.0, 250.0]))
+            rp = abi.RaymarchParams(steps, int(rng.integers(-1, 8)), True)
+            os_lanes = ["4", "8"][case % 2]
+            import os
+            os.environ["TBRM_RAY_LANES"] = os_lanes
+            try:
+                got, (ref, n_ref) = res.raymarch_lit(cam, tile, rp, world), orc.raymarch_lit(cam, tile, rp, world)
+                assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
+                worst = max(worst, float(np.abs(got - ref).max()))
+                assert np.array_equal(got, res.raymarch_lit(cam, tile, abi.RaymarchParams(steps, rp.jitter_frame, False), world)), "skipping changed the image"
+            finally:
+                os.environ.pop("TBRM_RAY_LANES", None)
+            worst = max(worst, float(np.abs(res.raymarch_intensity(cam, tile, rp, world) - orc.raymarch_intensity(cam, tile, rp, world)).max()))
+            mip = int(rng.integers(0, 4))
+            worst = max(worst, float(np.abs(res.raymarch_octree(cam, tile, rp, world, mip) - orc.raymarch_octree(cam, tile, rp, world, mip)).max()))
+        assert worst <= TIGHT_TOL, worst
