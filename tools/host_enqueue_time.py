@@ -1,8 +1,9 @@
+"""Host time to enqueue one fused ChangeDirLight (about a hundred kernel launches) against its GPU time: python tools/host_enqueue_time.py [n]."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from tbraymarcherplugin_amd import abi, synthetic as S
-n = 512; cfg = S.CONFIGS[3]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512; cfg = S.CONFIGS[3]
 vol = S.make_volume_torch((n, n, n), cfg["dtype"], S.seed_for_config(3), torch.device("cuda", 0))
 res = abi.Resources((n, n, n), abi.FMT_G16)
 torch.cuda.synchronize(); res.upload_volume_device(vol.data_ptr(), vol.numel() * 2)
