@@ -58,6 +58,58 @@ def test_argument_validation_without_touching_a_device():
     assert b"null" in lib.tbrm_last_error()
 
 
+def test_every_handle_taking_entry_point_rejects_a_null_handle():
+    """no entry point dereferences a null handle: TBRM_ERR_INVALID_ARG (or, for the two queries that return a value, 0) and a message"""
+    lib = abi.load()
+    z = C.c_void_p(None)
+    buf = (C.c_float * 64)()
+    i3 = (C.c_int32 * 3)()
+    calls = {
+        "tbrm_resources_light_volume_dims": lambda: lib.tbrm_resources_light_volume_dims(z, C.byref(i3)),
+        "tbrm_upload_volume": lambda: lib.tbrm_upload_volume(z, buf, 4),
+        "tbrm_upload_volume_device": lambda: lib.tbrm_upload_volume_device(z, buf, 4),
+        "tbrm_upload_volume_slices": lambda: lib.tbrm_upload_volume_slices(z, 0, 8, buf, 4),
+        "tbrm_set_tf_lut": lambda: lib.tbrm_set_tf_lut(z, buf),
+        "tbrm_set_windowing": lambda: lib.tbrm_set_windowing(z, C.byref(abi.WindowingParams())),
+        "tbrm_add_dir_lights": lambda: lib.tbrm_add_dir_lights(z, None, 0, 1, C.byref(abi.make_world()), None, None),
+        "tbrm_change_dir_light": lambda: lib.tbrm_change_dir_light(z, None, None, None, None),
+        "tbrm_clear_light_volume": lambda: lib.tbrm_clear_light_volume(z, 0.0),
+        "tbrm_raymarch_lit": lambda: lib.tbrm_raymarch_lit(z, None, None, None, None, buf),
+        "tbrm_raymarch_lit_device": lambda: lib.tbrm_raymarch_lit_device(z, None, None, None, None, None, buf),
+        "tbrm_raymarch_lit_slab_device": lambda: lib.tbrm_raymarch_lit_slab_device(z, None, None, None, None, None, buf, None, 0),
+        "tbrm_raymarch_intensity": lambda: lib.tbrm_raymarch_intensity(z, None, None, None, None, buf),
+        "tbrm_raymarch_octree": lambda: lib.tbrm_raymarch_octree(z, None, None, None, None, 0, buf),
+        "tbrm_generate_octree": lambda: lib.tbrm_generate_octree(z),
+        "tbrm_octree_mip_dims": lambda: lib.tbrm_octree_mip_dims(z, 0, C.byref(i3)),
+        "tbrm_count_nominal_samples": lambda: lib.tbrm_count_nominal_samples(z, None, None, None, None, None),
+        "tbrm_download_light_volume": lambda: lib.tbrm_download_light_volume(z, buf, 4),
+        "tbrm_download_light_slices": lambda: lib.tbrm_download_light_slices(z, 0, 8, buf, 4),
+        "tbrm_upload_light_volume": lambda: lib.tbrm_upload_light_volume(z, buf, 4),
+        "tbrm_light_volume_device_ptr": lambda: lib.tbrm_light_volume_device_ptr(z, None, None),
+        "tbrm_slab_light_begin": lambda: lib.tbrm_slab_light_begin(z, None, None, 1, None, None, None),
+        "tbrm_slab_pass_begin": lambda: lib.tbrm_slab_pass_begin(z, 0, None),
+        "tbrm_slab_pass_chunk": lambda: lib.tbrm_slab_pass_chunk(z, 0),
+        "tbrm_slab_pass_plane": lambda: lib.tbrm_slab_pass_plane(z, 0, 0, None),
+        "tbrm_slab_resident_slices": lambda: lib.tbrm_slab_resident_slices(z, C.byref(i3), C.byref(i3)),
+        "tbrm_slab_light_halo": lambda: lib.tbrm_slab_light_halo(z, 0, None, None, None),
+        "tbrm_launch_counters": lambda: lib.tbrm_launch_counters(z, None),
+        "tbrm_stream": lambda: lib.tbrm_stream(z, None),
+        "tbrm_last_gpu_time_ms": lambda: lib.tbrm_last_gpu_time_ms(z, 0, None),
+    }
+    for name, call in calls.items():
+        assert call() == abi.ERR_INVALID_ARG, name
+        assert lib.tbrm_last_error(), name
+    assert lib.tbrm_resources_is_initialized(z) == 0
+    assert lib.tbrm_resources_create_slab(None, None, None) == abi.ERR_INVALID_ARG
+    # every symbol that takes the handle first is covered here or in the test above
+    covered = set(calls) | {"tbrm_resources_destroy", "tbrm_resources_is_initialized", "tbrm_add_dir_light", "tbrm_flush",
+                            "tbrm_raymarch_intensity_device", "tbrm_raymarch_octree_device", "tbrm_download_octree_mip"}
+    free = {"tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_color_curve_to_lut",
+            "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip",
+            "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local"}
+    assert set(abi.SYMBOLS) == covered | free, set(abi.SYMBOLS) ^ (covered | free)
+
+
 @pytest.mark.skipif(abi.device_count() > 0, reason="only meaningful on a machine without a HIP device")
 def test_no_cpu_fallback_without_a_device():
     """The product path fails loudly instead of computing on the host."""

@@ -219,3 +219,64 @@ def test_full_size_properties_at_config3(gpu, monkeypatch):
                 assert d.max() <= 1 and (d != 0).mean() < 1e-3
     monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
     assert np.array_equal(volumes[0], volumes[1]), f"{np.count_nonzero(volumes[0] != volumes[1])} voxels differ between the chunk and the slice kernels"
+
+
+def test_error_behaviour_through_the_c_abi(gpu):
+    """wrong sizes, calls in the wrong order and out-of-range arguments fail with a code and a message, and leave the handle usable"""
+    import ctypes as C
+
+    from conftest import small_volume
+    from tbraymarcherplugin_amd import synthetic as S
+
+    lib = abi.load()
+    for bad in [dict(dims=(0, 8, 8)), dict(dims=(8, 8, 8), data_format=7), dict(dims=(8, 8, 8), device=99)]:
+        with pytest.raises(abi.TbrmError) as e:
+            abi.Resources(bad["dims"], bad.get("data_format", abi.FMT_G8), device=bad.get("device", 0))
+        assert e.value.code == abi.ERR_INVALID_ARG, bad
+    dims = (24, 20, 16)
+    vol = small_volume(dims, np.uint8)
+    world = S.default_world()
+    cam = S.default_camera(16, 16)
+    tile = abi.Tile(0, 0, 16, 16, 1)
+    rp = abi.RaymarchParams(16.0, -1, True)
+    with abi.Resources(dims, abi.FMT_G8) as res:
+        # nothing uploaded yet: the reference's "resources not initialised" (RaymarchUtils.cpp:39-49)
+        assert not res.is_initialized()
+        flag = C.c_int(1)
+        light = abi.DirLightParams((1, 0, 0), 0.5)
+        assert lib.tbrm_add_dir_light(res.handle, C.byref(light), 1, C.byref(world), C.byref(flag), 0) == abi.ERR_NOT_INITIALIZED and flag.value == 0
+        with pytest.raises(abi.TbrmError) as e:
+            res.raymarch_lit(cam, tile, rp, world)
+        assert e.value.code == abi.ERR_NOT_INITIALIZED
+        # wrong byte counts
+        assert lib.tbrm_upload_volume(res.handle, vol.ctypes.data, vol.nbytes - 1) == abi.ERR_INVALID_ARG and b"bytes" in lib.tbrm_last_error()
+        res.upload_volume(vol)
+        res.set_tf_lut(abi.make_default_tf_lut())
+        assert res.is_initialized()
+        out = np.empty(vol.shape, dtype=np.uint8)
+        assert lib.tbrm_download_light_volume(res.handle, out.ctypes.data, out.nbytes + 3) == abi.ERR_INVALID_ARG
+        # arguments out of range
+        for bad_rp in (abi.RaymarchParams(0.0, -1, True), abi.RaymarchParams(-5.0, -1, True), abi.RaymarchParams(float("nan"), -1, True)):
+            with pytest.raises(abi.TbrmError) as e:
+                res.raymarch_lit(cam, tile, bad_rp, world)
+            assert e.value.code == abi.ERR_INVALID_ARG
+        out4 = np.empty((4, 4, 4), dtype=np.float32)
+        bad_tile = abi.Tile(0, 0, -4, 4, 1)
+        assert lib.tbrm_raymarch_lit(res.handle, C.byref(cam), C.byref(bad_tile), C.byref(rp), C.byref(world), out4.ctypes.data) == abi.ERR_INVALID_ARG
+        with pytest.raises(abi.TbrmError):
+            res.raymarch_octree(cam, tile, rp, world, 0)      # no pyramid yet
+        res.generate_octree()
+        with pytest.raises(abi.TbrmError):
+            res.raymarch_octree(cam, tile, rp, world, 4)      # levels are 0..3
+        with pytest.raises(abi.TbrmError):
+            res.octree_mip_dims(-1)
+        ms = C.c_float()
+        assert lib.tbrm_last_gpu_time_ms(res.handle, 5, C.byref(ms)) == abi.ERR_INVALID_ARG
+        # a zero light direction is the reference's silent no-op that still reports success (LightingShaders.cpp:41-46)
+        before = res.download_light_volume()
+        assert res.add_dir_light(abi.DirLightParams((0, 0, 0), 1.0), True, world)
+        assert np.array_equal(res.download_light_volume(), before)
+        # and the handle still works
+        assert res.add_dir_light(light, True, world)
+        frame = res.raymarch_lit(cam, tile, rp, world)
+        assert np.isfinite(frame).all() and frame[..., 3].max() > 0
