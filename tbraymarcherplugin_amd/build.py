@@ -9,8 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtbrm.so")
 
-SOURCES = ["tbrm_api.cpp", "tbrm_host_math.cpp", "tbrm_kernels.hip", "tbrm_light_kernels.hip"]
-HEADERS = ["tbrm_internal.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "../../include/tbrm.h"]
+SOURCES = ["tbrm_api.cpp", "tbrm_light_passes.cpp", "tbrm_host_math.cpp", "tbrm_kernels.hip", "tbrm_light_kernels.hip"]
+HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "../../include/tbrm.h"]
 
 # -ffp-contract=off + explicit fma is the arithmetic contract with the oracle (DESIGN.md "Arithmetic spec").
 FLAGS = [

@@ -1,0 +1,588 @@
+// tbrm_light_passes.cpp — host side of the illumination operators: what LightingShaders.cpp:35-326 does on the render
+// thread (per light the axis passes, per pass the slice loop), planned here as chunks for the gfx950 kernels of
+// tbrm_light_kernels.hip and enqueued on the handle's stream. tbrm_api.cpp's entry points call enqueue_add /
+// enqueue_add_batch / enqueue_change for the whole-volume operators and plan_pass / enqueue_plan_chunk step by step for the
+// slab-partitioned ones.
+#include "tbrm_resources.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace tbrm_host {
+
+int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr,
+                         float b_added, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
+
+// ---- chunked propagation (tbrm_light_kernels.hip) --------------------------------------------------------------
+
+bool force_slice_kernel()
+{
+    const char* e = getenv("TBRM_FORCE_SLICE_KERNEL"); // read per call so tests can A/B the two kernels
+    return e && e[0] == '1';
+}
+int chunk_steps_override()
+{
+    const char* e = getenv("TBRM_CHUNK_STEPS");
+    return e ? atoi(e) : 0;
+}
+
+TapRange prev_tap_range(int size, float off)
+{
+    TapRange t;
+    if (!std::isfinite(off) || size <= 0) return t;
+    t.lo = INT32_MAX; t.hi = INT32_MIN;
+    for (int c = 0; c < size; ++c) {
+        const float u = (((float) (uint32_t) c + 0.5f) / (float) size) + off;
+        float x = u * (float) size - 0.5f;
+        x = std::fmin(std::fmax(x, -0x1p30f), 0x1p30f);
+        const int d = (int) std::floor(x) - c;
+        t.lo = std::min(t.lo, d);
+        t.hi = std::max(t.hi, d + 1);
+    }
+    t.ok = std::abs(t.lo) <= 64 && std::abs(t.hi) <= 64;
+    return t;
+}
+
+
+float through_light_format(int lv_fmt, float v)
+{
+    if (lv_fmt != FMT_U8) return v;
+    float x = v;
+    if (x != x) return 0.0f;
+    x = x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x);
+    const uint32_t c = (uint32_t) (x * 255.0f + 0.5f);
+    return (float) c / 255.0f;
+}
+
+void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt)
+{
+    s.border_light = p.border_light;
+    s.off_u = p.prev_pixel_offset[0];
+    s.off_v = p.prev_pixel_offset[1];
+    for (int c = 0; c < 3; ++c) s.uvw_off[c] = p.uvw_offset[c];
+    s.step100 = p.step_size * 100.0f;
+    s.init_value = through_light_format(lv_fmt, p.light_alpha); // Clear2DTexture of the read/write buffers
+}
+
+
+// why plan_pass last declined a pass (diagnostics of the slab entry points, which have no fallback)
+thread_local const char* g_plan_note = "";
+int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; }
+
+// Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
+// 16/8/4/2 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
+bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit)
+{
+    g_plan_note = "";
+    if (force_slice_kernel()) return declined("TBRM_FORCE_SLICE_KERNEL is set"), false;
+    const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
+    TapRange tx = prev_tap_range(W, pa.prev_pixel_offset[0]), ty = prev_tap_range(H, pa.prev_pixel_offset[1]);
+    if (!tx.ok || !ty.ok) return declined("previous-slice offset out of range"), false;
+    if (pr) {
+        const TapRange rx = prev_tap_range(W, pr->prev_pixel_offset[0]), ry = prev_tap_range(H, pr->prev_pixel_offset[1]);
+        if (!rx.ok || !ry.ok) return declined("previous-slice offset out of range"), false;
+        tx.lo = std::min(tx.lo, rx.lo); tx.hi = std::max(tx.hi, rx.hi);
+        ty.lo = std::min(ty.lo, ry.lo); ty.hi = std::max(ty.hi, ry.hi);
+    }
+    // Unsheared windows: a tile keeps its 32x32 pixels for the whole chunk and its window grows towards the light by
+    // the tap range per remaining slice (the range is widened to contain 0 so the window always covers the tile).
+    tx.lo = std::min(tx.lo, 0); tx.hi = std::max(tx.hi, 0);
+    ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
+    ChunkParams p{};
+    p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
+    p.dir = pa.dir;
+    p.j0 = pa.start;
+    const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
+    fit = ChunkFit{};
+    // With more tiles than CUs every CU works through several tiles per launch: the per-chunk overhead is paid once per
+    // round of tiles while the halo work of a long chunk (windows 1.56x the tile on average at 16 slices, 1.27x at 8) is
+    // paid by every tile, and 8-slice chunks win — measured for a fused Change: 640^3 5.2 -> 4.9 ms, 1024^3 16.7 -> 15.6,
+    // 1536^3 55.3 -> 49.7; at 512^3 (one tile per CU) 16 and 8 tie and 16 halves the launches.
+    const bool many_tiles = ceil_div(W, kChunkTile) * ceil_div(H, kChunkTile) > r->n_cus;
+    for (int cand : {16, 8, 4, 2}) { // 2: steep secondary passes (taps up to 16 texels from the pixel), still 5x the slice kernel
+        if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
+        if (cand == 16 && many_tiles && chunk_steps_override() == 0) continue;
+        p.n_steps = std::min(cand, D_pass);
+        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, pr != nullptr, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
+    }
+    if (fit.M <= 0) return declined("the previous-slice taps reach too far for a 2-slice chunk"), false;
+    fit.tx = tx;
+    fit.ty = ty;
+    return true;
+}
+
+// Returns TBRM_ERR_UNSUPPORTED (nothing enqueued) when the pass has to take the slice-per-launch path.
+// slab: the light-volume z range this handle owns (null: everything).
+// Rows of the slice plane (z, when the pass runs along x or y) a slice's previous-slice taps can lie from the pixel:
+// what a slab has to fetch from its neighbours after every slice of a slice-per-launch pass. < 0: offsets out of range.
+int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr)
+{
+    int reach = 0;
+    for (const tbrm_light_pass* q : {&pa, pr}) {
+        if (!q) continue;
+        const TapRange t = prev_tap_range(q->td[1], q->prev_pixel_offset[1]);
+        if (!t.ok || !prev_tap_range(q->td[0], q->prev_pixel_offset[0]).ok) return -1;
+        reach = std::max({reach, -t.lo, t.hi});
+    }
+    return reach;
+}
+
+// A slab-partitioned pass with the reference's one-slice-per-launch structure (the chunk kernels declined it): "chunk" c is
+// slice c of what this handle runs, the planes are the pass's read / write buffers in the light volume's format.
+int plan_pass_sliced(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+                     const tbrm_slab& slab, PassPlan& plan)
+{
+    const int nz = r->lv_dims[2], D_pass = pa.td[2];
+    if (slab.z_begin < 0 || slab.z_end > nz || slab.z_begin >= slab.z_end || slab.z_begin % kChunkTile || slab.z_end % kChunkTile || nz % kChunkTile)
+        return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep: bounds and depth must be multiples of %d", slab.z_begin,
+                    slab.z_end, nz, kChunkTile);
+    const int reach = slice_tap_reach(pa, pr);
+    if (reach < 0) return declined("previous-slice offset out of range");
+    plan = PassPlan{};
+    plan.sliced = true;
+    plan.mode = pr ? PASS_CHANGE : PASS_ADD;
+    plan.M = 1;
+    plan.p.W = pa.td[0];
+    plan.p.H = pa.td[1];
+    plan.p.axis = pa.axis;
+    plan.dir = pa.dir;
+    plan.D = D_pass;
+    plan.start = pa.start;
+    plan.chunks_of_pass = D_pass;
+    PropParams& p = plan.slice_params;
+    p = base;
+    p.b_added = b_added;
+    p.axis = pa.axis;
+    for (int c = 0; c < 3; ++c) p.td[c] = pa.td[c];
+    fill_stream(p.a, pa);
+    if (pr) fill_stream(p.r, *pr);
+    p.row_block0 = 0;
+    p.row_blocks = 0;
+    if (pa.axis == 2) {
+        plan.D = slab.z_end - slab.z_begin;
+        plan.start = pa.dir > 0 ? slab.z_begin : slab.z_end - 1;
+        plan.first_chunk_of_pass = pa.dir > 0 ? slab.z_begin : nz - slab.z_end;
+        plan.pass_begins_here = plan.first_chunk_of_pass == 0;
+    } else {
+        if (reach > slab.z_end - slab.z_begin) return declined("a slice's taps reach beyond the neighbouring slab");
+        plan.lateral = true;
+        plan.halo_rows = reach;
+        p.row_block0 = slab.z_begin / 16;
+        p.row_blocks = (slab.z_end - slab.z_begin) / 16;
+    }
+    plan.n_chunks = plan.D;
+    if (r->resident) {
+        if (slab.z_begin != r->owned.z_begin || slab.z_end != r->owned.z_end)
+            return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle runs its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
+    }
+    if (plan.pass_begins_here) { // the buffers start from the light's initial value (LightingShaders.cpp:74-79)
+        const size_t npx = (size_t) pa.td[0] * pa.td[1];
+        const int ax = pa.axis;
+        if (!pr) {
+            HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pa.light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        } else {
+            HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pr->light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pr->light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][2], r->lv_fmt, npx, pa.light_alpha, r->stream));
+            HIP_TRY(launch_fill(r->d_buf[ax][3], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        }
+    }
+    return TBRM_OK;
+}
+
+// the read buffer of stream si (0: a, 1: r) before this handle's slice number `boundary` (== n_chunks: what its last slice wrote)
+void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si)
+{
+    const int j = plan.start + boundary * plan.dir;
+    const int e = (j % 2 == 0) ? 0 : 1; // LightingShaders.cpp:149-156
+    const int ax = plan.p.axis;
+    if (plan.mode == PASS_ADD) return r->d_buf[ax][e];
+    return si == 0 ? r->d_buf[ax][2 + e] : r->d_buf[ax][e];
+}
+
+// pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
+// pr, both added with b_added / b_added2).
+int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+              const tbrm_slab* slab, PassPlan& plan, int two_stream_mode, float b_added2)
+{
+    g_plan_note = "";
+    ChunkFit fit;
+    if (!chunk_fit(r, pa, pr, fit)) {
+        if (!slab || two_stream_mode == PASS_ADD2) return TBRM_ERR_UNSUPPORTED;
+        return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
+    }
+    const bool change = pr != nullptr;
+    const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
+    plan = PassPlan{};
+    plan.mode = change ? two_stream_mode : PASS_ADD;
+    ChunkParams& p = plan.p;
+    p.data = base.data;
+    p.data_border = base.data_border;
+    p.tf = base.tf;
+    p.win = base.win;
+    p.light = base.light;
+    for (int c = 0; c < 3; ++c) { p.lv_dims[c] = base.lv_dims[c]; p.cc[c] = base.cc[c]; p.cd[c] = base.cd[c]; }
+    p.lv_bnx = base.lv_bnx; p.lv_bnxy = base.lv_bnxy;
+    p.clip_mode = base.clip_mode;
+    p.axis = pa.axis;
+    p.W = W; p.H = H;
+    p.dir = pa.dir;
+    p.dx_lo = fit.tx.lo; p.dx_hi = fit.tx.hi; p.dy_lo = fit.ty.lo; p.dy_hi = fit.ty.hi;
+    p.b_added = b_added;
+    p.b_added2 = b_added2;
+    fill_chunk_stream(p.a, pa, r->lv_fmt);
+    if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
+    const int M = fit.M;
+    plan.M = M;
+
+    // what this handle runs: the whole pass, or (slab-partitioned) its rows of every slice / its slices of a pass along z
+    plan.D = D_pass;
+    plan.start = pa.start;
+    plan.dir = pa.dir;
+    p.tiles_x = ceil_div(W, kChunkTile);
+    p.tiles_y = ceil_div(H, kChunkTile);
+    p.tile_row0 = 0;
+    p.occ_blocks_x = ceil_div(W, 16);
+    p.occ_blocks_y = ceil_div(H, 16);
+    p.roi_by0 = 0;
+    p.roi_by1 = p.occ_blocks_y;
+    plan.chunks_of_pass = ceil_div(D_pass, M);
+    if (slab) {
+        const int nz = r->lv_dims[2];
+        if (slab->z_begin < 0 || slab->z_end > nz || slab->z_begin >= slab->z_end || slab->z_begin % kChunkTile || slab->z_end % kChunkTile ||
+            nz % kChunkTile)
+            return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep: bounds and depth must be multiples of %d",
+                        slab->z_begin, slab->z_end, nz, kChunkTile);
+        if (pa.axis == 2) { // the pass runs along the slab axis: this handle advances its own slices, planes are handed on
+            plan.D = slab->z_end - slab->z_begin;
+            plan.start = pa.dir > 0 ? slab->z_begin : slab->z_end - 1;
+            plan.first_chunk_of_pass = (pa.dir > 0 ? slab->z_begin : nz - slab->z_end) / M;
+            plan.pass_begins_here = plan.first_chunk_of_pass == 0;
+        } else { // z is the plane's row axis: the slab's tile rows, and the occlusion of every row their windows can reach
+            plan.lateral = true;
+            p.tile_row0 = slab->z_begin / kChunkTile;
+            p.tiles_y = (slab->z_end - slab->z_begin) / kChunkTile;
+            p.roi_by0 = std::max(slab->z_begin - kChunkTile, 0) / 16;
+            p.roi_by1 = std::min(ceil_div(slab->z_end + kChunkTile, 16), p.occ_blocks_y);
+        }
+    }
+    if (r->resident) {
+        if (!slab || slab->z_begin != r->owned.z_begin || slab->z_end != r->owned.z_end)
+            return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle runs its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
+        // every data texel the occlusion of this handle's rows / slices can sample has to be resident: z range of the taps of
+        // light-volume slices [za, zb), with the kernel's own arithmetic (GetUVW + UVWOffset, texel split)
+        const int za = plan.lateral ? std::max(slab->z_begin - kChunkTile, 0) : slab->z_begin;
+        const int zb = plan.lateral ? std::min(slab->z_end + kChunkTile, r->lv_dims[2]) : slab->z_end;
+        int lo = INT32_MAX, hi = INT32_MIN;
+        for (const tbrm_light_pass* q : {&pa, pr}) {
+            if (!q) continue;
+            for (int z : {za, zb - 1}) {
+                const float w = (((float) (uint32_t) z + 0.5f) / (float) (uint32_t) r->lv_dims[2]) + q->uvw_offset[2];
+                float x = w * (float) r->desc.dim_z - 0.5f;
+                x = std::fmin(std::fmax(x, -0x1p30f), 0x1p30f);
+                const int i0 = (int) std::floor(x);
+                lo = std::min(lo, i0);
+                hi = std::max(hi, i0 + 1);
+            }
+        }
+        lo = clamp_int(lo, 0, r->desc.dim_z - 1);
+        hi = clamp_int(hi, 0, r->desc.dim_z - 1);
+        if ((lo >> 3) < r->res_data.lo || (hi >> 3) >= r->res_data.hi)
+            return fail(TBRM_ERR_UNSUPPORTED, "this pass samples data slices %d..%d, the handle holds %d..%d", lo, hi, r->res_data.lo * 8,
+                        r->res_data.hi * 8 - 1);
+    }
+    const int D = plan.D;
+    plan.n_chunks = ceil_div(D, M);
+
+    // The occlusion launches are decoupled from the chain's chunk length: one launch covers a "span" of S slices (several
+    // chunks), so that it has enough workgroups to fill 256 CUs even when the chain has to run short chunks (a strongly
+    // slanted pass runs M = 8) and the live-workgroup list of a span deals an even share to every CU.
+    int S = 128; // measured on MI355X, fused Change at 512^3: S = 32 2.80 ms, 64 2.61, 128 2.53, 256 2.52
+    if (const char* e = getenv("TBRM_OCC_SLICES")) S = atoi(e);
+    S = std::max(M, (S / M) * M);
+
+    // occlusion scratch, allocated on first use: ONE allocation = [page of ones | guard][stream a: S planes][guard]
+    // [stream r: S planes][guard], so that the chain addresses every copy source as base + 32-bit offset
+    size_t occ_elems = (size_t) S * W * H;
+    while (S > M && (2 * occ_elems + 3 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) { S -= M; occ_elems = (size_t) S * W * H; }
+    const size_t occ_total = 2 * occ_elems + 3 * kPlaneGuard;
+    if (occ_total * sizeof(float) >= ((size_t) 1 << 32)) return declined("slice plane too large for the occlusion scratch");
+    if (occ_elems > r->occ_elems) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->d_occ);
+        r->d_occ = nullptr;
+        r->occ_elems = 0;
+        HIP_TRY(hipMalloc((void**) &r->d_occ, occ_total * sizeof(float)));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_occ, 0x3f800000, 1024, r->stream)); // the page of ones
+        r->occ_elems = occ_elems;
+    }
+    plan.S = S;
+    plan.n_spans = ceil_div(D, S);
+    plan.occ_off_a = kPlaneGuard;
+    plan.occ_off_r = kPlaneGuard + r->occ_elems + kPlaneGuard;
+
+    // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
+    // workgroup of the whole pass, computed up front, and per span the ascending list of the workgroups with work
+    plan.sparse = !getenv("TBRM_NO_SPARSE_OCC");
+    plan.work_list = plan.sparse && !getenv("TBRM_NO_OCC_LIST");
+    p.occ_groups = ceil_div(S, kOccSlices);
+    plan.flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
+    plan.flags_per_span = (size_t) p.occ_groups * plan.flags_per_group;
+    if (plan.sparse) {
+        if (plan.n_spans > 4096) return declined("too many occlusion spans");
+        if (int e = ensure_skipping(r)) return e;
+        const size_t zbytes = plan.flags_per_span * plan.n_spans;
+        if (zbytes > r->occ_zero_bytes) {
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            (void) hipFree(r->d_occ_zero[0]);
+            (void) hipFree(r->d_occ_list);
+            r->d_occ_zero[0] = nullptr;
+            r->d_occ_list = nullptr;
+            r->occ_zero_bytes = 0;
+            HIP_TRY(hipMalloc((void**) &r->d_occ_zero[0], zbytes));
+            HIP_TRY(hipMalloc((void**) &r->d_occ_list, zbytes * sizeof(uint32_t) + 4096 * sizeof(int))); // lists + counts
+            r->occ_zero_bytes = zbytes;
+        }
+        p.empty_bits = r->d_empty;
+        p.occ_flags_out = r->d_occ_zero[0];
+        p.occ_list_out = plan.work_list ? r->d_occ_list : nullptr;
+        p.occ_count_out = (int*) (r->d_occ_list + r->occ_zero_bytes);
+        p.pass_start = plan.start;
+        p.pass_slices = D;
+        p.chunk_slices = S;
+        HIP_TRY(launch_occ_flags(p, plan.mode, plan.n_spans, r->stream));
+    }
+    p.occ_base = r->d_occ;
+    p.a.occ_next = r->d_occ + plan.occ_off_a;
+    p.r.occ_next = r->d_occ + plan.occ_off_r;
+    return TBRM_OK;
+}
+
+// The plane holding the propagated light of stream `si` (0: a, 1: r) BEFORE chunk `boundary` (boundary = n_chunks: after
+// the last one): chunk c reads the planes of parity c & 1 and writes the others.
+float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_plane[2 * si + (boundary & 1)] + kPlaneGuard; }
+
+// Enqueues chunk c of the plan: the occlusion of its span first if the span starts here, then the chain.
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
+{
+    if (plan.sliced) {
+        PropParams sp = plan.slice_params;
+        const int j = plan.start + c * plan.dir;
+        const int e = (j % 2 == 0) ? 0 : 1, ax = plan.p.axis;
+        sp.loop = j;
+        if (plan.mode == PASS_ADD) {
+            sp.a.read = r->d_buf[ax][e];
+            sp.a.write = r->d_buf[ax][1 - e];
+        } else {
+            sp.r.read = r->d_buf[ax][e];
+            sp.r.write = r->d_buf[ax][1 - e];
+            sp.a.read = r->d_buf[ax][2 + e];
+            sp.a.write = r->d_buf[ax][3 - e];
+        }
+        HIP_TRY(launch_propagate_slice(sp, plan.mode != PASS_ADD, r->stream));
+        ++r->launches[1];
+        return TBRM_OK;
+    }
+    ChunkParams p = plan.p;
+    const int M = plan.M, S = plan.S, D = plan.D, W = p.W, H = p.H;
+    const int sp = (c * M) / S;
+    const int s0 = sp * S, sn = std::min(S, D - s0);
+    const int c0 = s0 / M, c1 = ceil_div(s0 + sn, M);
+    // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple of 4
+    // does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
+    auto chunk_sparse_ok = [&](int cc) { return (std::min(M, D - cc * M) * -p.dx_lo) % 4 == 0; };
+    bool span_sparse = plan.sparse;
+    for (int cc = c0; cc < c1; ++cc) span_sparse = span_sparse && chunk_sparse_ok(cc); // else the whole span runs dense
+    const bool work_list = plan.work_list;
+
+    if (c == c0) { // occlusion of the span: fills {a,r}.occ_next with sn planes
+        p.j0 = plan.start + s0 * plan.dir;
+        p.n_steps = sn;
+        p.occ_flags = nullptr;
+        p.occ_list = span_sparse && work_list ? r->d_occ_list + (size_t) sp * plan.flags_per_span : nullptr;
+        p.occ_count = span_sparse && work_list ? (const int*) (r->d_occ_list + r->occ_zero_bytes) + sp : nullptr;
+        if (span_sparse && !work_list) p.occ_flags = r->d_occ_zero[0] + (size_t) sp * plan.flags_per_span;
+        HIP_TRY(launch_light_occlusion(p, plan.mode, r->stream));
+    }
+    const int k0 = c * M - s0; // first slice of the chunk within the span
+    p.n_steps = std::min(M, D - c * M);
+    p.j0 = plan.start + c * M * plan.dir;
+    p.first_chunk = c == 0 && plan.pass_begins_here;
+    p.a.plane_in = plan_plane(r, c, 0); p.a.plane_out = plan_plane(r, c + 1, 0);
+    p.r.plane_in = plan_plane(r, c, 1); p.r.plane_out = plan_plane(r, c + 1, 1);
+    p.a.occ_off = (uint32_t) (plan.occ_off_a + (size_t) k0 * W * H);
+    p.r.occ_off = (uint32_t) (plan.occ_off_r + (size_t) k0 * W * H);
+    p.occ_phase = k0 % kOccSlices;
+    p.occ_list = nullptr;
+    p.occ_count = nullptr;
+    p.occ_flags = span_sparse ? r->d_occ_zero[0] + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
+    HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
+    ++r->launches[0];
+    return TBRM_OK;
+}
+
+int enqueue_pass_chunked(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr,
+                         float b_added, int two_stream_mode, float b_added2)
+{
+    PassPlan plan;
+    if (int e = plan_pass(r, base, pa, pr, b_added, nullptr, plan, two_stream_mode, b_added2)) return e;
+    for (int c = 0; c < plan.n_chunks; ++c)
+        if (int e = enqueue_plan_chunk(r, plan, c)) return e;
+    return TBRM_OK;
+}
+
+// the reference's structure: one launch per slice (LightingShaders.cpp:132-158 / :289-318)
+int enqueue_pass_sliced(tbrm_resources* r, PropParams p, const tbrm_light_pass& pa, const tbrm_light_pass* pr)
+{
+    const bool change = pr != nullptr;
+    const size_t npx = (size_t) pa.td[0] * pa.td[1];
+    const int ax = pa.axis;
+    if (!change) {
+        HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pa.light_alpha, r->stream));
+    } else {
+        HIP_TRY(launch_fill(r->d_buf[ax][0], r->lv_fmt, npx, pr->light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][1], r->lv_fmt, npx, pr->light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][2], r->lv_fmt, npx, pa.light_alpha, r->stream));
+        HIP_TRY(launch_fill(r->d_buf[ax][3], r->lv_fmt, npx, pa.light_alpha, r->stream));
+    }
+    p.axis = ax;
+    for (int c = 0; c < 3; ++c) p.td[c] = pa.td[c];
+    fill_stream(p.a, pa);
+    if (change) fill_stream(p.r, *pr);
+    for (int j = pa.start; j != pa.stop; j += pa.dir) {
+        p.loop = j;
+        const int e = (j % 2 == 0) ? 0 : 1; // switch read and write buffers each slice
+        if (!change) {
+            p.a.read = r->d_buf[ax][e];
+            p.a.write = r->d_buf[ax][1 - e];
+        } else {
+            p.r.read = r->d_buf[ax][e];
+            p.r.write = r->d_buf[ax][1 - e];
+            p.a.read = r->d_buf[ax][2 + e];
+            p.a.write = r->d_buf[ax][3 - e];
+        }
+        HIP_TRY(launch_propagate_slice(p, change, r->stream));
+        ++r->launches[1];
+    }
+    return TBRM_OK;
+}
+
+int enqueue_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added)
+{
+    const int e = enqueue_pass_chunked(r, base, pa, pr, b_added);
+    if (e != TBRM_ERR_UNSUPPORTED) return e;
+    PropParams p = base;
+    p.b_added = b_added;
+    return enqueue_pass_sliced(r, p, pa, pr);
+}
+
+// AddDirLightToSingleLightVolume_RenderThread (LightingShaders.cpp:35-166)
+int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world)
+{
+    tbrm_light_pass passes[2];
+    int n = 0;
+    if (!host_light_passes(light, world, r->lv_dims, r->desc.border_mode, passes, &n)) return TBRM_OK; // :41-46
+    const PropParams base = base_prop_params(r, world);
+    for (int i = 0; i < n; ++i) // breaks on weight == 0 (:65,:94)
+        if (int e = enqueue_pass(r, base, passes[i], nullptr, added ? 1.0f : -1.0f)) return e;
+    return TBRM_OK;
+}
+
+// Several AddDirLightToSingleLightVolume calls as one (the multi-light optimisation of the Sunden/Ropinski
+// scheme the reference left out, Readme.md:166,186-187). The axis passes of all lights are collected; two passes of
+// different lights that leave the same cube face (same axis, same direction) share one slice loop — the data volume's
+// bricks, the plane geometry and the per-chunk overhead are paid once for both (PASS_ADD2: light a's read-modify-write,
+// then light b's on its result, exactly as if pass a and then pass b had run over the volume). Passes are taken in
+// the lights' order; each pairs with the first later pass of the same face. The order of the per-voxel updates thus
+// differs from adding the lights one after the other; `schedule` (4 ints per entry: light and pass of a, light and
+// pass of b or -1 -1) reports it so that a checker can replay it.
+int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
+                      int32_t* schedule, int32_t* n_entries)
+{
+    struct Entry { int light, pass; tbrm_light_pass p; bool done; };
+    std::vector<Entry> all;
+    for (int i = 0; i < n_lights; ++i) {
+        tbrm_light_pass passes[2];
+        int n = 0;
+        if (!host_light_passes(lights[i], world, r->lv_dims, r->desc.border_mode, passes, &n)) continue; // zero direction
+        for (int k = 0; k < n; ++k) all.push_back(Entry{i, k, passes[k], false});
+    }
+    const PropParams base = base_prop_params(r, world);
+    const float b = added ? 1.0f : -1.0f;
+    const bool pairing = !getenv("TBRM_NO_LIGHT_BATCHING");
+    int entries = 0;
+    for (size_t ia = 0; ia < all.size(); ++ia) {
+        Entry& a = all[ia];
+        if (a.done) continue;
+        a.done = true;
+        // Partner: a later pass of the same face whose previous-slice taps fall inside this pass's tap range or the other
+        // way round. Two lights in one slice loop share the per-chunk overhead and the per-slice latency of the chain, but
+        // every window has to cover both lights' taps: measured on MI355X (512^3, all pairs of the 8 config lights), a pair
+        // only pays when the union of the two tap ranges is no wider than the wider of the two — then 0.3 to 0.5 ms per
+        // paired pass (lights 1 and 7: 3.61 -> 2.53 ms for both passes); with diverging directions the wider windows and
+        // shorter chunks cost up to 0.2 ms more than they save.
+        Entry* partner = nullptr;
+        ChunkFit fa;
+        if (pairing && chunk_fit(r, a.p, nullptr, fa)) {
+            int best_area = INT32_MAX;
+            for (size_t ib = ia + 1; ib < all.size(); ++ib) {
+                Entry& b2 = all[ib];
+                ChunkFit fb, fp;
+                if (b2.done || b2.light == a.light || b2.p.face != a.p.face) continue;
+                if (!chunk_fit(r, b2.p, nullptr, fb) || !chunk_fit(r, a.p, &b2.p, fp)) continue;
+                if (getenv("TBRM_LIGHT_BATCHING_FORCE")) { partner = &b2; break; } // diagnostics: pair whatever fits
+                const int sx = fp.tx.hi - fp.tx.lo, sy = fp.ty.hi - fp.ty.lo;
+                const bool contained = sx <= std::max(fa.tx.hi - fa.tx.lo, fb.tx.hi - fb.tx.lo) && sy <= std::max(fa.ty.hi - fa.ty.lo, fb.ty.hi - fb.ty.lo);
+                if (!contained || fp.M < std::min(fa.M, fb.M)) continue;
+                if (sx * sy < best_area) { best_area = sx * sy; partner = &b2; }
+            }
+        }
+        if (schedule) {
+            schedule[4 * entries + 0] = a.light; schedule[4 * entries + 1] = a.pass;
+            schedule[4 * entries + 2] = partner ? partner->light : -1; schedule[4 * entries + 3] = partner ? partner->pass : -1;
+        }
+        ++entries;
+        if (partner) {
+            partner->done = true;
+            const int e = enqueue_pass_chunked(r, base, a.p, &partner->p, b, PASS_ADD2, b);
+            if (e == TBRM_OK) continue;
+            if (e != TBRM_ERR_UNSUPPORTED) return e;
+            if (int e2 = enqueue_pass(r, base, a.p, nullptr, b)) return e2; // the pair does not fit one launch: a, then b
+            if (int e2 = enqueue_pass(r, base, partner->p, nullptr, b)) return e2;
+        } else if (int e = enqueue_pass(r, base, a.p, nullptr, b)) return e;
+    }
+    if (n_entries) *n_entries = entries;
+    return TBRM_OK;
+}
+
+// ChangeDirLightInSingleLightVolume_RenderThread (LightingShaders.cpp:168-326)
+int enqueue_change(tbrm_resources* r, const tbrm_dir_light_params& removed, const tbrm_dir_light_params& added_light,
+                   const tbrm_world_params& world)
+{
+    tbrm_light_pass rp[2], ap[2];
+    int rn = 0, an = 0;
+    const bool r_ok = host_light_passes(removed, world, r->lv_dims, r->desc.border_mode, rp, &rn);
+    const bool a_ok = host_light_passes(added_light, world, r->lv_dims, r->desc.border_mode, ap, &an);
+    if (!r_ok || !a_ok) return TBRM_OK; // :173-179
+    if (rp[0].face != ap[0].face || rp[1].face != ap[1].face) { // :192-198
+        const int e = enqueue_add(r, removed, false, world);
+        if (e != TBRM_OK) return e;
+        return enqueue_add(r, added_light, true, world);
+    }
+    const PropParams base = base_prop_params(r, world);
+    for (int i = 0; i < 2; ++i) { // no break on weight 0 (:238)
+        // Both streams dark (weight 0 on this axis for old and new light): buffers and borders are 0, every
+        // propagated value is 0*(1-s) = 0 and |0-0| > 1e-3 never holds: the pass cannot touch the light volume.
+        if (rp[i].light_alpha == 0.0f && ap[i].light_alpha == 0.0f && rp[i].border_light == 0.0f && ap[i].border_light == 0.0f)
+            continue;
+        if (int e = enqueue_pass(r, base, ap[i], &rp[i], 0.0f)) return e;
+    }
+    return TBRM_OK;
+}
+
+} // namespace tbrm_host

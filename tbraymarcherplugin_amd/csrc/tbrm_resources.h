@@ -1,0 +1,173 @@
+// tbrm_resources.h — what the host side of the library shares between its translation units: the handle behind the
+// C-ABI's opaque tbrm_resources, error reporting, and the light-pass layer (planning and enqueueing the axis passes of the
+// Add / Change operators, tbrm_light_passes.cpp) that tbrm_api.cpp's entry points drive. Internal; not installed.
+#pragma once
+
+#include "../../include/tbrm.h"
+#include "tbrm_host_math.h"
+#include "tbrm_internal.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace tbrm_host {
+
+int fail(int code, const char* fmt, ...); // sets tbrm_last_error() of the calling thread, returns code
+inline size_t format_bytes(int fmt) { return fmt == TBRM_FMT_G8 ? 1 : (fmt == TBRM_FMT_G16 ? 2 : 4); }
+
+} // namespace tbrm_host
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        const hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                                 \
+            return tbrm_host::fail(e_ == hipErrorOutOfMemory ? TBRM_ERR_OUT_OF_MEMORY : TBRM_ERR_NO_DEVICE, "%s failed: %s", \
+                #expr, hipGetErrorString(e_));                                                                \
+    } while (0)
+
+struct tbrm_resources {
+    tbrm_resources_desc desc{};
+    int32_t lv_dims[3]{};
+    int lv_fmt = tbrm::FMT_U8;
+    int n_cus = 256;               // compute units of the device (chunk length heuristics)
+    hipStream_t stream = nullptr;
+
+    void* d_data = nullptr;        // bricked data volume; slab-resident handles: rebased so that global brick offsets apply
+    size_t data_bytes = 0;
+    bool has_volume = false;
+
+    // Slab-resident handles (tbrm_resources_create_slab) hold only some z brick layers of the two volumes: layers
+    // [lo, hi) contiguously, then one more layer holding a copy of layer `wrap_src` (what wrap addressing reaches from the
+    // first / last slice; -1: none). d_data / d_light point lo * layer_bytes BEFORE the allocation, so a kernel that only
+    // touches resident layers addresses them with the global brick offsets, unchanged.
+    struct Residency { int lo = 0, hi = 0, wrap_src = -1; size_t layer_bytes = 0; void* alloc = nullptr; };
+    bool resident = false;
+    tbrm_slab owned{};
+    Residency res_data, res_light;
+
+    float4* d_tf = nullptr;
+    float tf_host[1024]{};
+    bool has_tf = false;
+
+    tbrm_windowing_params win{0.5f, 1.0f, 1, 1};
+
+    void* d_light = nullptr;
+    size_t light_bytes = 0;        // linear size (what download/upload exchange)
+    size_t light_bricked_bytes = 0;
+    size_t data_bricked_bytes = 0;
+    int dbn[3]{};                  // data volume bricks per axis
+    int lbn[3]{};                  // light volume bricks per axis
+    void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
+    float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
+    float* d_occ = nullptr;        // chunk kernel: page of ones + the occlusion plane stacks of a span (allocated on first use)
+    size_t occ_elems = 0;
+    uint8_t* d_occ_zero[2]{};      // empty-block flags of the two occlusion buffers
+    uint32_t* d_occ_list = nullptr; // work lists of the pass (one uint32 per flag) followed by 4096 per-chunk counts
+    size_t occ_zero_bytes = 0;
+
+    // empty-space-skipping metadata
+    int bn[3]{};
+    float2* d_minmax = nullptr;
+    uint32_t* d_empty = nullptr;
+    uint8_t* d_dist[2]{};          // empty-space leaping: per-brick distance field (ping-pong of the separable passes; [0] is final)
+    int* d_alpha_prefix = nullptr;
+    bool minmax_valid = false, empty_valid = false;
+
+    // Octree render mode: 4-level UNORM16 max pyramid (allocated by the first tbrm_generate_octree)
+    uint16_t* d_octree[4]{};
+    int oct_dims[4][3]{};
+    bool octree_valid = false;
+
+    unsigned long long* d_counter = nullptr;
+    float* d_out = nullptr; // staging for the host-pointer raymarch variant
+    size_t out_bytes = 0;
+
+    struct SlabOp* slab_op = nullptr; // the slab-partitioned light operation in flight (tbrm_slab_*)
+
+    hipEvent_t ev[2][2]{};
+    bool ev_valid[2]{};
+    uint64_t launches[3]{}; // chunk, slice, raymarch
+};
+
+
+namespace tbrm_host {
+
+using namespace tbrm;
+
+inline int floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+inline int ceil_div(int a, int b) { return -floor_div(-a, b); }
+inline int clamp_int(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- handle helpers (tbrm_api.cpp) ------------------------------------------------------------------------------------
+int bind(const tbrm_resources* r);
+bool initialized(const tbrm_resources* r);
+VolumeDev data_view(const tbrm_resources* r);
+WindowDev window_dev(const tbrm_resources* r);
+PropParams base_prop_params(const tbrm_resources* r, const tbrm_world_params& world);
+void fill_stream(PropStream& s, const tbrm_light_pass& p);
+int begin_timed(tbrm_resources* r, int kind);
+int end_timed(tbrm_resources* r, int kind);
+int ensure_skipping(tbrm_resources* r);
+
+// ---- the light-pass layer (tbrm_light_passes.cpp) ------------------------------------------------------------------------
+// Range of (tap index - pixel index) of the previous-slice bilinear fetch over one buffer axis, evaluated with the
+// kernel's own fp32 sequence (texel_split of ((c+0.5)/size + offset)); hi includes the +1 tap.
+struct TapRange { int lo = 0, hi = 0; bool ok = false; };
+
+struct ChunkFit { int M = 0; TapRange tx, ty; };
+
+// One axis pass (Add: stream a only; Change: a = added, r = removed) as a plan: everything that is constant over the
+// pass, worked out once, and the chunks then enqueued one by one (plan_pass / enqueue_plan_chunk). A single-GPU pass
+// enqueues all of them back to back; a slab-partitioned pass (tbrm_slab_*) stops after each chunk so that the host can
+// exchange the propagated planes between ranks.
+struct PassPlan {
+    ChunkParams p{};
+    int mode = PASS_ADD;        // PASS_ADD / PASS_CHANGE / PASS_ADD2
+    bool two_streams() const { return mode != PASS_ADD; }
+    int M = 0, S = 0;           // slices per chain chunk / per occlusion span
+    int D = 0;                  // slices this handle runs (the whole pass, or its slab's part of a pass along z)
+    int start = 0, dir = 1;     // first of them
+    int n_chunks = 0, n_spans = 0;
+    bool pass_begins_here = true; // chunk 0 starts from the cleared buffers' value (else from imported planes)
+    bool sparse = false, work_list = false;
+    size_t flags_per_group = 0, flags_per_span = 0, occ_off_a = 0, occ_off_r = 0;
+    // slab-partitioned passes
+    bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
+    int first_chunk_of_pass = 0, chunks_of_pass = 0;
+    // a slab-partitioned pass whose taps reach too far for the chunk kernels: one slice per "chunk" with the reference's
+    // kernel structure (k_propagate_slice) on the read / write buffers, which then are the planes the host exchanges
+    bool sliced = false;
+    PropParams slice_params{};
+    int halo_rows = 0;          // lateral: rows a slice's taps can reach beyond a slab
+};
+
+extern thread_local const char* g_plan_note; // why chunk_fit / plan_pass last declined a pass
+bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit);
+int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr);
+int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+              const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
+float* plan_plane(const tbrm_resources* r, int boundary, int si);
+void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c);
+int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
+int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
+                      int32_t* schedule, int32_t* n_entries);
+int enqueue_change(tbrm_resources* r, const tbrm_dir_light_params& removed, const tbrm_dir_light_params& added_light,
+                   const tbrm_world_params& world);
+
+} // namespace tbrm_host
+
+// A light operation taken apart for slab-partitioned execution: its axis passes, and the plan of the one being stepped.
+struct SlabOp {
+    tbrm_slab slab{};
+    bool change = false;
+    float b_added = 0.0f;
+    int n = 0;
+    tbrm_light_pass a[2]{}, r[2]{};
+    tbrm::PropParams base{};
+    int current = -1; // pass being stepped
+    tbrm_host::PassPlan plan;
+};
+
