@@ -1,10 +1,9 @@
 // tbrm_api.cpp — the C-ABI of include/tbrm.h over the gfx950 kernels.
 //
-// Plays the role of the reference's game-thread operator library + render-thread drivers:
+// Plays the role of the reference's game-thread operator library:
 //   URaymarchUtils::AddDirLightToSingleVolume / ChangeDirLightInSingleVolume / ClearResourceLightVolumes
 //       Source/Raymarcher/Private/Util/RaymarchUtils.cpp:35-111
-//   AddDirLightToSingleLightVolume_RenderThread / ChangeDirLightInSingleLightVolume_RenderThread
-//       Source/Raymarcher/Private/Rendering/LightingShaders.cpp:35-326
+//   (their render-thread drivers, LightingShaders.cpp:35-326, are tbrm_light_passes.cpp)
 //   ARaymarchVolume::InitializeRaymarchResources / FreeRaymarchResources
 //       Source/Raymarcher/Private/Actor/RaymarchVolume.cpp:821-949
 // Every call enqueues on the handle's HIP stream (FIFO, like ENQUEUE_RENDER_COMMAND) and returns; parameter
