@@ -361,7 +361,8 @@ def test_random_slab_resident_scenes_against_one_handle(gpu, seed):
     rng = np.random.default_rng(0x5EED0800 + seed)
     depth = int(rng.choice([64, 96, 128]))
     n_slabs = int(rng.choice([s for s in (2, 3, 4) if depth % (32 * s) == 0]))
-    dims = (int(rng.integers(40, 150)), int(rng.integers(40, 150)), depth)
+    half_res = seed % 5 == 4  # the light volume at half the data volume's resolution: `depth` is the LIGHT volume's
+    dims = (int(rng.integers(40, 150)), int(rng.integers(40, 150)), 2 * depth if half_res else depth)
     dtype = [np.uint8, np.uint16, np.float32][seed % 3]
     light_32bit = seed % 4 == 3
     addr = abi.ADDRESS_CLAMP if seed % 2 else abi.ADDRESS_WRAP
@@ -369,10 +370,11 @@ def test_random_slab_resident_scenes_against_one_handle(gpu, seed):
     lut = abi.color_curve_to_lut(S.tf_keys("AB"[seed % 2]))
     w = abi.WindowingParams(float(rng.uniform(0.35, 0.65)), float(rng.uniform(0.5, 1.1)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
     fmt = abi.DTYPE_FMT[np.dtype(dtype)]
-    full = abi.Resources(dims, fmt, light_32bit, False, 0, addr)
+    full = abi.Resources(dims, fmt, light_32bit, half_res, 0, addr)
     full.upload_volume(vol)
+    assert full.light_dims[2] == depth
     bounds = slabs.slab_bounds(depth, n_slabs)
-    parts = [abi.Resources(dims, fmt, light_32bit, False, 0, addr, owned=abi.Slab(*bounds[k])) for k in range(n_slabs)]
+    parts = [abi.Resources(dims, fmt, light_32bit, half_res, 0, addr, owned=abi.Slab(*bounds[k])) for k in range(n_slabs)]
     dev = torch.device("cuda", 0)
     if seed % 2:
         q = rng.normal(size=4)
