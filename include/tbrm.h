@@ -165,6 +165,15 @@ TBRM_API const char* tbrm_version(void);
 TBRM_API const char* tbrm_last_error(void);       /* thread-local message of the last failing call */
 TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the HIP runtime has none */
 
+/* Process-wide tunables: A/B switches for measurements and parity tests (no counterpart in the reference; nothing a
+ * host needs to call). Each starts from the environment variable TBRM_<NAME IN CAPITALS>, read once when the library is
+ * loaded; no operator reads the environment. Names (default): force_slice_kernel (0), chunk_steps (0 = by fit),
+ * tile_h (0 = by fit; 16 / 32), occ_slices (0 = 128), sparse_occ (1), occ_list (1), occ_prefetch (1),
+ * light_batching (1; 0 never, 2 always), share_grid (1), ray_lanes (0 = by load; 4 / 8). Unknown name:
+ * TBRM_ERR_INVALID_ARG. */
+TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
+TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* resources: ARaymarchVolume::InitializeRaymarchResources / FreeRaymarchResources                   */
 /* (RaymarchVolume.cpp:821-949). The handle owns every device allocation (data volume copy, TF LUT,   */
@@ -215,11 +224,12 @@ TBRM_API int tbrm_add_dir_light(tbrm_resources* res, const tbrm_dir_light_params
 TBRM_API int tbrm_add_dir_lights(tbrm_resources* res, const tbrm_dir_light_params* lights, int32_t n_lights, int added,
                                  const tbrm_world_params* world, int32_t* schedule, int32_t* n_entries);
 
-/* ChangeDirLightInSingleVolume(Resources, Old, New, WorldParameters, LightAdded). Falls back to
- * remove + add when the two major axes differ (LightingShaders.cpp:192-198). */
+/* ChangeDirLightInSingleVolume(Resources, Old, New, WorldParameters, LightAdded, bGPUSync) (RaymarchUtils.h:39-41).
+ * Falls back to remove + add when the two major axes differ (LightingShaders.cpp:192-198). gpu_sync is accepted and
+ * ignored, as in tbrm_add_dir_light (the reference's ChangeDirLight body never reads it, RaymarchUtils.cpp:70-92). */
 TBRM_API int tbrm_change_dir_light(tbrm_resources* res, const tbrm_dir_light_params* old_light,
                                    const tbrm_dir_light_params* new_light, const tbrm_world_params* world,
-                                   int* light_added);
+                                   int* light_added, int gpu_sync);
 
 /* ---- slabs: one light operation spread over the GPUs of a node (BASELINE config 4) --------------
  * The reference has no multi-GPU path; this is the same AddDirLight / ChangeDirLight arithmetic, partitioned. Every

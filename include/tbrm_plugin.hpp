@@ -132,11 +132,10 @@ struct URaymarchUtils { // RaymarchUtils.h:33-93; all static, like the Blueprint
                                              const FDirLightParameters NewLightParameters, const FRaymarchWorldParameters WorldParameters,
                                              bool& LightAdded, bool bGPUSync = false)
     {
-        (void) bGPUSync;
         const tbrm_dir_light_params o = OldLightParameters.abi(), n = NewLightParameters.abi();
         const tbrm_world_params w = WorldParameters.abi();
         int flag = 0;
-        tbrm_change_dir_light(Resources.Handle, &o, &n, &w, &flag);
+        tbrm_change_dir_light(Resources.Handle, &o, &n, &w, &flag, bGPUSync ? 1 : 0);
         LightAdded = flag != 0;
     }
     // RaymarchUtils.cpp:94-102
@@ -302,6 +301,10 @@ public:
             bRequestedRecompute = true;
             WorldParameters = GetWorldParameters();
         }
+        if (bRequestedOctreeRebuild && SelectRaymarchMaterial == ERaymarchMaterial::Octree) { // :358-363
+            URaymarchUtils::GenerateOctree(RaymarchResources);
+            bRequestedOctreeRebuild = false; // also when generation failed, as in the reference: no retry every tick
+        }
         if (SelectRaymarchMaterial != ERaymarchMaterial::Lit) return;
         if (bRequestedRecompute) { ResetAllLights(); return; }
         std::vector<ARaymarchLight*> LightsToUpdate;
@@ -382,8 +385,9 @@ public:
         return tbrm_raymarch_intensity(RaymarchResources.Handle, &Camera, &tile, &rp, &w, OutRGBA) == TBRM_OK;
     }
 
-    // Offscreen replacement of the M_Octree_Raymarch material pass over level OctreeVolumeMip; the pyramid is rebuilt
-    // when a rebuild was requested (new volume, SwitchRenderer(Octree)), as ARaymarchVolume::Tick does (:358-363).
+    // Offscreen replacement of the M_Octree_Raymarch material pass over level OctreeVolumeMip. Tick rebuilds the pyramid
+    // when a rebuild was requested (new volume, SwitchRenderer(Octree); :358-363); a host that renders without ticking
+    // gets the pending rebuild here.
     int OctreeVolumeMip = 0; // RaymarchVolume.h: the level the octree material samples
     bool bRequestedOctreeRebuild = true;
     bool RenderOctree(const tbrm_camera& Camera, float* OutRGBA, int JitterFrame = -1)

@@ -114,7 +114,7 @@ class SlabPass(C.Structure):  # tbrm_slab_pass
 
 # every symbol include/tbrm.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
-    "tbrm_version", "tbrm_last_error", "tbrm_device_count",
+    "tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable",
     "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
@@ -155,6 +155,8 @@ def load():
     P = C.POINTER
     vp = C.c_void_p
     lib.tbrm_device_count.argtypes = [P(C.c_int)]
+    lib.tbrm_set_tunable.argtypes = [C.c_char_p, C.c_int32]
+    lib.tbrm_get_tunable.argtypes = [C.c_char_p, P(C.c_int32)]
     lib.tbrm_resources_create.argtypes = [P(ResourcesDesc), P(vp)]
     lib.tbrm_resources_create_slab.argtypes = [P(ResourcesDesc), P(Slab), P(vp)]
     lib.tbrm_slab_resident_slices.argtypes = [vp, P(C.c_int32 * 3), P(C.c_int32 * 3)]
@@ -173,7 +175,7 @@ def load():
     lib.tbrm_set_windowing.argtypes = [vp, P(WindowingParams)]
     lib.tbrm_add_dir_light.argtypes = [vp, P(DirLightParams), C.c_int, P(WorldParams), P(C.c_int), C.c_int]
     lib.tbrm_add_dir_lights.argtypes = [vp, vp, C.c_int32, C.c_int, P(WorldParams), vp, P(C.c_int32)]
-    lib.tbrm_change_dir_light.argtypes = [vp, P(DirLightParams), P(DirLightParams), P(WorldParams), P(C.c_int)]
+    lib.tbrm_change_dir_light.argtypes = [vp, P(DirLightParams), P(DirLightParams), P(WorldParams), P(C.c_int), C.c_int]
     lib.tbrm_clear_light_volume.argtypes = [vp, C.c_float]
     lib.tbrm_slab_light_begin.argtypes = [vp, P(DirLightParams), P(DirLightParams), C.c_int, P(WorldParams), P(Slab), P(C.c_int32)]
     lib.tbrm_slab_pass_begin.argtypes = [vp, C.c_int32, P(SlabPass)]
@@ -302,6 +304,17 @@ def device_count():
     return n.value if code == OK else 0
 
 
+def set_tunable(name, value):
+    """Process-wide A/B switch of the library (include/tbrm.h tbrm_set_tunable)."""
+    check(load().tbrm_set_tunable(name.encode(), int(value)))
+
+
+def get_tunable(name):
+    v = C.c_int32(0)
+    check(load().tbrm_get_tunable(name.encode(), C.byref(v)))
+    return v.value
+
+
 class Resources:
     """Owns one tbrm_resources handle (FBasicRaymarchRenderingResources)."""
 
@@ -372,9 +385,9 @@ class Resources:
         check(self.lib.tbrm_add_dir_lights(self.handle, arr, n, int(bool(added)), C.byref(world), sched, C.byref(n_entries)))
         return [tuple(sched[4 * e:4 * e + 4]) for e in range(n_entries.value)]
 
-    def change_dir_light(self, old, new, world):
+    def change_dir_light(self, old, new, world, gpu_sync=False):
         flag = C.c_int(0)
-        check(self.lib.tbrm_change_dir_light(self.handle, C.byref(old), C.byref(new), C.byref(world), C.byref(flag)))
+        check(self.lib.tbrm_change_dir_light(self.handle, C.byref(old), C.byref(new), C.byref(world), C.byref(flag), int(gpu_sync)))
         return bool(flag.value)
 
     def clear_light_volume(self, value=0.0):

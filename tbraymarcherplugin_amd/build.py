@@ -9,8 +9,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtbrm.so")
 
-SOURCES = ["tbrm_api.cpp", "tbrm_light_passes.cpp", "tbrm_host_math.cpp", "tbrm_kernels.hip", "tbrm_light_kernels.hip"]
-HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "../../include/tbrm.h"]
+# (source, object name, extra flags): tbrm_light_chain.hip is compiled once per light-volume format so that the two halves
+# of the chain kernel's instantiations build in parallel
+UNITS = [
+    ("tbrm_api.cpp", "tbrm_api", []), ("tbrm_light_passes.cpp", "tbrm_light_passes", []), ("tbrm_host_math.cpp", "tbrm_host_math", []),
+    ("tbrm_kernels.hip", "tbrm_kernels", []), ("tbrm_light_kernels.hip", "tbrm_light_kernels", []),
+    ("tbrm_light_chain.hip", "tbrm_light_chain_u8", ["-DTBRM_CHAIN_LFMT=0"]), ("tbrm_light_chain.hip", "tbrm_light_chain_f32", ["-DTBRM_CHAIN_LFMT=2"]),
+]
+SOURCES = sorted({u[0] for u in UNITS})
+HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h",
+           "../../include/tbrm.h"]
 
 # -ffp-contract=off + explicit fma is the arithmetic contract with the oracle (DESIGN.md "Arithmetic spec").
 FLAGS = [
@@ -35,10 +43,28 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
+    """One hipcc -c per source, in parallel (the kernel files take most of a minute each), then one link."""
     if not force and not needs_build():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+
+    def compile_one(unit):
+        src, name, extra = unit
+        obj = os.path.join(obj_dir, name + ".o")
+        cmd = [hipcc_path()] + compile_flags + extra + ["-c", "-x", "hip", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
+        objs = list(pool.map(compile_one, UNITS))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -12,6 +12,8 @@
 #include "tbrm_resources.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,7 +28,49 @@ using namespace tbrm_host;
 
 namespace {
 thread_local char g_error[512] = "";
+
+// ---- tunables (tbrm_internal.h): name, default; initialised from TBRM_<NAME> when the library is loaded ------------
+struct TunableDef { const char* name; int def; };
+const TunableDef kTunables[TUNE_COUNT] = {
+    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"tile_h", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1},
+    {"occ_prefetch", 1}, {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_stagger", 0}, {"chain_stamps", 0},
+};
+struct TunableStore {
+    std::atomic<int> v[TUNE_COUNT];
+    TunableStore()
+    {
+        for (int t = 0; t < TUNE_COUNT; ++t) {
+            char env[64] = "TBRM_";
+            size_t n = strlen(env);
+            for (const char* c = kTunables[t].name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char) toupper((unsigned char) *c);
+            env[n] = 0;
+            const char* e = getenv(env);
+            v[t].store(e && *e ? atoi(e) : kTunables[t].def, std::memory_order_relaxed);
+        }
+    }
+};
+TunableStore g_tunables;
 } // namespace
+
+namespace tbrm {
+int tune(Tunable t) { return g_tunables.v[t].load(std::memory_order_relaxed); }
+} // namespace tbrm
+
+int tbrm_set_tunable(const char* name, int32_t value)
+{
+    if (!name) return tbrm_host::fail(TBRM_ERR_INVALID_ARG, "null argument");
+    for (int t = 0; t < TUNE_COUNT; ++t)
+        if (!strcmp(name, kTunables[t].name)) { g_tunables.v[t].store(value, std::memory_order_relaxed); return TBRM_OK; }
+    return tbrm_host::fail(TBRM_ERR_INVALID_ARG, "no tunable named '%s'", name);
+}
+
+int tbrm_get_tunable(const char* name, int32_t* value)
+{
+    if (!name || !value) return tbrm_host::fail(TBRM_ERR_INVALID_ARG, "null argument");
+    for (int t = 0; t < TUNE_COUNT; ++t)
+        if (!strcmp(name, kTunables[t].name)) { *value = tune((Tunable) t); return TBRM_OK; }
+    return tbrm_host::fail(TBRM_ERR_INVALID_ARG, "no tunable named '%s'", name);
+}
 
 namespace tbrm_host {
 
@@ -157,7 +201,7 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     host_local_clipping(*world, p.cc, p.cd);
     p.clip_mode = raymarch_clip_mode(p.cc, p.cd);
     p.share_grid = (r->lv_dims[0] == r->desc.dim_x && r->lv_dims[1] == r->desc.dim_y && r->lv_dims[2] == r->desc.dim_z &&
-                    !r->resident && !getenv("TBRM_NO_SHARE_GRID")) ? 1 : 0; // (the two volumes of a slab-resident handle relocate different layers)
+                    !r->resident && tune(TUNE_SHARE_GRID)) ? 1 : 0; // (the two volumes of a slab-resident handle relocate different layers)
     p.tile_x0 = tile->x0; p.tile_y0 = tile->y0; p.tile_w = tile->w; p.tile_h = tile->h;
     p.row_group_step = tile->row_group_step > 0 ? tile->row_group_step : 1;
     p.steps = rp->steps;
@@ -315,7 +359,22 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     } while (0)
 
     CREATE_TRY(hipSetDevice(desc->device));
-    CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    {
+        // the handle's FIFO stream at the highest priority, the occlusion prefetch stream at the lowest: when both have
+        // workgroups waiting for a CU, the latency-bound chain goes first
+        int prio_least = 0, prio_greatest = 0;
+        (void) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        CREATE_TRY(hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, prio_greatest));
+        CREATE_TRY(hipStreamCreateWithPriority(&r->stream2, hipStreamNonBlocking, prio_least));
+        for (int b = 0; b < 2; ++b) {
+            CREATE_TRY(hipEventCreateWithFlags(&r->ev_occ_done[b], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&r->ev_chain_done[b], hipEventDisableTiming));
+        }
+        CREATE_TRY(hipEventCreateWithFlags(&r->ev_ready, hipEventDisableTiming));
+        CREATE_TRY(hipMalloc((void**) &r->d_stagger, 2048 * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void**) &r->d_stamps, 4096 * 32 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(r->d_stagger, 0, 2048 * sizeof(uint32_t), r->stream));
+    }
     if (hipDeviceGetAttribute(&r->n_cus, hipDeviceAttributeMultiprocessorCount, desc->device) != hipSuccess || r->n_cus <= 0) r->n_cus = 256;
     {
         tbrm_resources::Residency& q = r->res_data;
@@ -353,6 +412,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
 {
     if (!r) return TBRM_OK;
     (void) hipSetDevice(r->desc.device);
+    if (r->stream2) (void) hipStreamSynchronize(r->stream2);
     if (r->stream) (void) hipStreamSynchronize(r->stream);
     (void) hipFree(r->res_data.alloc);
     (void) hipFree(r->d_tf);
@@ -361,9 +421,11 @@ int tbrm_resources_destroy(tbrm_resources* r)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
     delete r->slab_op;
-    (void) hipFree(r->d_occ);
+    for (float* o : r->d_occ) (void) hipFree(o);
+    (void) hipFree(r->d_stagger);
+    (void) hipFree(r->d_stamps);
     for (uint8_t* z : r->d_occ_zero) (void) hipFree(z);
-    (void) hipFree(r->d_occ_list);
+    for (uint32_t* l : r->d_occ_list) (void) hipFree(l);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     for (uint16_t* o : r->d_octree) (void) hipFree(o);
@@ -374,6 +436,9 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (auto& k : r->ev)
         for (hipEvent_t e : k)
             if (e) (void) hipEventDestroy(e);
+    for (hipEvent_t e : {r->ev_occ_done[0], r->ev_occ_done[1], r->ev_chain_done[0], r->ev_chain_done[1], r->ev_ready})
+        if (e) (void) hipEventDestroy(e);
+    if (r->stream2) (void) hipStreamDestroy(r->stream2);
     if (r->stream) (void) hipStreamDestroy(r->stream);
     delete r;
     return TBRM_OK;
@@ -477,8 +542,9 @@ int tbrm_add_dir_light(tbrm_resources* r, const tbrm_dir_light_params* light, in
     if (light_added) *light_added = 1;
     if (int e = bind(r)) return e;
     if (int e = begin_timed(r, 0)) return e;
-    if (int e = enqueue_add(r, *light, added != 0, *world)) return e;
-    return end_timed(r, 0);
+    const int e = enqueue_add(r, *light, added != 0, *world);
+    const int e2 = end_timed(r, 0); // also after a failure: the events then bracket whatever was enqueued
+    return e ? e : e2;
 }
 
 int tbrm_add_dir_lights(tbrm_resources* r, const tbrm_dir_light_params* lights, int32_t n_lights, int added, const tbrm_world_params* world,
@@ -490,22 +556,25 @@ int tbrm_add_dir_lights(tbrm_resources* r, const tbrm_dir_light_params* lights, 
     if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
     if (int e = bind(r)) return e;
     if (int e = begin_timed(r, 0)) return e;
-    if (int e = enqueue_add_batch(r, lights, n_lights, added != 0, *world, schedule, n_entries)) return e;
-    return end_timed(r, 0);
+    const int e = enqueue_add_batch(r, lights, n_lights, added != 0, *world, schedule, n_entries);
+    const int e2 = end_timed(r, 0);
+    return e ? e : e2;
 }
 
 int tbrm_change_dir_light(tbrm_resources* r, const tbrm_dir_light_params* old_light, const tbrm_dir_light_params* new_light,
-                          const tbrm_world_params* world, int* light_added)
+                          const tbrm_world_params* world, int* light_added, int gpu_sync)
 {
     if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: light operators run through tbrm_slab_*");
+    (void) gpu_sync; // accepted and ignored (RaymarchUtils.cpp:70-92 never reads it)
     if (light_added) *light_added = 0;
     if (!r || !old_light || !new_light || !world) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function"); // :74-80
     if (light_added) *light_added = 1;
     if (int e = bind(r)) return e;
     if (int e = begin_timed(r, 0)) return e;
-    if (int e = enqueue_change(r, *old_light, *new_light, *world)) return e;
-    return end_timed(r, 0);
+    const int e = enqueue_change(r, *old_light, *new_light, *world);
+    const int e2 = end_timed(r, 0);
+    return e ? e : e2;
 }
 
 // ---- slab-partitioned illumination (tbrm.h "slabs") ------------------------------------------------------------
@@ -573,6 +642,7 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
     if (e == TBRM_ERR_UNSUPPORTED)
         return fail(e, "pass %d (axis %d) has no slab-partitioned form: %s", (int) pass, (int) op.a[pass].axis, g_plan_note);
     if (e) return e;
+    if (int e3 = begin_operator(r)) return e3;
     op.current = pass;
     const PassPlan& pl = op.plan;
     out->axis = pl.p.axis;
@@ -593,7 +663,7 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
 int tbrm_slab_pass_chunk(tbrm_resources* r, int32_t chunk)
 {
     if (!r || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight (tbrm_slab_pass_begin first)");
-    const PassPlan& pl = r->slab_op->plan;
+    PassPlan& pl = r->slab_op->plan;
     if (chunk < 0 || chunk >= pl.n_chunks) return fail(TBRM_ERR_INVALID_ARG, "chunk %d of %d", chunk, pl.n_chunks);
     if (int e = bind(r)) return e;
     return enqueue_plan_chunk(r, pl, chunk);
@@ -1014,6 +1084,15 @@ int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     for (int k = 0; k < 3; ++k) out[k] = r->launches[k];
+    return TBRM_OK;
+}
+
+// diagnostics (not in tbrm.h): the phase stamps of the last chain launch, 8 per workgroup, up to 4096 workgroups
+extern "C" __attribute__((visibility("default"))) int tbrm_debug_chain_stamps(tbrm_resources* r, unsigned long long* out, int n_workgroups)
+{
+    if (!r || !out || n_workgroups > 4096) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(out, r->d_stamps, (size_t) n_workgroups * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return TBRM_OK;
 }
 

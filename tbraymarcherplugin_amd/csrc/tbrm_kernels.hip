@@ -339,9 +339,9 @@ static hipError_t launch_ray2(const RayParams& p, hipStream_t s)
     //   8 lanes per ray          0.61                    0.95                0.14               1.17
     // More lanes per ray shorten the serial chain, fewer keep more rays (and their setup) per wave: few rays or long rays
     // want 8. The rule: rays x (512 / steps) <= 700 k.
-    const char* e = getenv("TBRM_RAY_LANES");
     const double load = (double) p.tile_w * (double) p.tile_h * 512.0 / (double) (p.steps > 1.0f ? p.steps : 1.0f);
-    const int rl = e ? atoi(e) : (load <= 700000.0 ? 8 : 4);
+    const int forced = tune(TUNE_RAY_LANES);
+    const int rl = forced ? forced : (load <= 700000.0 ? 8 : 4);
     return rl == 8 ? launch_ray3<DFMT, LFMT, 8>(p, s) : launch_ray3<DFMT, LFMT, 4>(p, s);
 }
 template <int DFMT>

@@ -23,6 +23,7 @@
 // LDS reads and one multiply per voxel, with no memory latency between slices. Arithmetic per voxel is exactly the
 // reference's, including the per-slice UNORM8 re-quantisation of the propagated light (RaymarchVolume.cpp:857-866).
 #include "tbrm_device_sampling.h"
+#include "tbrm_light_chain.h"
 
 #include <type_traits>
 
@@ -124,79 +125,28 @@ hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t 
 // ------------------------------------------------------------------------------------------------------------
 // a chunk of slices per launch pair
 
-__device__ __forceinline__ char* carve(char*& cursor, size_t bytes)
-{
-    char* r = cursor;
-    cursor += (bytes + 15) & ~(size_t) 15;
-    return r;
-}
-
-// Window geometry of one chain workgroup. A tile keeps its 32x32 pixels for the whole chunk; with r slices still to
-// go its window is [r*lox, T + r*hix) x [r*loy, T + r*hiy) in tile coordinates (lox <= 0 <= hix: the range of the
-// previous-slice taps, widened to contain 0), i.e. it grows towards the light by the tap range per remaining slice.
-struct ChunkGeom {
-    int n;                  // steps in this chunk
-    int lox, hix, loy, hiy;
-    int HX, HY;             // hull = window at r = n (the input state)
-    int RS;                 // LDS plane edge / row stride in floats (0: the hull does not fit any instantiation)
-    int padx, pady;         // plane coordinates of tile pixel (0,0)
-    int lv_layers;          // 8-slice brick layers of the light volume the chunk touches
-    int lv_layer0;          // first of them
-};
-
-// LDS planes are RS x RS floats, RS an odd multiple of 8 (bank-conflict-free 8x8 patches, see k_light_chain)
-__host__ __device__ constexpr int chain_plane_elems(int RS) { return RS * RS + 8; } // + slack for inactive slots' reads
-__host__ __device__ constexpr int chain_row_stride(int hull) { return hull <= 40 ? 40 : (hull <= 56 ? 56 : (hull <= 72 ? 72 : 0)); }
-
-__host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
-{
-    ChunkGeom g;
-    g.n = p.n_steps;
-    g.lox = p.dx_lo; g.hix = p.dx_hi; g.loy = p.dy_lo; g.hiy = p.dy_hi;
-    g.HX = kChunkTile + g.n * (g.hix - g.lox);
-    g.HY = kChunkTile + g.n * (g.hiy - g.loy);
-    g.RS = chain_row_stride(g.HX > g.HY ? g.HX : g.HY);
-    g.padx = -g.n * g.lox;
-    g.pady = -g.n * g.loy;
-    const int ja = p.j0, jb = p.j0 + (g.n - 1) * p.dir;
-    const int jlo = ja < jb ? ja : jb, jhi = ja < jb ? jb : ja;
-    g.lv_layer0 = jlo >> 3;
-    g.lv_layers = (jhi >> 3) - g.lv_layer0 + 1;
-    return g;
-}
-
-constexpr int kOccRing = 3; // slices the occlusion operands are staged ahead of their use
-
-// Workgroup barrier for LDS traffic only. __syncthreads() carries a workgroup-scope fence, which the compiler has to
-// lower to s_waitcnt vmcnt(0): inside the chain's slice loop that would drain the asynchronous global->LDS copies
-// issued for the slices AHEAD at every barrier and expose their full latency once per slice. Here only this wave's LDS
-// operations are waited for; copy completion is tracked explicitly with s_waitcnt vmcnt(N) by the caller.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// instantiated shapes: Change runs RS 40/56 (two streams of 72 x 72 planes exceed the LDS), Add RS 40/56/72
+// LDS bytes of a chain workgroup; 1 GiB when no instantiated kernel shape holds the chunk's hull
+// (tbrm_light_chain.hip launch_chain3 lists the shapes)
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
-    if (g.RS == 0 || (change && g.RS > 56)) return (size_t) 1 << 30;
+    const size_t none = (size_t) 1 << 30;
+    if (g.RS == 0) return none;
     const int ns = change ? 2 : 1;
-    size_t total = (size_t) ns * (2 + kOccRing) * chain_plane_elems(g.RS) * 4; // windows + staged occlusion ring
-    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;             // light-volume tile
+    if (g.TY == 16) { // k_light_chain2: 512 halo lanes take the hull's pixels outside the tile, at most 3 each
+        const int kh = (g.HX * g.HY - 512 + 511) / 512;
+        const int kh_max = (g.RS == 40 && g.RR == 24) ? 1 : ((g.RS == 56 && g.RR == 32) ? 3 : 2);
+        if (kh > kh_max) return none;
+        size_t total = (size_t) ns * (2 + chain2_ring(g.RS, g.RR, ns)) * chain_plane_elems(g.RS, g.RR) * 4 + 4096; // ring + windows + slack
+        if (lv_fmt == FMT_U8) total += (size_t) 8 * g.lv_layers * 512;                                             // light-volume tile
+        return total;
+    }
+    const int threads = kChunkTileW * g.TY;
+    const int kh = (g.HX * g.HY - threads + threads - 1) / threads;
+    if ((change && g.RS > 56) || kh > 3) return none;
+    size_t total = (size_t) ns * (2 + kOccRing) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged occlusion ring
+    if (lv_fmt == FMT_U8) total += (size_t) 4 * (g.TY / 8) * g.lv_layers * 512;       // light-volume tile
     return total;
-}
-
-// asynchronous global -> LDS copies: lane l of the wave lands at lds_wave_base + size*l
-__device__ __forceinline__ void dma_dword(const float* src, float* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
-                                     (__attribute__((address_space(3))) void*) lds_wave_base, 4, 0, 0);
-}
-__device__ __forceinline__ void dma_16(const void* src, void* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) src,
-                                     (__attribute__((address_space(3))) void*) lds_wave_base, 16, 0, 0);
 }
 
 // ---- k_light_occlusion: CurrentSample (AddDirLightShader.usf:85-114) for every voxel of a chunk ------------------
@@ -589,343 +539,6 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     else run(F_{}, F_{}, T_{});                                           // bricks did not fit in LDS
 }
 
-// ---- k_light_chain: one tile through the slices of the chunk ---------------------------------------------------
-// Everything a slice needs is in LDS before the slice starts: the propagated-light windows, the occlusion factors of
-// the window (staged two slices ahead with asynchronous 16-byte global->LDS copies) and, for UNORM8 light volumes, the
-// tile's light-volume bricks (loaded once, read-modify-written in LDS, stored once).
-//
-// LDS planes are RS x RS floats with RS a compile-time odd multiple of 8: every window/ring/stream offset is an
-// immediate of the ds instruction (one address register per slot and stream instead of five), and the eight rows of a
-// wave's 8x8 patch fall on disjoint groups of eight banks. Per slice: refill the ring slot read in the previous slice
-// with the slice two ahead, issue every LDS read of the slice, compute, write, and meet ONCE at a barrier.
-
-template <int LFMT, int MODE, int AXIS, int KH, int RS> // KH = halo pixels per thread: ceil((hull area - tile area) / threads)
-__global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = kChunkTile;
-    constexpr int NS = MODE != PASS_ADD ? 2 : 1;
-    constexpr bool LV_LDS = LFMT == FMT_U8;
-    constexpr int KS = 1 + KH; // + the owned pixel
-    constexpr int PLANE = chain_plane_elems(RS);
-    constexpr int GPR = RS / 4;                                         // 16-byte copy groups per plane row
-    constexpr int GROUPS = RS * GPR;
-    constexpr int ROUNDS = (GROUPS + kChunkThreads - 1) / kChunkThreads; // copy groups per thread
-    static_assert(RS % 16 == 8 && ROUNDS <= 2, "row stride must be an odd multiple of 8");
-    const ChunkGeom g = chunk_geometry(p);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int plane_elems = p.H * p.W;
-    // Tile of this workgroup. Workgroups go to the 8 XCDs round-robin by linear id (an affinity used for speed only): XCD x
-    // takes the x-th eighth of the row-major tile list — a band of neighbouring tiles whose overlapping halo reads of the
-    // occlusion planes then meet in one L2.
-    const int n_tiles = p.tiles_x * p.tiles_y, per_xcd = (n_tiles + 7) >> 3;
-    const int tile_id = ((int) blockIdx.x & 7) * per_xcd + ((int) blockIdx.x >> 3);
-    if (((int) blockIdx.x >> 3) >= per_xcd || tile_id >= n_tiles) return;
-    const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
-    const int base_x = tile_x * T, base_y = (p.tile_row0 + tile_y) * T;
-
-    // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, ring slot q at ((2 + q)*NS + si)*PLANE; then the
-    // light-volume tile (bytes)
-    float* const lds = (float*) smem;
-    uint8_t* const lv_tile = (uint8_t*) (lds + (2 + kOccRing) * NS * PLANE);
-    auto window = [&](int w, int si) -> float* { return lds + (w * NS + si) * PLANE; };
-    auto ring = [&](int q, int si) -> float* { return lds + ((2 + q) * NS + si) * PLANE; };
-
-    // ---- 16-byte staging pattern: copy group i = floats [4i, 4i+4) of an LDS plane = 4 pixels of one hull row ------
-    int st_src[ROUNDS];   // pixel index of the group's first pixel inside a plane (may run off the row ends: guard bands)
-    bool st_ok[ROUNDS];
-    int st_dst[ROUNDS];   // this wave's 64 x 4 floats
-    bool st_one[ROUNDS][2] = {}; // the group's 4 pixels lie in empty blocks of slice group 0 / 1 of the chunk
-    int ndma = 0;         // copies this WAVE issues per staged slice (wave-uniform)
-#pragma unroll
-    for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int gi = (int) threadIdx.x + rd * kChunkThreads;
-        const int row = gi / GPR, col = (gi - row * GPR) * 4;
-        const int py = base_y - g.pady + row;
-        st_src[rd] = py * p.W + base_x - g.padx + col;
-        st_ok[rd] = gi < GROUPS && row < g.HY && col < g.HX && (unsigned) py < (unsigned) p.H;
-        st_dst[rd] = (wave * 64 + rd * kChunkThreads) * 4;
-        if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NS;
-        // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: their factor 1 - 0 is staged from
-        // a page of ones
-        if (p.occ_flags && st_ok[rd]) {
-            const int x_first = base_x - g.padx + col, x_last = x_first + 3;
-            const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = py >> 4;
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                bool one = x_last >= 0 && x_first < p.W && z * kOccDepth < p.occ_phase + g.n;
-                if (one) {
-                    const uint8_t* frow = p.occ_flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
-                    one = frow[bx0] != 0 && frow[bx1] != 0;
-                }
-                st_one[rd][z] = one;
-            }
-        }
-    }
-    // The occlusion stacks of both streams and the page of ones live in one allocation: a copy's source is the uniform
-    // base plus a 32-bit offset, and flagged-empty lanes only swap the offset (the same number of copy instructions per
-    // wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on).
-    auto stage_occ = [&](int sf, int q) {
-        if (sf >= g.n) return;
-        const int group = (p.occ_phase + sf) / kOccDepth;
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            if (!st_ok[rd]) continue;
-            const bool one = group == 0 ? st_one[rd][0] : st_one[rd][1];
-            const uint32_t px = (uint32_t) (sf * plane_elems + st_src[rd]);
-#pragma unroll
-            for (int si = 0; si < NS; ++si) {
-                const uint32_t off = one ? (uint32_t) lane * 4u : (si == 0 ? p.a.occ_off : p.r.occ_off) + px;
-                dma_16(p.occ_base + off, ring(q, si) + st_dst[rd]);
-            }
-        }
-    };
-
-    // ---- input state: the plane after the previous chunk ------------------------------------------------------------
-    if (!p.first_chunk) {
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; ++rd) {
-            if (!st_ok[rd]) continue;
-            dma_16(p.a.plane_in + st_src[rd], window(0, 0) + st_dst[rd]);
-            if constexpr (NS == 2) dma_16(p.r.plane_in + st_src[rd], window(0, 1) + st_dst[rd]);
-        }
-    }
-    stage_occ(0, 0);
-    stage_occ(1, 1);
-
-    // ---- light-volume tile: the 4x4 brick columns under the tile, every brick layer the chunk touches --------------
-    constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
-    const int lbn[3] = {p.lv_bnx, p.lv_bnxy / p.lv_bnx, (p.lv_dims[2] + 7) >> 3};
-    auto tile_brick_global = [&](int lb, bool& exists) -> uint32_t { // lb = (layer*4 + bv)*4 + bu
-        const int bu = (base_x >> 3) + (lb & 3), bv = (base_y >> 3) + ((lb >> 2) & 3), bl = g.lv_layer0 + (lb >> 4);
-        exists = bu < lbn[dim_u] && bv < lbn[dim_v] && bl < lbn[dim_s];
-        int b3[3];
-        b3[dim_u] = bu; b3[dim_v] = bv; b3[dim_s] = bl;
-        return (uint32_t) ((b3[2] * lbn[1] + b3[1]) * lbn[0] + b3[0]) * 512u;
-    };
-    if constexpr (LV_LDS) {
-        const int chunks = 16 * g.lv_layers * 32; // 16-byte pieces
-        for (int cb = wave * 64; cb < chunks; cb += kChunkThreads) {
-            const int c = cb + lane;
-            bool exists;
-            const uint32_t gofs = tile_brick_global(c >> 5, exists) + (uint32_t) (c & 31) * 16u;
-            if (c < chunks && exists) dma_16((const uint8_t*) p.light + gofs, lv_tile + cb * 16);
-        }
-    }
-
-    // ---- this thread's slots: slot 0 = its owned pixel (8x8 patch per wave over the 32x32 tile), the rest = its share of
-    // the halo (hull minus tile). A slot's pixel, window index, tap offsets and weights never change during the chunk.
-    int sqx[KS], sqy[KS];
-    sqx[0] = (wave & 3) * 8 + (lane & 7);
-    sqy[0] = (wave >> 2) * 8 + (lane >> 3);
-    {
-        // halo slots enumerated as: full rows above the tile, the two side strips of the tile rows, full rows below
-        const int top = g.pady * g.HX, side = g.HX - T, mid = T * side;
-        const int n_halo = g.HX * g.HY - T * T;
-        const float inv_hx = 1.0f / (float) g.HX, inv_side = side > 0 ? 1.0f / (float) side : 0.0f;
-#pragma unroll
-        for (int k = 0; k < KH; ++k) {
-            const int h = threadIdx.x + k * kChunkThreads;
-            int lx = 0, ly = 0;
-            if (h < top) { ly = (int) (((float) h + 0.5f) * inv_hx); lx = h - ly * g.HX; }
-            else if (h < top + mid) {
-                const int m = h - top;
-                const int row = (int) (((float) m + 0.5f) * inv_side), col = m - row * side;
-                ly = g.pady + row;
-                lx = col < g.padx ? col : col + T;
-            } else {
-                const int m = h - top - mid;
-                const int row = (int) (((float) m + 0.5f) * inv_hx);
-                ly = g.pady + T + row;
-                lx = m - row * g.HX;
-            }
-            sqx[1 + k] = h < n_halo ? lx - g.padx : INT32_MIN / 2; // sentinel: never inside a window
-            sqy[1 + k] = ly - g.pady;
-        }
-    }
-    // floor(a / d) for 0 <= a < 4096 and a small positive integer d, as a multiplication: (a + 0.5) / d is never within
-    // 0.5 / d of an integer, far more than the rounding error of the product
-    auto small_div = [](int a, float inv_d) -> int { return (int) (((float) a + 0.5f) * inv_d); };
-    const float inv_lox = g.lox < 0 ? 1.0f / (float) -g.lox : 0.0f, inv_hix = g.hix > 0 ? 1.0f / (float) g.hix : 0.0f;
-    const float inv_loy = g.loy < 0 ? 1.0f / (float) -g.loy : 0.0f, inv_hiy = g.hiy > 0 ? 1.0f / (float) g.hiy : 0.0f;
-    int rmin[KS];          // the slot is inside the window while r >= rmin (huge: never / outside the buffer)
-    int li[KS];            // LDS index of the slot inside a plane
-    int ti[NS][KS];        // LDS index of the first previous-slice tap inside a plane
-    float wfx[NS][KS], wfy[NS][KS]; // bilinear weights of the previous-slice fetch
-    bool off_plane[KS];    // inside the hull but outside the buffer: holds the border colour
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const int qx = sqx[k], qy = sqy[k];
-        const int px = base_x + qx, py = base_y + qy;
-        const bool valid = qx > INT32_MIN / 4;
-        const bool inplane = valid && (unsigned) px < (unsigned) p.W && (unsigned) py < (unsigned) p.H;
-        int need = 0; // smallest r whose window contains the slot: ceil(distance to the tile / growth per slice)
-        if (qx < 0) need = max(need, g.lox < 0 ? small_div(-qx + (-g.lox) - 1, inv_lox) : INT32_MAX / 2);
-        if (qx >= T) need = max(need, g.hix > 0 ? small_div(qx - T + g.hix, inv_hix) : INT32_MAX / 2);
-        if (qy < 0) need = max(need, g.loy < 0 ? small_div(-qy + (-g.loy) - 1, inv_loy) : INT32_MAX / 2);
-        if (qy >= T) need = max(need, g.hiy > 0 ? small_div(qy - T + g.hiy, inv_hiy) : INT32_MAX / 2);
-        rmin[k] = inplane ? need : INT32_MAX / 2;
-        off_plane[k] = valid && !inplane;
-        li[k] = valid ? (qy + g.pady) * RS + qx + g.padx : 0;
-        // (PixelLoc + 0.5) / BufferSize: the same for both streams
-        const float pu = ((float) (uint32_t) px + 0.5f) / (float) p.W, pv = ((float) (uint32_t) py + 0.5f) / (float) p.H;
-#pragma unroll
-        for (int si = 0; si < NS; ++si) {
-            // previous-slice tap split: ((c + 0.5)/size + PrevPixelOffset) -> (tap - c, frac) (AddDirLightShader.usf:81-82)
-            const ChunkStream& s = si == 0 ? p.a : p.r;
-            int ix = 0, iy = 0;
-            float fx = 0.0f, fy = 0.0f;
-            if (inplane) {
-                texel_split(pu + s.off_u, (float) p.W, ix, fx);
-                texel_split(pv + s.off_v, (float) p.H, iy, fy);
-                ix -= px;
-                iy -= py;
-            }
-            ti[si][k] = li[k] + iy * RS + ix;
-            wfx[si][k] = fx;
-            wfy[si][k] = fy;
-        }
-    }
-    const int own_idx = (base_y + sqy[0]) * p.W + base_x + sqx[0]; // owned pixel inside a plane
-
-    // the owned pixel's voxel: constant in-plane part + per-slice part, as an offset into the bricked global volume
-    // (float light volumes) or into the LDS tile (UNORM8)
-    uint32_t lv_const = 0;
-    {
-        const int px = base_x + sqx[0], py = base_y + sqy[0];
-        if constexpr (LV_LDS) {
-            const uint32_t lb = (uint32_t) ((sqy[0] >> 3) * 4 + (sqx[0] >> 3)) * 512u;
-            if (AXIS == 0) lv_const = lb + (uint32_t) (py & 7) * 64u + (uint32_t) (px & 7) * 8u;
-            else if (AXIS == 1) lv_const = lb + (uint32_t) (py & 7) * 64u + (uint32_t) (px & 7);
-            else lv_const = lb + (uint32_t) (py & 7) * 8u + (uint32_t) (px & 7);
-        } else {
-            if (AXIS == 0) lv_const = brick_off_y(px, p.lv_bnx) + brick_off_z(py, p.lv_bnxy);
-            else if (AXIS == 1) lv_const = brick_off_x(px) + brick_off_z(py, p.lv_bnxy);
-            else lv_const = brick_off_x(px) + brick_off_y(py, p.lv_bnx);
-        }
-    }
-    auto lv_slice_off = [&](int j) -> uint32_t {
-        if constexpr (LV_LDS) {
-            const uint32_t layer = (uint32_t) ((j >> 3) - g.lv_layer0) * 16u * 512u;
-            return layer + (uint32_t) (j & 7) * (AXIS == 0 ? 1u : (AXIS == 1 ? 8u : 64u));
-        } else {
-            return AXIS == 0 ? brick_off_x(j) : (AXIS == 1 ? brick_off_y(j, p.lv_bnx) : brick_off_z(j, p.lv_bnxy));
-        }
-    };
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's copies (input window, first occlusion planes, tile) have landed
-    __syncthreads();
-    // slots outside the buffer hold the read sampler's border colour in BOTH windows for the whole chunk
-    // (AddDirLightShader.usf:22-25); in the first chunk the buffers were just cleared to the initial light
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-#pragma unroll
-        for (int si = 0; si < NS; ++si) {
-            const ChunkStream& s = si == 0 ? p.a : p.r;
-            if (off_plane[k]) { window(0, si)[li[k]] = s.border_light; window(1, si)[li[k]] = s.border_light; }
-            else if (p.first_chunk && rmin[k] < INT32_MAX / 2) window(0, si)[li[k]] = s.init_value;
-        }
-    }
-    __syncthreads();
-
-    // one slice: window `cur` holds the state before it, ring slot `q` the slice's occlusion factors
-    auto step = [&](int s, int cur, int q) {
-        const int r = g.n - 1 - s; // slices that remain after this one
-        const uint32_t vi = lv_const + lv_slice_off(p.j0 + s * p.dir);
-        // every LDS read of the slice first (the writes below may alias them as far as the compiler can tell, so reads
-        // issued after a write would wait for it: issued up front, their latencies overlap instead of adding up)
-        bool act[KS];
-        float t00[KS][NS], t01[KS][NS], t10[KS][NS], t11[KS][NS], fac[KS][NS];
-        float lv_old = 0.0f;
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            act[k] = r >= rmin[k];
-            if (!act[k]) continue;
-#pragma unroll
-            for (int si = 0; si < NS; ++si) {
-                const float* pw = window(cur, si) + ti[si][k];
-                t00[k][si] = pw[0]; t01[k][si] = pw[1]; t10[k][si] = pw[RS]; t11[k][si] = pw[RS + 1];
-                fac[k][si] = ring(q, si)[li[k]];
-            }
-            if (k == 0) {
-                if constexpr (LV_LDS) lv_old = decode_u8(lv_tile[vi]);
-                else lv_old = load_voxel<LFMT>(p.light, vi);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            if (!act[k]) continue;
-            float lval[NS];
-#pragma unroll
-            for (int si = 0; si < NS; ++si) {
-                // previous slice, bilinear with border colour (AddDirLightShader.usf:81-82)
-                const float prev = lerp_(lerp_(t00[k][si], t01[k][si], wfx[si][k]), lerp_(t10[k][si], t11[k][si], wfx[si][k]), wfy[si][k]);
-                const float l = prev * fac[k][si]; // :117 (the occlusion kernel stored 1 - CurrentSample)
-                lval[si] = l;
-                window(cur ^ 1, si)[li[k]] = through_format<LFMT>(l); // WriteBuffer[PixelLoc] = L (:120)
-            }
-            if (k == 0) { // the owned pixel: this workgroup writes its light-volume voxel
-                float nv;
-                bool write;
-                if constexpr (MODE == PASS_ADD) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; } // :123-126
-                else if constexpr (MODE == PASS_CHANGE) { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; } // Change :152-154
-                else { // two lights added in one pass: light a's read-modify-write, then light r's on its result (:123-126 twice)
-                    const bool wa = fabsf(lval[0]) > 1e-3f, wb = fabsf(lval[NS - 1]) > 1e-3f;
-                    nv = wa ? through_format<LFMT>(lv_old + lval[0] * p.b_added) : lv_old;
-                    if (wb) nv = nv + lval[NS - 1] * p.b_added2;
-                    write = wa || wb;
-                }
-                if (write) {
-                    if constexpr (LV_LDS) lv_tile[vi] = (uint8_t) encode_u8(nv);
-                    else store_voxel<LFMT>(p.light, vi, nv);
-                }
-                if (r == 0) {
-#pragma unroll
-                    for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[own_idx] = through_format<LFMT>(lval[si]);
-                }
-            }
-        }
-    };
-
-    static_assert(kOccRing == 3, "the slice loop below is unrolled for a ring of three");
-    // Per slice: refill the ring slot the PREVIOUS slice read (every wave left that slice at the barrier) with the slice
-    // two ahead, compute, then wait until only that refill may still be in flight — the copies of slice s+1, issued a
-    // whole slice ago, have landed — and meet at the barrier that also publishes this slice's window writes. Copies
-    // complete in issue order and, with a UNORM8 light volume, are the only vector-memory operations of the loop; a float
-    // light volume adds the owned voxel's load and conditional store, so that variant drains everything.
-    for (int s0 = 0; s0 < g.n; s0 += 6) {
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int s = s0 + u;
-            stage_occ(s + 2, (u + 2) % 3);
-            if (s < g.n) step(s, u & 1, u % 3);
-            const int pending = (LV_LDS && s + 2 < g.n) ? ndma : 0;
-            if (pending == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (pending == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            lds_barrier();
-        }
-    }
-
-    // ---- write the tile's light-volume bricks back ----------------------------------------------------------------
-    if constexpr (LV_LDS) {
-        const int chunks = 16 * g.lv_layers * 32;
-        for (int c = threadIdx.x; c < chunks; c += kChunkThreads) {
-            bool exists;
-            const uint32_t gofs = tile_brick_global(c >> 5, exists) + (uint32_t) (c & 31) * 16u;
-            if (exists) *(uint4*) ((uint8_t*) p.light + gofs) = *(const uint4*) (lv_tile + c * 16);
-        }
-    }
-}
-
-constexpr int kMaxDevices = 64;
-static int current_device()
-{
-    int dev = 0;
-    (void) hipGetDevice(&dev);
-    return dev >= 0 && dev < kMaxDevices ? dev : 0;
-}
-
 template <int DFMT, int MODE, int AXIS>
 static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
 {
@@ -933,8 +546,8 @@ static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
     const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
     size_t lds = occlusion_lds_bytes(p);
     if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
-    static bool attr[kMaxDevices] = {}; // the attribute is per device
-    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_occlusion<DFMT, MODE, AXIS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr[dev] = true; }
+    static std::atomic<uint64_t> attr_done{0};
+    if (const hipError_t e = allow_big_lds(k_light_occlusion<DFMT, MODE, AXIS>, attr_done, 128 * 1024); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_light_occlusion<DFMT, MODE, AXIS>), grid, block, lds, s, p, (int) lds);
     return hipGetLastError();
 }
@@ -959,50 +572,10 @@ hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s)
     }
 }
 
-template <int LFMT, int MODE, int AXIS, int KH, int RS>
-static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
-{
-    static bool attr[kMaxDevices] = {}; // the attribute is per device
-    if (const int dev = current_device(); !attr[dev]) { (void) hipFuncSetAttribute((const void*) k_light_chain<LFMT, MODE, AXIS, KH, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr[dev] = true; }
-    const size_t lds = chunk_lds_bytes(p, MODE != PASS_ADD, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
-    return hipGetLastError();
-}
-template <int LFMT, int MODE, int AXIS>
-static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
-{
-    const ChunkGeom g = chunk_geometry(p);
-    const int halo = g.HX * g.HY - kChunkTile * kChunkTile;
-    const int kh = (halo + kChunkThreads - 1) / kChunkThreads; // <= 3 for hulls up to 64 x 64
-    if constexpr (MODE != PASS_ADD) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
-        if (g.RS == 40) return launch_chain4<LFMT, MODE, AXIS, 1, 40>(p, s);
-        if (g.RS == 56) {
-            if (kh <= 1) return launch_chain4<LFMT, MODE, AXIS, 1, 56>(p, s);
-            if (kh == 2) return launch_chain4<LFMT, MODE, AXIS, 2, 56>(p, s);
-            return launch_chain4<LFMT, MODE, AXIS, 3, 56>(p, s);
-        }
-    } else {
-        if (g.RS == 40) return launch_chain4<LFMT, MODE, AXIS, 1, 40>(p, s);
-        if (g.RS == 56) return launch_chain4<LFMT, MODE, AXIS, 3, 56>(p, s);
-        if (g.RS == 72 && kh <= 3) return launch_chain4<LFMT, MODE, AXIS, 3, 72>(p, s);
-    }
-    return hipErrorInvalidConfiguration; // the host's LDS check (chunk_lds_bytes) rules these shapes out
-}
-template <int LFMT, int MODE>
-static hipError_t launch_chain2(const ChunkParams& p, hipStream_t s)
-{
-    return p.axis == 0 ? launch_chain3<LFMT, MODE, 0>(p, s) : (p.axis == 1 ? launch_chain3<LFMT, MODE, 1>(p, s) : launch_chain3<LFMT, MODE, 2>(p, s));
-}
-// advances every tile through the chunk (j0, n_steps), reading the occlusion planes at occ_base + {a,r}.occ_off
-template <int LFMT>
-static hipError_t launch_chain1(const ChunkParams& p, int mode, hipStream_t s)
-{
-    return mode == PASS_ADD ? launch_chain2<LFMT, PASS_ADD>(p, s) : (mode == PASS_CHANGE ? launch_chain2<LFMT, PASS_CHANGE>(p, s) : launch_chain2<LFMT, PASS_ADD2>(p, s));
-}
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s)
 {
     if (p.n_steps <= 0 || p.tiles_x <= 0 || p.tiles_y <= 0) return hipSuccess;
-    return lv_fmt == FMT_U8 ? launch_chain1<FMT_U8>(p, mode, s) : launch_chain1<FMT_F32>(p, mode, s);
+    return lv_fmt == FMT_U8 ? launch_light_chain_u8(p, mode, s) : launch_light_chain_f32(p, mode, s);
 }
 
 } // namespace tbrm

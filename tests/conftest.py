@@ -38,6 +38,22 @@ def gpu(abi_mod):
     return abi_mod
 
 
+@pytest.fixture
+def tunables(abi_mod):
+    """tunables(name, value) flips one of the library's process-wide A/B switches (tbrm_set_tunable) for the duration of
+    the test; every switch touched goes back to what it was."""
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = abi_mod.get_tunable(name)
+        abi_mod.set_tunable(name, value)
+
+    yield set_
+    for name, value in saved.items():
+        abi_mod.set_tunable(name, value)
+
+
 def small_volume(dims, dtype, seed=0x5EED0002):
     from tbraymarcherplugin_amd import synthetic
 

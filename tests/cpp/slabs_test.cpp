@@ -94,15 +94,15 @@ int main(int argc, char** argv)
         for (const auto& l : all) TRY(tbrm_add_dir_light(whole, &l, 1, &world, &flag, 0));
         const tbrm_dir_light_params moved{{-.45, 1, -.25}, 0.4f, 0}, turned{{1, .1, -.2}, 0.4f, 0};
         group.ChangeDirLight(lights[1], moved, world);   // fused
-        TRY(tbrm_change_dir_light(whole, &lights[1], &moved, &world, &flag));
+        TRY(tbrm_change_dir_light(whole, &lights[1], &moved, &world, &flag, 0));
         group.ChangeDirLight(lights[2], turned, world);  // across faces: remove + add
-        TRY(tbrm_change_dir_light(whole, &lights[2], &turned, &world, &flag));
+        TRY(tbrm_change_dir_light(whole, &lights[2], &turned, &world, &flag, 0));
         for (int rep = 0; rep < 6; ++rep) { // back-to-back operations: the handles' streams run ahead of each other
             const tbrm_dir_light_params a{{0.3 + 0.1 * rep, -0.8, 0.4 - 0.15 * rep}, 0.2f, 0}, b{{0.35 + 0.1 * rep, -0.8, 0.45 - 0.15 * rep}, 0.25f, 0};
             group.AddDirLight(a, true, world);
             TRY(tbrm_add_dir_light(whole, &a, 1, &world, &flag, 0));
             group.ChangeDirLight(a, b, world);
-            TRY(tbrm_change_dir_light(whole, &a, &b, &world, &flag));
+            TRY(tbrm_change_dir_light(whole, &a, &b, &world, &flag, 0));
         }
 
         std::vector<uint8_t> ref((size_t) nx * ny * nz), got((size_t) nx * ny * nz / n_slabs);

@@ -72,7 +72,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
         "tbrm_set_tf_lut": lambda: lib.tbrm_set_tf_lut(z, buf),
         "tbrm_set_windowing": lambda: lib.tbrm_set_windowing(z, C.byref(abi.WindowingParams())),
         "tbrm_add_dir_lights": lambda: lib.tbrm_add_dir_lights(z, None, 0, 1, C.byref(abi.make_world()), None, None),
-        "tbrm_change_dir_light": lambda: lib.tbrm_change_dir_light(z, None, None, None, None),
+        "tbrm_change_dir_light": lambda: lib.tbrm_change_dir_light(z, None, None, None, None, 0),
         "tbrm_clear_light_volume": lambda: lib.tbrm_clear_light_volume(z, 0.0),
         "tbrm_raymarch_lit": lambda: lib.tbrm_raymarch_lit(z, None, None, None, None, buf),
         "tbrm_raymarch_lit_device": lambda: lib.tbrm_raymarch_lit_device(z, None, None, None, None, None, buf),
@@ -104,7 +104,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
     # every symbol that takes the handle first is covered here or in the test above
     covered = set(calls) | {"tbrm_resources_destroy", "tbrm_resources_is_initialized", "tbrm_add_dir_light", "tbrm_flush",
                             "tbrm_raymarch_intensity_device", "tbrm_raymarch_octree_device", "tbrm_download_octree_mip"}
-    free = {"tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_color_curve_to_lut",
+    free = {"tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable", "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_color_curve_to_lut",
             "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip",
             "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local"}
     assert set(abi.SYMBOLS) == covered | free, set(abi.SYMBOLS) ^ (covered | free)

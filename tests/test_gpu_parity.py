@@ -40,19 +40,16 @@ def assert_light_equal(res, orc):
 
 
 @pytest.fixture(params=["chunk", "slice"])
-def kernel_variant(request, monkeypatch):
+def kernel_variant(request, tunables):
     """Runs a test with the production chunk kernel and with the one-slice-per-launch kernel."""
-    if request.param == "slice":
-        monkeypatch.setenv("TBRM_FORCE_SLICE_KERNEL", "1")
-    else:
-        monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+    tunables("force_slice_kernel", 1 if request.param == "slice" else 0)
     return request.param
 
 
 @pytest.fixture(params=["4", "8"])
-def ray_lanes(request, monkeypatch):
+def ray_lanes(request, tunables):
     """Runs a raymarch test with both lanes-per-ray variants of k_raymarch_lit (the launcher picks by frame size otherwise)."""
-    monkeypatch.setenv("TBRM_RAY_LANES", request.param)
+    tunables("ray_lanes", int(request.param))
     return request.param
 
 
@@ -452,7 +449,7 @@ def test_steep_secondary_passes(gpu, oracle_mod, kernel_variant):
 
 @pytest.mark.parametrize("light_32bit", [False, True])
 @pytest.mark.parametrize("dims", [(48, 40, 56), (64, 64, 64)])
-def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, kernel_variant, monkeypatch):
+def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, kernel_variant, tunables):
     """tbrm_add_dir_lights pairs passes of different lights that share a cube face; the oracle replays the reported pass
     order one pass at a time. UNORM8: bit-exact."""
     res, orc = make_pair(gpu, oracle_mod, dims, np.uint16, light_32bit, seed=0x5EED0500)
@@ -488,7 +485,7 @@ def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, 
             d = np.abs(batched.astype(int) - seq.astype(int))
             assert d.max() <= 1 and np.count_nonzero(d) <= 2e-3 * d.size, (int(d.max()), int(np.count_nonzero(d)))
         # the switch that turns pairing off: the reference's order, bit for bit
-        monkeypatch.setenv("TBRM_NO_LIGHT_BATCHING", "1")
+        tunables("light_batching", 0)
         res.clear_light_volume(0.0)
         sched = res.add_dir_lights(lights, True, world)
         assert all(b < 0 for _, _, b, _ in sched)
@@ -655,7 +652,7 @@ def test_non_finite_voxels_and_degenerate_windows(gpu, oracle_mod):
 # ---- randomized sweep of the render modes --------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("seed", range(16))
-def test_random_render_scenes_against_oracle(gpu, oracle_mod, seed):
+def test_random_render_scenes_against_oracle(gpu, oracle_mod, seed, tunables):
     """Seeded random scenes for the three render modes: ragged sizes, data / light formats, half-resolution light volume,
     wrap / clamp, transfer functions, windows, rotated and non-uniformly scaled volumes with clip planes, cameras anywhere
     (inside, far, grazing), fields of view, step counts from a fraction of a step to hundreds, jitter frames, odd tiles with
@@ -695,16 +692,11 @@ def test_random_render_scenes_against_oracle(gpu, oracle_mod, seed):
             tile = abi.Tile(int(rng.integers(0, 6)), int(rng.integers(0, 6)), int(rng.integers(1, w - 6)), th, step)
             steps = float(rng.choice([0.5, 3.0, 17.25, 64.0, 250.0]))
             rp = abi.RaymarchParams(steps, int(rng.integers(-1, 8)), True)
-            os_lanes = ["4", "8"][case % 2]
-            import os
-            os.environ["TBRM_RAY_LANES"] = os_lanes
-            try:
-                got, (ref, n_ref) = res.raymarch_lit(cam, tile, rp, world), orc.raymarch_lit(cam, tile, rp, world)
-                assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
-                worst = max(worst, float(np.abs(got - ref).max()))
-                assert np.array_equal(got, res.raymarch_lit(cam, tile, abi.RaymarchParams(steps, rp.jitter_frame, False), world)), "skipping changed the image"
-            finally:
-                os.environ.pop("TBRM_RAY_LANES", None)
+            tunables("ray_lanes", [4, 8][case % 2])
+            got, (ref, n_ref) = res.raymarch_lit(cam, tile, rp, world), orc.raymarch_lit(cam, tile, rp, world)
+            assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
+            worst = max(worst, float(np.abs(got - ref).max()))
+            assert np.array_equal(got, res.raymarch_lit(cam, tile, abi.RaymarchParams(steps, rp.jitter_frame, False), world)), "skipping changed the image"
             worst = max(worst, float(np.abs(res.raymarch_intensity(cam, tile, rp, world) - orc.raymarch_intensity(cam, tile, rp, world)).max()))
             mip = int(rng.integers(0, 4))
             worst = max(worst, float(np.abs(res.raymarch_octree(cam, tile, rp, world, mip) - orc.raymarch_octree(cam, tile, rp, world, mip)).max()))

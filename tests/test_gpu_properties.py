@@ -19,16 +19,13 @@ def make(gpu, n, dtype=np.uint16, light_32bit=False, tf="A", window=(0.5, 0.9, T
     return res
 
 
-def test_chunk_kernels_equal_slice_kernel_at_256(gpu, monkeypatch):
+def test_chunk_kernels_equal_slice_kernel_at_256(gpu, tunables):
     """The production kernels (16 slices per launch pair) and the reference-structured kernel (one slice per launch)
     produce the same UNORM8 light volume, bit for bit, on a 256^3 volume with 4 lights and two selective updates."""
     world = S.default_world()
     results = []
     for variant in ("chunk", "slice"):
-        if variant == "slice":
-            monkeypatch.setenv("TBRM_FORCE_SLICE_KERNEL", "1")
-        else:
-            monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+        tunables("force_slice_kernel", 1 if variant == "slice" else 0)
         with make(gpu, 256) as res:
             for i in range(4):
                 res.add_dir_light(S.light(i), True, world)
@@ -177,7 +174,7 @@ def test_light_parallel_reset_on_device(gpu):
             res.close()
 
 
-def test_full_size_properties_at_config3(gpu, monkeypatch):
+def test_full_size_properties_at_config3(gpu, tunables):
     """BASELINE config 3 at full size (512^3 UNORM16, 1024^2 frame, 512 steps), where the oracle would take minutes: the
     production chunk kernels and the reference-structured slice kernel leave the same light volume bit for bit after four
     Adds and a fused Change; empty-space skipping / leaping does not change a single pixel; interleaved row-group tiles
@@ -186,10 +183,7 @@ def test_full_size_properties_at_config3(gpu, monkeypatch):
     new1 = abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1])
     volumes = []
     for variant in ("chunk", "slice"):
-        if variant == "slice":
-            monkeypatch.setenv("TBRM_FORCE_SLICE_KERNEL", "1")
-        else:
-            monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+        tunables("force_slice_kernel", 1 if variant == "slice" else 0)
         with make(gpu, 512) as res:
             for i in range(4):
                 res.add_dir_light(S.light(i), True, world)
@@ -217,7 +211,7 @@ def test_full_size_properties_at_config3(gpu, monkeypatch):
                 assert (lit.astype(np.int32) >= before).all() and (lit != before).any()
                 d = np.abs(after[unsaturated].astype(np.int32) - before[unsaturated])
                 assert d.max() <= 1 and (d != 0).mean() < 1e-3
-    monkeypatch.delenv("TBRM_FORCE_SLICE_KERNEL", raising=False)
+    tunables("force_slice_kernel", 0)
     assert np.array_equal(volumes[0], volumes[1]), f"{np.count_nonzero(volumes[0] != volumes[1])} voxels differ between the chunk and the slice kernels"
 
 

@@ -92,12 +92,12 @@ def test_slab_partitioned_lights_equal_single_handle(gpu, n_slabs, dims, half_re
             h.close()
 
 
-@pytest.mark.parametrize("switch", ["TBRM_NO_OCC_LIST", "TBRM_NO_SPARSE_OCC", "TBRM_CHUNK_STEPS=4"])
-def test_slabs_with_the_diagnostic_kernel_paths(gpu, monkeypatch, switch):
+@pytest.mark.parametrize("switch", ["occ_list=0", "sparse_occ=0", "chunk_steps=4", "tile_h=16", "tile_h=32", "occ_prefetch=0"])
+def test_slabs_with_the_diagnostic_kernel_paths(gpu, tunables, switch):
     """the occlusion launch without the work list / without the empty-block flags (block rows outside the slab's reach are
     then cut inside the kernel), and 4-slice chunks (four times the exchanges)"""
     name, _, value = switch.partition("=")
-    monkeypatch.setenv(name, value or "1")
+    tunables(name, int(value))
     _, _, _, handles = make_handles(3, (72, 56, 64), np.uint16)
     full, parts = handles[0], handles[1:]
     members, fabric, _ = slab_setup(parts, 2)
@@ -274,8 +274,8 @@ def test_frame_marched_slab_by_slab_is_the_plain_frame(gpu, addr, n_slabs, dims,
 
 
 @pytest.fixture(params=["4", "8"])
-def ray_lanes_env(request, monkeypatch):
-    monkeypatch.setenv("TBRM_RAY_LANES", request.param)
+def ray_lanes_env(request, tunables):
+    tunables("ray_lanes", int(request.param))
     return request.param
 
 

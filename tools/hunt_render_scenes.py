@@ -14,7 +14,7 @@ lo, hi = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 for seed in range(lo, hi):
     try:
-        T.test_random_render_scenes_against_oracle(abi, oracle, seed)
+        T.test_random_render_scenes_against_oracle(abi, oracle, seed, abi.set_tunable)
     except Exception as e:
         bad += 1
         print("SEED", seed, "FAILED:", str(e)[:300], flush=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Batched multi-light add (tbrm_add_dir_lights), evidence for the pairing rule: GPU time of every pair of the 8 config lights at 512^3, light by light vs forced into one slice loop (TBRM_LIGHT_BATCHING_FORCE=1), with each pass's cube face and previous-slice tap ranges."""
+"""Batched multi-light add (tbrm_add_dir_lights), evidence for the pairing rule: GPU time of every pair of the 8 config lights at 512^3, light by light vs forced into one slice loop (tunable light_batching = 2), with each pass's cube face and previous-slice tap ranges."""
 import sys, numpy as np, torch, os, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tbraymarcherplugin_amd import abi, synthetic as S
@@ -35,7 +35,7 @@ for i, l in enumerate(lights):
     ps, k = abi.host_light_passes(l, world, dims)
     info.append([(p.face, rng(p.td[0], p.prev_pixel_offset[0]), rng(p.td[1], p.prev_pixel_offset[1])) for p in ps[:k]])
     print(i, f"{ts[i]:.3f} ms", info[-1])
-os.environ["TBRM_LIGHT_BATCHING_FORCE"] = "1"
+abi.set_tunable("light_batching", 2)
 for i, j in itertools.combinations(range(8), 2):
     tb, sched = batch([lights[i], lights[j]])
     pairs = [s for s in sched if s[2] >= 0]
