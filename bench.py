@@ -10,10 +10,14 @@ selective light-volume update; a 5 degree rotation about Z, fused path) followed
 rank's share of the framebuffer, and (N>1) the RCCL all-gather of the tiles. Inputs are resident in HBM before
 the timed region; the initial ResetAllLights (clear + 4 adds) is untimed setup and reported separately.
 
-N>1 (one process per GPU, torch.distributed/RCCL): weak scaling by image tiles — the framebuffer grows to
-~N x 1024^2 pixels at the same field of view, rank r renders every N-th group of 8 rows (load-balanced
-interleave), volumes are replicated, the selective light update is computed redundantly on every GPU (no
-data-path collective), and the only exchange is the final all_gather of the tiles.
+N>1 (one process per GPU, torch.distributed/RCCL; `python bench.py --gpus N` from a bare shell re-launches itself under
+torch.distributed.run): BASELINE config 5 as north_star words it — 512^3 volume, ONE 2048^2 frame tile-partitioned over
+the GPUs, empty-space skipping on, 8 lights, TF-B — i.e. STRONG scaling of a fixed frame: rank r renders every N-th
+group of 8 rows (load-balanced interleave), volumes are replicated, the selective light update is computed redundantly
+on every GPU (no data-path collective: the update of ONE light is one serial slice sweep per axis) and the
+only exchange is the all_gather of the tiles. The line reports the full step, the raymarch-only rate, the same workload
+timed on one GPU in the same run, and the Amdahl ceiling the redundant update puts on the step. `--weak` keeps round
+1's mode (the framebuffer grows to ~N x fb^2 pixels); `--config K` picks another workload.
 
 value = nominal samples of all ranks per step / step time, in Msamples/s (nominal sample = one loop iteration of
 PerformWindowedLitRaymarch that geometry prescribes, independent of early termination and skipping).
@@ -44,12 +48,41 @@ def framebuffer_for(n_gpus, base):
     return w, h
 
 
+def relaunch_under_torchrun(n_gpus):
+    """`python bench.py --gpus N` from a bare shell: one process per GPU through torch.distributed.run on this node
+    (rendezvous on 127.0.0.1, a free port), same arguments. Returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def gpu_ms(torch, stream, fn):
+    """GPU time of whatever fn() enqueues on the library's stream, by HIP events recorded on that stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    fn()
+    e1.record(stream)
+    e1.synchronize()
+    return float(e0.elapsed_time(e1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=3, help="SURVEY.md §8d config number (3 = the metric's config)")
+    ap.add_argument("--config", type=int, default=None,
+                    help="SURVEY.md §8d config number; default: 3 (the metric's config) at N=1, 5 (north_star's scaling config) at N>1")
+    ap.add_argument("--weak", action="store_true", help="N>1: grow the framebuffer with N (~N x fb^2 pixels) instead of splitting one frame")
+    ap.add_argument("--fixed-frame", action="store_true", help="N>1: split ONE frame of the config's size over the GPUs (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--no-skipping", action="store_true")
@@ -66,6 +99,15 @@ def main():
                          "light volumes (tbrm_resources_create_slab); a step = slab-partitioned ChangeDirLight + light-volume halo "
                          "exchange + the frame marched slab by slab (strong scaling: one frame of the config's size)")
     args = ap.parse_args()
+    if args.config is None:
+        args.config = 3 if (args.gpus == 1 or args.slab_resident or args.slab_illumination) else 5
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
+    if os.environ.get("TBRM_BENCH_LAUNCH_CHECK") == "1":  # tests/test_bench_launcher.py: what did the launcher start?
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "world_size": int(os.environ.get("WORLD_SIZE", "1")), "master_addr": os.environ.get("MASTER_ADDR"),
+                          "config": args.config, "gpus": args.gpus}), flush=True)
+        return
 
     import torch
 
@@ -106,7 +148,10 @@ def main():
     n = cfg["n"]
     dims = (n, n, n)
     seed = S.seed_for_config(args.config)
-    fb_w, fb_h = framebuffer_for(n_gpus, cfg["fb"])
+    fixed_frame = n_gpus > 1 and not args.weak
+    fb_w, fb_h = (cfg["fb"], cfg["fb"]) if fixed_frame else framebuffer_for(n_gpus, cfg["fb"])
+    if fb_h % (8 * n_gpus):
+        raise SystemExit(f"framebuffer height {fb_h} does not split into interleaved 8-row groups over {n_gpus} GPUs")
     rows_per_rank = fb_h // n_gpus
     steps = float(cfg["steps"])
 
@@ -126,6 +171,13 @@ def main():
 
     lights = [S.light(i) for i in cfg["lights"]]
     light_dirs = [S.LIGHTS[i][0] for i in cfg["lights"]]
+    lib_stream = torch.cuda.ExternalStream(res.stream(), device=device)  # the library's HIP stream, as torch sees it
+
+    def reset_all_lights():  # ARaymarchVolume::ResetAllLights (RaymarchVolume.cpp:418-451) with the lights' current parameters
+        res.clear_light_volume(0.0)
+        for l in lights:
+            res.add_dir_light(l, True, world)
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if args.light_parallel_reset and dist is not None and not cfg["light_32bit"]:
@@ -155,9 +207,7 @@ def main():
 
         sharding.reset_all_lights_light_parallel(res, lights, world, rank, n_gpus, combine_u8)
     else:
-        res.clear_light_volume(0.0)  # ResetAllLights (RaymarchVolume.cpp:418-451)
-        for l in lights:
-            res.add_dir_light(l, True, world)
+        reset_all_lights()  # first call: includes allocating the propagation scratch and the brick metadata kernels
         res.flush()
     reset_ms = (time.perf_counter() - t0) * 1e3
 
@@ -203,7 +253,7 @@ def main():
 
             slab_fabric = slabs.make_fabric(z_bounds, list(range(n_gpus)), rank, p2p, sync_local=False)
         else:
-            slab_fabric = slabs.dist_fabric(z_bounds, rank, n_gpus)
+            slab_fabric = slabs.dist_fabric(z_bounds, rank, n_gpus, member=slab_member)
 
     def gather_light(full, part):
         if one_gpu_dry_run:
@@ -213,7 +263,6 @@ def main():
         else:
             dist.all_gather_into_tensor(full, part)
 
-    lib_stream = torch.cuda.ExternalStream(res.stream(), device=device)  # the library's HIP stream, as torch sees it
     angle = [0.0] * len(lights)
     ms_illum, ms_ray = [], []
     last = [0]  # buffer index of the most recent frame
@@ -333,6 +382,49 @@ def main():
             print(f"[rank {rank}] light volume sha1: slabs {hg}, unpartitioned replay {hw}; mismatching bytes per 8-slice layer: "
                   f"{ {i: b for i, b in enumerate(bad) if b} }", flush=True)
 
+    # ---- the rest of SURVEY.md 8d's operator sequence, GPU time by HIP events on the library's stream (untimed pass) ----
+    # Every rank runs the same operators, so the replicated light volumes stay identical.
+    ops_ms = {}
+    one_gpu = None
+    if not args.raymarch_only and slab_member is None:
+        res.flush()
+        full_tile = abi.Tile(0, 0, fb_w, fb_h, 1)
+        full = torch.empty((fb_h, fb_w, 4), dtype=torch.float32, device=device)
+        # ResetAllLights with everything allocated (clear + every light added), and the "recompute every frame" case of
+        # APerformanceTest1 (PerformanceTest1.cpp:64-74): reset + frame
+        ops_ms["reset_all_lights"] = min(gpu_ms(torch, lib_stream, reset_all_lights) for _ in range(2))
+        ops_ms["reset_all_lights_plus_frame"] = gpu_ms(torch, lib_stream, lambda: (reset_all_lights(), res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())))
+        # ChangeDirLight whose old and new major axes differ: remove + add (LightingShaders.cpp:192-198). A quarter turn about z
+        # moves the first light's major axis from x to y; the second call turns it back.
+        turned = abi.DirLightParams(S.rotate_z(light_dirs[0], angle[0] + 90.0), lights[0].light_intensity)
+        fb_ms = []
+        for old, new in ((lights[0], turned), (turned, lights[0])):
+            res.change_dir_light(old, new, world)
+            fb_ms.append(res.last_gpu_time_ms(0))
+        ops_ms["change_dir_light_fallback"] = float(np.mean(fb_ms))
+        if n_gpus > 1:
+            # the same workload on ONE GPU, in the same run (every rank does it, rank 0 reports): the whole frame + the update
+            def whole_step(k):
+                li = k % len(lights)
+                angle[li] += 5.0
+                new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li]), lights[li].light_intensity)
+                res.change_dir_light(lights[li], new, world)
+                lights[li] = new
+                res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())
+
+            for k in range(2):
+                whole_step(k)
+            res.flush()
+            k1 = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for k in range(k1):
+                whole_step(2 + k)
+            res.flush()
+            one_ms = (time.perf_counter() - t1) / k1 * 1e3
+            res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())
+            one_ray_ms = res.last_gpu_time_ms(1)
+            one_gpu = {"ms_per_step": round(one_ms, 4), "raymarch_ms": round(one_ray_ms, 4)}
+
     # ---- roofline of the dominant kernel (algorithmic bytes) -------------------------------
     b_data = np.dtype(cfg["dtype"]).itemsize
     b_light = 4 if cfg["light_32bit"] else 1
@@ -349,7 +441,8 @@ def main():
     # summarised by tools/pmc_traffic.py into profiles/): per launch of the raymarch kernel, or summed over the launches
     # one ChangeDirLight makes (tools/pmc_traffic.py "_per_operator_call")
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    traffic_source = None
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if os.path.exists(pmc_path) and args.config == 3 and n_gpus == 1:
         try:
             with open(pmc_path) as f:
@@ -357,42 +450,58 @@ def main():
             per_call = pmc["_per_operator_call"]
             traffic = per_call["raymarch_hbm_bytes"] if dom["kernel"].startswith("k_raymarch") else per_call["change_dir_light_hbm_bytes"]
             traffic = int(traffic)
+            traffic_source = ("profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                              "(tools/measure_round.sh), NOT measured in this run")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic,
+                "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4)}
 
     # ---- CPU baseline: the oracle on this host's cores, rank 0, N=1 only, bounded sample -------------------
-    cpu = None
+    cpu = parity = None
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         moved = abi.DirLightParams(S.rotate_z(light_dirs[0], angle[0] + 5.0), lights[0].light_intensity)
-        cpu = cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, lights[0], moved)
+        cpu, parity = cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, lights[0], moved)
 
     if rank == 0:
         value = total_samples * args.steps / elapsed / 1e6
+        step_ms = elapsed / args.steps * 1e3
+        scaling_note = None
+        if n_gpus > 1 and one_gpu is not None:
+            # what tile-parallel rendering can gain when every GPU repeats the light update (Amdahl): one GPU's step over
+            # (update + 1/N of the frame); and what was measured
+            ceiling = one_gpu["ms_per_step"] / (one_gpu["ms_per_step"] - one_gpu["raymarch_ms"] * (1.0 - 1.0 / n_gpus))
+            scaling_note = {"one_gpu_same_workload": one_gpu, "speedup_vs_one_gpu": round(one_gpu["ms_per_step"] / step_ms, 3),
+                            "raymarch_only_speedup_vs_one_gpu": round(one_gpu["raymarch_ms"] / ray_ms, 3),
+                            "amdahl_ceiling_with_redundant_light_update": round(ceiling, 3)}
         line = {
             "metric": "volume Msamples/s (rays x steps) at 512^3, 1024^2 view; % HBM roofline",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_ms, 4), "higher_is_better": True, "scaling": "strong" if fixed_frame else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"config {args.config}: {n}^3 {np.dtype(cfg['dtype']).name} volume, "
                                    f"{'f32' if cfg['light_32bit'] else 'u8'} light volume, {fb_w}x{fb_h} RGBA f32 framebuffer, "
                                    f"{int(steps)} steps, {len(lights)} dir lights, TF-{cfg['tf']}, 1 selective light update "
                                    f"(ChangeDirLight) + 1 lit raymarch per step",
                        "volume": [n, n, n], "framebuffer": [fb_w, fb_h], "steps": int(steps), "lights": len(lights),
-                       "parallelism": f"image tiles x{n_gpus} (interleaved 8-row groups), volumes replicated"
-                                      if n_gpus > 1 else "single GPU",
+                       "parallelism": (f"image tiles x{n_gpus} (interleaved 8-row groups) of "
+                                       + ("ONE frame (strong scaling)" if fixed_frame else "a framebuffer that grows with N (weak scaling)")
+                                       + ", volumes replicated, light update repeated on every GPU") if n_gpus > 1 else "single GPU",
                        "empty_space_skipping": not args.no_skipping, "raymarch_only": bool(args.raymarch_only),
                        "light_parallel_reset": bool(args.light_parallel_reset and dist is not None),
                        "slab_illumination": slab_member is not None},
             "nominal_samples_per_step": total_samples,
             "gathered_frame_equals_single_gpu_render": gather_ok,
             "slab_light_volume_equals_unpartitioned": slab_ok,
-            "gpu_ms": {"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4), "reset_all_lights_setup": round(reset_ms, 2)},
-            "raymarch_only_msamples_per_s": round(my_samples / (ray_ms * 1e-3) / 1e6, 2),
+            "gpu_ms": dict({"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4)},
+                           **{k: round(v, 4) for k, v in ops_ms.items()},
+                           first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
+            "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
+            "scaling_detail": scaling_note,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "full_size_parity": parity,
         }
         print(json.dumps(line), flush=True)
     res.close()
@@ -451,7 +560,7 @@ def slab_resident_bench(args, torch, dist, S, abi, rank, local_rank, n_gpus, dev
 
         fabric = slabs.make_fabric(z_bounds, list(range(n_gpus)), rank, p2p, sync_local=False)
     else:
-        fabric = slabs.dist_fabric(z_bounds, rank, n_gpus)
+        fabric = slabs.dist_fabric(z_bounds, rank, n_gpus, member=member)
     lights = [S.light(i) for i in cfg["lights"]]
     light_dirs = [S.LIGHTS[i][0] for i in cfg["lights"]]
     angle = [0.0] * len(lights)
@@ -533,10 +642,15 @@ def slab_resident_bench(args, torch, dist, S, abi, rank, local_rank, n_gpus, dev
 
 
 def cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, light_old, light_new):
-    """Times the oracle (oracle/, test infrastructure) on a bounded sample of the same workload — one step: the lit
-    raymarch of every g-th group of 8 rows of the same frame (g chosen so the sample takes about --cpu-seconds), reading
-    the light volume the GPU just produced, and one ChangeDirLight of the whole light volume. The reported rate is the
-    step rate the sample implies: nominal samples of the frame / (frame time extrapolated from the rows + update time)."""
+    """Times the oracle (oracle/, test infrastructure: the checker, never the thing measured as `value`) on a bounded
+    sample of the same workload — one step: the lit raymarch of every g-th group of 8 rows of the same frame (g chosen so
+    that the sample takes about --cpu-seconds; g = 1, the whole frame, at config 3 on the GPU box), reading the light
+    volume the GPU just produced, and one ChangeDirLight of the whole light volume. The reported rate is the step rate the
+    sample implies: nominal samples of the frame / (frame time extrapolated from the rows + update time).
+
+    The same oracle results are the FULL-SIZE PARITY check of the run: the oracle's rows against the GPU's frame of the
+    same light volume (RGBA, tolerance 1e-4) and the oracle's light volume after the ChangeDirLight against the GPU's after
+    the same operator (UNORM8: bit for bit). Returns (cpu_baseline, full_size_parity)."""
     from oracle import oracle
     from tbraymarcherplugin_amd import abi
 
@@ -544,7 +658,9 @@ def cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, 
     orc = oracle.OracleScene(vol, cfg["light_32bit"])
     orc.set_tf_lut(lut)
     orc.set_windowing(win)
+    res.flush()
     orc.light[...] = res.download_light_volume()
+    gpu_frame = res.raymarch_lit(cam, abi.Tile(0, 0, fb_w, fb_h, 1), rp, world)  # the GPU's frame of this very light volume
     cores = oracle.load().orc_num_threads()
     groups = fb_h // 8
     # probe: 2 row groups from the middle of the frame
@@ -559,22 +675,38 @@ def cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, 
         g *= 2
     sample = abi.Tile(0, 0, fb_w, (groups // g) * 8, g)
     t0 = time.perf_counter()
-    _, n_s = orc.raymarch_lit(cam, sample, rp, world)
+    cpu_rows, n_s = orc.raymarch_lit(cam, sample, rp, world)
     dt = time.perf_counter() - t0
     ray_rate = n_s / dt
     frame_s = n_full / ray_rate
+    rows = (np.arange(sample.h) // 8) * 8 * g + np.arange(sample.h) % 8  # framebuffer row of every row of the sample tile
+    rgba_max_abs = float(np.abs(cpu_rows - gpu_frame[rows]).max())
+    parity = {"frame": f"{fb_w}x{fb_h}, every {g}-th 8-row group ({sample.h} rows) of the GPU frame against the oracle",
+              "rgba_max_abs": rgba_max_abs, "rgba_tolerance": 1e-4, "rgba_ok": bool(rgba_max_abs <= 1e-4)}
+    build = "gcc " + oracle.build_flags()
     if args.raymarch_only:
-        return {"value": round(ray_rate / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
-                "sample": f"oracle lit raymarch of every {g}-th 8-row group of the same {fb_w}x{fb_h} frame "
-                          f"({n_s} nominal samples, {dt:.1f} s, OpenMP x{cores}); light volume taken from the GPU"}
+        return ({"value": round(ray_rate / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port", "build": build,
+                 "sample": f"oracle lit raymarch of every {g}-th 8-row group of the same {fb_w}x{fb_h} frame "
+                           f"({n_s} nominal samples, {dt:.1f} s, OpenMP x{cores}); light volume taken from the GPU"}, parity)
     t0 = time.perf_counter()
     orc.change_dir_light(light_old, light_new, world)
     change_s = time.perf_counter() - t0
-    return {"value": round(n_full / (frame_s + change_s) / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port",
-            "sample": f"one step of the oracle, OpenMP x{cores}: ChangeDirLight over the whole light volume ({change_s:.2f} s) + lit "
-                      f"raymarch of every {g}-th 8-row group of the same {fb_w}x{fb_h} frame ({n_s} nominal samples in {dt:.2f} s, "
-                      f"i.e. {frame_s:.2f} s per frame); light volume taken from the GPU",
-            "raymarch_only_msamples_per_s": round(ray_rate / 1e6, 3), "change_dir_light_s": round(change_s, 3)}
+    res.change_dir_light(light_old, light_new, world)  # the same operator on the GPU, from the same light volume
+    gpu_light = res.download_light_volume()
+    if cfg["light_32bit"]:
+        d = float(np.abs(gpu_light - orc.light).max())
+        parity.update({"light_volume": "R32F light volume after one ChangeDirLight", "light_max_abs": d, "light_ok": bool(d <= 1e-5)})
+    else:
+        differ = int(np.count_nonzero(gpu_light != orc.light))
+        parity.update({"light_volume": f"UNORM8 light volume ({gpu_light.size} voxels) after one ChangeDirLight, GPU against oracle",
+                       "light_voxels_differ": differ, "light_ok": differ == 0})
+    res.change_dir_light(light_new, light_old, world)
+    cpu = {"value": round(n_full / (frame_s + change_s) / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port", "build": build,
+           "sample": f"one step of the oracle, OpenMP x{cores}: ChangeDirLight over the whole light volume ({change_s:.2f} s) + lit "
+                     f"raymarch of every {g}-th 8-row group of the same {fb_w}x{fb_h} frame ({n_s} nominal samples in {dt:.2f} s, "
+                     f"i.e. {frame_s:.2f} s per frame); light volume taken from the GPU",
+           "raymarch_only_msamples_per_s": round(ray_rate / 1e6, 3), "change_dir_light_s": round(change_s, 3)}
+    return cpu, parity
 
 
 if __name__ == "__main__":

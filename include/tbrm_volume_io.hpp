@@ -86,7 +86,9 @@ template <typename In, typename Out>
 inline void NormalizeArray(const uint8_t* bytes, long long byte_size, std::vector<uint8_t>& out, float& out_min, float& out_max)
 {
     const long long n = byte_size / (long long) sizeof(In);
-    In lo = std::numeric_limits<In>::max(), hi = std::numeric_limits<In>::min();
+    // (the reference seeds the maximum with numeric_limits<T>::min(), TextureUtilities.h:110 — for float that is the smallest
+    // POSITIVE value, so an all-negative MET_FLOAT volume got a maximum of ~0; lowest() is what was meant: deliberate deviation)
+    In lo = std::numeric_limits<In>::max(), hi = std::numeric_limits<In>::lowest();
     for (long long i = 0; i < n; ++i) {
         In v;
         std::memcpy(&v, bytes + i * sizeof(In), sizeof(In));

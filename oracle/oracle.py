@@ -39,6 +39,15 @@ def build(force=False):
     return LIB_PATH
 
 
+def build_flags():
+    """The CFLAGS the oracle library is compiled with (oracle/Makefile), for bench.py's cpu_baseline record."""
+    with open(os.path.join(HERE, "Makefile")) as f:
+        for line in f:
+            if line.startswith("CFLAGS"):
+                return line.split("=", 1)[1].strip()
+    return ""
+
+
 def load():
     global _lib
     if _lib is not None:

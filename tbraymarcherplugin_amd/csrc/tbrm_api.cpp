@@ -32,8 +32,8 @@ thread_local char g_error[512] = "";
 // ---- tunables (tbrm_internal.h): name, default; initialised from TBRM_<NAME> when the library is loaded ------------
 struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
-    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"tile_h", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1},
-    {"occ_prefetch", 1}, {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_stagger", 0}, {"chain_stamps", 0},
+    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1},
+    {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -359,22 +359,7 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     } while (0)
 
     CREATE_TRY(hipSetDevice(desc->device));
-    {
-        // the handle's FIFO stream at the highest priority, the occlusion prefetch stream at the lowest: when both have
-        // workgroups waiting for a CU, the latency-bound chain goes first
-        int prio_least = 0, prio_greatest = 0;
-        (void) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-        CREATE_TRY(hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, prio_greatest));
-        CREATE_TRY(hipStreamCreateWithPriority(&r->stream2, hipStreamNonBlocking, prio_least));
-        for (int b = 0; b < 2; ++b) {
-            CREATE_TRY(hipEventCreateWithFlags(&r->ev_occ_done[b], hipEventDisableTiming));
-            CREATE_TRY(hipEventCreateWithFlags(&r->ev_chain_done[b], hipEventDisableTiming));
-        }
-        CREATE_TRY(hipEventCreateWithFlags(&r->ev_ready, hipEventDisableTiming));
-        CREATE_TRY(hipMalloc((void**) &r->d_stagger, 2048 * sizeof(uint32_t)));
-        CREATE_TRY(hipMalloc((void**) &r->d_stamps, 4096 * 32 * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemsetAsync(r->d_stagger, 0, 2048 * sizeof(uint32_t), r->stream));
-    }
+    CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     if (hipDeviceGetAttribute(&r->n_cus, hipDeviceAttributeMultiprocessorCount, desc->device) != hipSuccess || r->n_cus <= 0) r->n_cus = 256;
     {
         tbrm_resources::Residency& q = r->res_data;
@@ -412,7 +397,6 @@ int tbrm_resources_destroy(tbrm_resources* r)
 {
     if (!r) return TBRM_OK;
     (void) hipSetDevice(r->desc.device);
-    if (r->stream2) (void) hipStreamSynchronize(r->stream2);
     if (r->stream) (void) hipStreamSynchronize(r->stream);
     (void) hipFree(r->res_data.alloc);
     (void) hipFree(r->d_tf);
@@ -421,11 +405,9 @@ int tbrm_resources_destroy(tbrm_resources* r)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
     delete r->slab_op;
-    for (float* o : r->d_occ) (void) hipFree(o);
-    (void) hipFree(r->d_stagger);
-    (void) hipFree(r->d_stamps);
-    for (uint8_t* z : r->d_occ_zero) (void) hipFree(z);
-    for (uint32_t* l : r->d_occ_list) (void) hipFree(l);
+    (void) hipFree(r->d_occ);
+    (void) hipFree(r->d_occ_zero);
+    (void) hipFree(r->d_occ_list);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     for (uint16_t* o : r->d_octree) (void) hipFree(o);
@@ -436,9 +418,6 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (auto& k : r->ev)
         for (hipEvent_t e : k)
             if (e) (void) hipEventDestroy(e);
-    for (hipEvent_t e : {r->ev_occ_done[0], r->ev_occ_done[1], r->ev_chain_done[0], r->ev_chain_done[1], r->ev_ready})
-        if (e) (void) hipEventDestroy(e);
-    if (r->stream2) (void) hipStreamDestroy(r->stream2);
     if (r->stream) (void) hipStreamDestroy(r->stream);
     delete r;
     return TBRM_OK;
@@ -642,7 +621,6 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
     if (e == TBRM_ERR_UNSUPPORTED)
         return fail(e, "pass %d (axis %d) has no slab-partitioned form: %s", (int) pass, (int) op.a[pass].axis, g_plan_note);
     if (e) return e;
-    if (int e3 = begin_operator(r)) return e3;
     op.current = pass;
     const PassPlan& pl = op.plan;
     out->axis = pl.p.axis;
@@ -663,7 +641,7 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
 int tbrm_slab_pass_chunk(tbrm_resources* r, int32_t chunk)
 {
     if (!r || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight (tbrm_slab_pass_begin first)");
-    PassPlan& pl = r->slab_op->plan;
+    const PassPlan& pl = r->slab_op->plan;
     if (chunk < 0 || chunk >= pl.n_chunks) return fail(TBRM_ERR_INVALID_ARG, "chunk %d of %d", chunk, pl.n_chunks);
     if (int e = bind(r)) return e;
     return enqueue_plan_chunk(r, pl, chunk);
@@ -730,6 +708,7 @@ int tbrm_upload_volume_slices(tbrm_resources* r, int32_t z_begin, int32_t z_coun
     if (code != TBRM_OK) return code;
     HIP_TRY(e1);
     r->has_volume = true;
+    r->octree_valid = false;
     r->minmax_valid = false;
     return TBRM_OK;
 }
@@ -1084,15 +1063,6 @@ int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     for (int k = 0; k < 3; ++k) out[k] = r->launches[k];
-    return TBRM_OK;
-}
-
-// diagnostics (not in tbrm.h): the phase stamps of the last chain launch, 8 per workgroup, up to 4096 workgroups
-extern "C" __attribute__((visibility("default"))) int tbrm_debug_chain_stamps(tbrm_resources* r, unsigned long long* out, int n_workgroups)
-{
-    if (!r || !out || n_workgroups > 4096) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    HIP_TRY(hipMemcpy(out, r->d_stamps, (size_t) n_workgroups * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return TBRM_OK;
 }
 

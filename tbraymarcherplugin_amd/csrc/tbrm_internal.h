@@ -92,11 +92,7 @@ struct ChunkParams {
     int dir;                // +-1
     int j0, n_steps;        // first slice and number of slices of this launch (a span for the occlusion, a chunk for the chain)
     int first_chunk;        // chain: the pass starts here (windows start from the cleared buffers' value)
-    int tile_h;             // chain: tile height (32 or 16; tiles are 32 wide)
-    int stagger;            // chain (experiment): every second workgroup to arrive on a CU starts its slice loop this many x 128 cycles late
-    uint32_t* stagger_counters; // per-CU arrival counters (2048 words)
-    unsigned long long* stamps; // experiment: s_memtime stamps of workgroup phases, [workgroup][8] (null: off)
-    int tiles_x, tiles_y;   // chain: tiles of the slice plane this launch advances (tiles_y rows from tile_row0 on)
+    int tiles_x, tiles_y;   // chain: 32x32 tiles of the slice plane this launch advances (tiles_y rows from tile_row0 on)
     int tile_row0;          // chain: first tile row (slab-partitioned passes run only the rows of their slab; else 0)
     int roi_by0, roi_by1;   // occlusion: block rows [roi_by0, roi_by1) can be read by those tiles; the rest is never computed
     int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch, widened to contain 0
@@ -199,10 +195,9 @@ struct RelayoutParams {
 };
 
 constexpr int kOccSlices = 8;      // slices per occlusion workgroup (kOccDepth in tbrm_light_kernels.hip)
-constexpr int kChunkTile = 32;      // granularity of slab bounds = the largest core tile edge of the chain kernel (pixels)
-constexpr int kChunkTileW = 32;     // core tile width of the chain kernel; its height is ChunkParams::tile_h (32 or 16)
-constexpr int kDefaultTileH = 32;   // the planner's tile height when the tile_h tunable is 0
-constexpr int kChunkMaxGrowth = 32; // steps * tap range of a chunk (how far its windows reach beyond the tile) stays within this
+constexpr int kChunkTile = 32;      // core tile edge of the chunked propagation kernel (pixels)
+constexpr int kChunkThreads = 1024;
+constexpr int kChunkMaxHull = 64;   // T + steps * growth must stay within this
 
 // Process-wide tunables (A/B switches of the measurements in DESIGN.md and of the parity tests). Each starts from the
 // environment variable TBRM_<NAME> read ONCE when the library is loaded; afterwards tbrm_set_tunable changes it. No launch
@@ -210,16 +205,12 @@ constexpr int kChunkMaxGrowth = 32; // steps * tap range of a chunk (how far its
 enum Tunable : int {
     TUNE_FORCE_SLICE_KERNEL, // 1: every axis pass takes the reference's one-slice-per-launch structure (k_propagate_slice)
     TUNE_CHUNK_STEPS,        // > 0: only this chunk length is tried (16 / 8 / 4 / 2)
-    TUNE_TILE_H,             // chain tile height: 32, 16, or 0 = the planner's choice
     TUNE_OCC_SLICES,         // slices per occlusion span (0: default)
     TUNE_SPARSE_OCC,         // 0: occlusion blocks that can only see empty bricks are computed like the others
     TUNE_OCC_LIST,           // 0: live occlusion blocks keep their grid position instead of being dealt from a work list
-    TUNE_OCC_PREFETCH,       // 0: the occlusion of a span runs on the handle's main stream, in front of the span's chain
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
-    TUNE_CHAIN_STAGGER,      // experiment: see ChunkParams::stagger
-    TUNE_CHAIN_STAMPS,       // experiment: 1 = the chain kernel records s_memtime stamps of its phases (tbrm_debug_chain_stamps)
     TUNE_COUNT
 };
 int tune(Tunable t);

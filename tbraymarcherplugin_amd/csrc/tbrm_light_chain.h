@@ -8,24 +8,21 @@
 
 namespace tbrm {
 
-// Window geometry of one chain workgroup. A tile keeps its 32 x TY pixels (TY = 16 or 32) for the whole chunk; with r
-// slices still to go its window is [r*lox, 32 + r*hix) x [r*loy, TY + r*hiy) in tile coordinates (lox <= 0 <= hix: the
-// range of the previous-slice taps, widened to contain 0), i.e. it grows towards the light by the tap range per
-// remaining slice.
+// Window geometry of one chain workgroup. A tile keeps its 32x32 pixels for the whole chunk; with r slices still to
+// go its window is [r*lox, T + r*hix) x [r*loy, T + r*hiy) in tile coordinates (lox <= 0 <= hix: the range of the
+// previous-slice taps, widened to contain 0), i.e. it grows towards the light by the tap range per remaining slice.
 struct ChunkGeom {
     int n;                  // steps in this chunk
     int lox, hix, loy, hiy;
-    int TY;                 // tile height
     int HX, HY;             // hull = window at r = n (the input state)
-    int RS, RR;             // LDS plane row stride in floats / rows (RS == 0: the hull does not fit any instantiation)
+    int RS;                 // LDS plane edge / row stride in floats (0: the hull does not fit any instantiation)
     int padx, pady;         // plane coordinates of tile pixel (0,0)
     int lv_layers;          // 8-slice brick layers of the light volume the chunk touches
     int lv_layer0;          // first of them
 };
 
-// LDS planes are RS floats wide (RS an odd multiple of 8: bank-conflict-free 8x8 patches, see k_light_chain) and RR rows
-// high. 32 x 32 tiles use square planes (RR = RS in {40, 56, 72}); 32 x 16 tiles RS in {40, 56} and RR in {24, 32}.
-__host__ __device__ constexpr int chain_plane_elems(int RS, int RR) { return RS * RR + 8; } // + slack for inactive slots' reads
+// LDS planes are RS x RS floats, RS an odd multiple of 8 (bank-conflict-free 8x8 patches, see k_light_chain)
+__host__ __device__ constexpr int chain_plane_elems(int RS) { return RS * RS + 8; } // + slack for inactive slots' reads
 __host__ __device__ constexpr int chain_row_stride(int hull) { return hull <= 40 ? 40 : (hull <= 56 ? 56 : (hull <= 72 ? 72 : 0)); }
 
 __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
@@ -33,17 +30,9 @@ __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
     ChunkGeom g;
     g.n = p.n_steps;
     g.lox = p.dx_lo; g.hix = p.dx_hi; g.loy = p.dy_lo; g.hiy = p.dy_hi;
-    g.TY = p.tile_h;
-    g.HX = kChunkTileW + g.n * (g.hix - g.lox);
-    g.HY = g.TY + g.n * (g.hiy - g.loy);
-    if (g.TY == kChunkTileW) {
-        g.RS = chain_row_stride(g.HX > g.HY ? g.HX : g.HY);
-        g.RR = g.RS;
-    } else {
-        g.RS = g.HX <= 56 ? chain_row_stride(g.HX) : 0;
-        g.RR = g.HY <= 24 ? 24 : (g.HY <= 32 ? 32 : 0);
-        if (g.RR == 0) g.RS = 0;
-    }
+    g.HX = kChunkTile + g.n * (g.hix - g.lox);
+    g.HY = kChunkTile + g.n * (g.hiy - g.loy);
+    g.RS = chain_row_stride(g.HX > g.HY ? g.HX : g.HY);
     g.padx = -g.n * g.lox;
     g.pady = -g.n * g.loy;
     const int ja = p.j0, jb = p.j0 + (g.n - 1) * p.dir;
@@ -53,16 +42,7 @@ __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
     return g;
 }
 
-constexpr int kOccRing = 3; // slices the occlusion operands are staged ahead of their use (k_light_chain)
-
-// k_light_chain2 (32 x 16 tiles): depth of the occlusion ring — as deep as a workgroup that shares its CU with a second
-// one (78 KB) allows, 3 to 6 slices
-__host__ __device__ constexpr int chain2_ring(int RS, int RR, int NS)
-{
-    for (int r = 6; r > 3; --r)
-        if ((2 + r) * NS * chain_plane_elems(RS, RR) * 4 + 12 * 1024 <= 78 * 1024) return r;
-    return 3;
-}
+constexpr int kOccRing = 3; // slices the occlusion operands are staged ahead of their use
 
 // Workgroup barrier for LDS traffic only. __syncthreads() carries a workgroup-scope fence, which the compiler has to
 // lower to s_waitcnt vmcnt(0): inside the chain's slice loop that would drain the asynchronous global->LDS copies

@@ -126,26 +126,15 @@ hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t 
 // a chunk of slices per launch pair
 
 // LDS bytes of a chain workgroup; 1 GiB when no instantiated kernel shape holds the chunk's hull
-// (tbrm_light_chain.hip launch_chain3 lists the shapes)
+// (tbrm_light_chain.hip launch_chain3 lists the shapes: Change runs RS 40/56 — two streams of 72 x 72 planes exceed the
+// LDS — Add RS 40/56/72)
 size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
-    const size_t none = (size_t) 1 << 30;
-    if (g.RS == 0) return none;
+    if (g.RS == 0 || (change && g.RS > 56)) return (size_t) 1 << 30;
     const int ns = change ? 2 : 1;
-    if (g.TY == 16) { // k_light_chain2: 512 halo lanes take the hull's pixels outside the tile, at most 3 each
-        const int kh = (g.HX * g.HY - 512 + 511) / 512;
-        const int kh_max = (g.RS == 40 && g.RR == 24) ? 1 : ((g.RS == 56 && g.RR == 32) ? 3 : 2);
-        if (kh > kh_max) return none;
-        size_t total = (size_t) ns * (2 + chain2_ring(g.RS, g.RR, ns)) * chain_plane_elems(g.RS, g.RR) * 4 + 4096; // ring + windows + slack
-        if (lv_fmt == FMT_U8) total += (size_t) 8 * g.lv_layers * 512;                                             // light-volume tile
-        return total;
-    }
-    const int threads = kChunkTileW * g.TY;
-    const int kh = (g.HX * g.HY - threads + threads - 1) / threads;
-    if ((change && g.RS > 56) || kh > 3) return none;
-    size_t total = (size_t) ns * (2 + kOccRing) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged occlusion ring
-    if (lv_fmt == FMT_U8) total += (size_t) 4 * (g.TY / 8) * g.lv_layers * 512;       // light-volume tile
+    size_t total = (size_t) ns * (2 + kOccRing) * chain_plane_elems(g.RS) * 4; // windows + staged occlusion ring
+    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;             // light-volume tile
     return total;
 }
 

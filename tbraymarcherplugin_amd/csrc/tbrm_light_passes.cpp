@@ -62,35 +62,8 @@ void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt)
 thread_local const char* g_plan_note = "";
 int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; }
 
-// Tile height and chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover.
-// false: the chunk kernels decline.
-//
-// Per tile height the longest of 16/8/4/2 slices whose window (tile + steps * growth) has an instantiated kernel shape
-// and fits in LDS. 32 x 16 tiles (512 threads) are sized so that two workgroups share a CU — the chain is bound by the
-// lockstep of one workgroup's LDS phase, arithmetic phase and barrier, and a second, independent workgroup on the same CU
-// fills those stalls — so for them a chunk that leaves room for a second workgroup is preferred to a longer one that
-// does not.
-static int fit_steps(const tbrm_resources* r, ChunkParams p, bool two, int TY, int g, int D_pass, int tiles)
-{
-    p.tile_h = TY;
-    const int per_cu = TY == 16 ? 2 : 1;
-    // With more tiles than the CUs hold at once every CU works through several per launch: the per-chunk overhead is paid
-    // once per round of tiles while the halo work of a long chunk (windows 1.56x the tile on average at 16 slices, 1.27x
-    // at 8) is paid by every tile, and 8-slice chunks win — measured for a fused Change with 32 x 32 tiles: 640^3
-    // 5.2 -> 4.9 ms, 1024^3 16.7 -> 15.6, 1536^3 55.3 -> 49.7; at 512^3 (one tile per CU) 16 and 8 tie.
-    const bool many_tiles = tiles > r->n_cus * per_cu;
-    const size_t shared_cu = (size_t) 78 * 1024, whole_cu = (size_t) 156 * 1024;
-    for (size_t budget : {TY == 16 ? shared_cu : whole_cu, whole_cu})
-        for (int cand : {16, 8, 4, 2}) { // 2: steep secondary passes (taps up to 16 texels from the pixel), still 5x the slice kernel
-            if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
-            if (cand == 16 && many_tiles && chunk_steps_override() == 0) continue;
-            p.n_steps = std::min(cand, D_pass);
-            p.j0 = 0; // aligned chunks: one light-volume brick layer when the chunk is 8 slices or shorter
-            if (cand * g <= kChunkMaxGrowth && chunk_lds_bytes(p, two, r->lv_fmt) <= budget) return cand;
-        }
-    return 0;
-}
-
+// Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
+// 16/8/4/2 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
 bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit)
 {
     g_plan_note = "";
@@ -104,25 +77,28 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         tx.lo = std::min(tx.lo, rx.lo); tx.hi = std::max(tx.hi, rx.hi);
         ty.lo = std::min(ty.lo, ry.lo); ty.hi = std::max(ty.hi, ry.hi);
     }
-    // Unsheared windows: a tile keeps its pixels for the whole chunk and its window grows towards the light by the tap
-    // range per remaining slice (the range is widened to contain 0 so the window always covers the tile).
+    // Unsheared windows: a tile keeps its 32x32 pixels for the whole chunk and its window grows towards the light by
+    // the tap range per remaining slice (the range is widened to contain 0 so the window always covers the tile).
     tx.lo = std::min(tx.lo, 0); tx.hi = std::max(tx.hi, 0);
     ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
     ChunkParams p{};
     p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
     p.dir = pa.dir;
+    p.j0 = pa.start;
     const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
     fit = ChunkFit{};
-    const int forced = tune(TUNE_TILE_H);
-    int best_ty = 0, best_m = 0;
-    for (int TY : {kDefaultTileH, kDefaultTileH == 16 ? 32 : 16}) {
-        if (forced != 0 && forced != TY) continue;
-        const int m = fit_steps(r, p, pr != nullptr, TY, g, D_pass, ceil_div(W, kChunkTileW) * ceil_div(H, TY));
-        if (m > best_m && (best_m == 0 || m >= 4 * best_m)) { best_m = m; best_ty = TY; } // the other height only when the default runs very short chunks
+    // With more tiles than CUs every CU works through several tiles per launch: the per-chunk overhead is paid once per
+    // round of tiles while the halo work of a long chunk (windows 1.56x the tile on average at 16 slices, 1.27x at 8) is
+    // paid by every tile, and 8-slice chunks win — measured for a fused Change: 640^3 5.2 -> 4.9 ms, 1024^3 16.7 -> 15.6,
+    // 1536^3 55.3 -> 49.7; at 512^3 (one tile per CU) 16 and 8 tie and 16 halves the launches.
+    const bool many_tiles = ceil_div(W, kChunkTile) * ceil_div(H, kChunkTile) > r->n_cus;
+    for (int cand : {16, 8, 4, 2}) { // 2: steep secondary passes (taps up to 16 texels from the pixel), still 5x the slice kernel
+        if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
+        if (cand == 16 && many_tiles && chunk_steps_override() == 0) continue;
+        p.n_steps = std::min(cand, D_pass);
+        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, pr != nullptr, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
     }
-    if (best_m <= 0) return declined("the previous-slice taps reach too far for a 2-slice chunk"), false;
-    fit.M = best_m;
-    fit.TY = best_ty;
+    if (fit.M <= 0) return declined("the previous-slice taps reach too far for a 2-slice chunk"), false;
     fit.tx = tx;
     fit.ty = ty;
     return true;
@@ -257,13 +233,8 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     plan.D = D_pass;
     plan.start = pa.start;
     plan.dir = pa.dir;
-    const int TY = fit.TY;
-    p.tile_h = TY;
-    p.stagger = tune(TUNE_CHAIN_STAGGER);
-    p.stagger_counters = r->d_stagger;
-    p.stamps = tune(TUNE_CHAIN_STAMPS) ? r->d_stamps : nullptr;
-    p.tiles_x = ceil_div(W, kChunkTileW);
-    p.tiles_y = ceil_div(H, TY);
+    p.tiles_x = ceil_div(W, kChunkTile);
+    p.tiles_y = ceil_div(H, kChunkTile);
     p.tile_row0 = 0;
     p.occ_blocks_x = ceil_div(W, 16);
     p.occ_blocks_y = ceil_div(H, 16);
@@ -283,8 +254,8 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
             plan.pass_begins_here = plan.first_chunk_of_pass == 0;
         } else { // z is the plane's row axis: the slab's tile rows, and the occlusion of every row their windows can reach
             plan.lateral = true;
-            p.tile_row0 = slab->z_begin / TY;
-            p.tiles_y = (slab->z_end - slab->z_begin) / TY;
+            p.tile_row0 = slab->z_begin / kChunkTile;
+            p.tiles_y = (slab->z_end - slab->z_begin) / kChunkTile;
             p.roi_by0 = std::max(slab->z_begin - kChunkTile, 0) / 16;
             p.roi_by1 = std::min(ceil_div(slab->z_end + kChunkTile, 16), p.occ_blocks_y);
         }
@@ -324,26 +295,19 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     if (tune(TUNE_OCC_SLICES) > 0) S = tune(TUNE_OCC_SLICES);
     S = std::max(M, (S / M) * M);
 
-    // occlusion scratch, allocated on first use, twice (the stack of span s+1 is filled while the chain reads that of span
-    // s): ONE allocation each = [page of ones | guard][stream a: S planes][guard][stream r: S planes][guard], so that the
-    // chain addresses every copy source as base + 32-bit offset
+    // occlusion scratch, allocated on first use: ONE allocation = [page of ones | guard][stream a: S planes][guard]
+    // [stream r: S planes][guard], so that the chain addresses every copy source as base + 32-bit offset
     size_t occ_elems = (size_t) S * W * H;
     while (S > M && (2 * occ_elems + 3 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) { S -= M; occ_elems = (size_t) S * W * H; }
     const size_t occ_total = 2 * occ_elems + 3 * kPlaneGuard;
     if (occ_total * sizeof(float) >= ((size_t) 1 << 32)) return declined("slice plane too large for the occlusion scratch");
     if (occ_elems > r->occ_elems) {
-        HIP_TRY(hipStreamSynchronize(r->stream2));
         HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->d_occ);
+        r->d_occ = nullptr;
         r->occ_elems = 0;
-        for (int b = 0; b < 2; ++b) {
-            (void) hipFree(r->d_occ[b]);
-            r->d_occ[b] = nullptr;
-        }
-        for (int b = 0; b < 2; ++b) {
-            HIP_TRY(hipMalloc((void**) &r->d_occ[b], occ_total * sizeof(float)));
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_occ[b], 0x3f800000, 1024, r->stream)); // the page of ones
-        }
-        HIP_TRY(hipStreamSynchronize(r->stream)); // the prefetch stream reads the pages without an event of its own
+        HIP_TRY(hipMalloc((void**) &r->d_occ, occ_total * sizeof(float)));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_occ, 0x3f800000, 1024, r->stream)); // the page of ones
         r->occ_elems = occ_elems;
     }
     plan.S = S;
@@ -353,7 +317,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
     // workgroup of the whole pass and per span the ascending list of the workgroups with work, computed in front of the
-    // pass's first occlusion launch (issue_span)
+    // pass's first occlusion launch (enqueue_plan_chunk)
     plan.sparse = tune(TUNE_SPARSE_OCC) != 0;
     plan.work_list = plan.sparse && tune(TUNE_OCC_LIST) != 0;
     p.occ_groups = ceil_div(S, kOccSlices);
@@ -364,19 +328,14 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
         if (int e = ensure_skipping(r)) return e;
         const size_t zbytes = plan.flags_per_span * plan.n_spans;
         if (zbytes > r->occ_zero_bytes) {
-            HIP_TRY(hipStreamSynchronize(r->stream2));
             HIP_TRY(hipStreamSynchronize(r->stream));
+            (void) hipFree(r->d_occ_zero);
+            (void) hipFree(r->d_occ_list);
+            r->d_occ_zero = nullptr;
+            r->d_occ_list = nullptr;
             r->occ_zero_bytes = 0;
-            for (int b = 0; b < 2; ++b) {
-                (void) hipFree(r->d_occ_zero[b]);
-                (void) hipFree(r->d_occ_list[b]);
-                r->d_occ_zero[b] = nullptr;
-                r->d_occ_list[b] = nullptr;
-            }
-            for (int b = 0; b < 2; ++b) {
-                HIP_TRY(hipMalloc((void**) &r->d_occ_zero[b], zbytes));
-                HIP_TRY(hipMalloc((void**) &r->d_occ_list[b], zbytes * sizeof(uint32_t) + 4096 * sizeof(int))); // lists + counts
-            }
+            HIP_TRY(hipMalloc((void**) &r->d_occ_zero, zbytes));
+            HIP_TRY(hipMalloc((void**) &r->d_occ_list, zbytes * sizeof(uint32_t) + 4096 * sizeof(int))); // lists + counts
             r->occ_zero_bytes = zbytes;
         }
         p.empty_bits = r->d_empty;
@@ -384,25 +343,12 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
         p.pass_slices = D;
         p.chunk_slices = S;
     }
-    plan.slot = (int) (r->pass_seq++ & 1);
     return TBRM_OK;
 }
 
 // The plane holding the propagated light of stream `si` (0: a, 1: r) BEFORE chunk `boundary` (boundary = n_chunks: after
 // the last one): chunk c reads the planes of parity c & 1 and writes the others.
 float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_plane[2 * si + (boundary & 1)] + kPlaneGuard; }
-
-static hipStream_t occlusion_stream(const tbrm_resources* r) { return tune(TUNE_OCC_PREFETCH) != 0 ? r->stream2 : r->stream; }
-
-// Start of a light operator: whatever the prefetch stream launches for it has to see everything enqueued on the
-// handle's stream so far (volume upload, transfer function, brick metadata, the previous operator's chain).
-int begin_operator(tbrm_resources* r)
-{
-    if (occlusion_stream(r) == r->stream) return TBRM_OK;
-    HIP_TRY(hipEventRecord(r->ev_ready, r->stream));
-    HIP_TRY(hipStreamWaitEvent(r->stream2, r->ev_ready, 0));
-    return TBRM_OK;
-}
 
 struct SpanRange { int s0, sn, c0, c1; bool sparse; };
 static SpanRange span_range(const PassPlan& plan, int sp)
@@ -421,46 +367,9 @@ static SpanRange span_range(const PassPlan& plan, int sp)
     return q;
 }
 
-// Enqueues the occlusion of span sp (spans are issued in order; the pass's flags and work lists go in front of span 0):
-// on the prefetch stream behind the chain that last read the stack it fills, or (prefetch off) on the handle's stream.
-static int issue_span(tbrm_resources* r, PassPlan& plan, int sp)
-{
-    if (sp != plan.issued) return fail(TBRM_ERR_INVALID_ARG, "occlusion spans are issued in order (span %d after %d)", sp, plan.issued);
-    hipStream_t st = occlusion_stream(r);
-    const uint64_t seq = r->occ_seq++;
-    if (sp == 0) plan.seq0 = seq;
-    else if (seq != plan.seq0 + (uint64_t) sp) return fail(TBRM_ERR_INVALID_ARG, "another pass's occlusion was issued inside this pass");
-    const int buf = (int) (seq & 1);
-    if (st != r->stream) HIP_TRY(hipStreamWaitEvent(st, r->ev_chain_done[buf], 0)); // a never-recorded event does not block
-    ChunkParams p = plan.p;
-    const int slot = plan.slot;
-    int* const counts = (int*) (r->d_occ_list[slot] + r->occ_zero_bytes);
-    if (sp == 0 && plan.sparse) {
-        p.occ_flags_out = r->d_occ_zero[slot];
-        p.occ_list_out = plan.work_list ? r->d_occ_list[slot] : nullptr;
-        p.occ_count_out = counts;
-        HIP_TRY(launch_occ_flags(p, plan.mode, plan.n_spans, st));
-    }
-    const SpanRange q = span_range(plan, sp);
-    p.j0 = plan.start + q.s0 * plan.dir;
-    p.n_steps = q.sn;
-    p.occ_base = r->d_occ[buf];
-    p.a.occ_next = r->d_occ[buf] + plan.occ_off_a;
-    p.r.occ_next = r->d_occ[buf] + plan.occ_off_r;
-    p.occ_flags = nullptr;
-    p.occ_list = q.sparse && plan.work_list ? r->d_occ_list[slot] + (size_t) sp * plan.flags_per_span : nullptr;
-    p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
-    if (q.sparse && !plan.work_list) p.occ_flags = r->d_occ_zero[slot] + (size_t) sp * plan.flags_per_span;
-    HIP_TRY(launch_light_occlusion(p, plan.mode, st));
-    if (st != r->stream) HIP_TRY(hipEventRecord(r->ev_occ_done[buf], st));
-    plan.issued = sp + 1;
-    return TBRM_OK;
-}
-
-// Enqueues chunk c of the plan. At the first chunk of a span: the span's occlusion if it is not on its way yet, then the
-// NEXT span's occlusion on the prefetch stream (the next pass's first span after this pass's last: `next`, may be null),
-// so that it is computed while the chain works through this span.
-int enqueue_plan_chunk(tbrm_resources* r, PassPlan& plan, int c, PassPlan* next)
+// Enqueues chunk c of the plan: in front of the pass's first chunk the empty-block flags and work lists of the whole
+// pass, in front of a span's first chunk the occlusion of the span, then the chain.
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
 {
     if (plan.sliced) {
         PropParams sp = plan.slice_params;
@@ -484,38 +393,39 @@ int enqueue_plan_chunk(tbrm_resources* r, PassPlan& plan, int c, PassPlan* next)
     const int M = plan.M, D = plan.D, W = p.W, H = p.H;
     const int sp = (c * M) / plan.S;
     const SpanRange q = span_range(plan, sp);
-    const bool prefetch = occlusion_stream(r) != r->stream;
-    if (c == q.c0) {
-        if (plan.issued <= sp)
-            if (int e = issue_span(r, plan, sp)) return e;
-        if (prefetch) {
-            if (sp + 1 < plan.n_spans) {
-                if (plan.issued == sp + 1)
-                    if (int e = issue_span(r, plan, sp + 1)) return e;
-            } else if (next && !next->sliced && next->issued == 0) {
-                if (int e = issue_span(r, *next, 0)) return e;
-            }
-        }
+    int* const counts = (int*) (r->d_occ_list + r->occ_zero_bytes);
+    p.occ_base = r->d_occ;
+    p.a.occ_next = r->d_occ + plan.occ_off_a;
+    p.r.occ_next = r->d_occ + plan.occ_off_r;
+    if (c == 0 && plan.sparse) {
+        p.occ_flags_out = r->d_occ_zero;
+        p.occ_list_out = plan.work_list ? r->d_occ_list : nullptr;
+        p.occ_count_out = counts;
+        HIP_TRY(launch_occ_flags(p, plan.mode, plan.n_spans, r->stream));
     }
-    if (plan.issued <= sp) return fail(TBRM_ERR_INVALID_ARG, "chunk %d enqueued before the first chunk of its span", c);
-    const int buf = (int) ((plan.seq0 + (uint64_t) sp) & 1);
-    if (c == q.c0 && prefetch) HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_occ_done[buf], 0));
+    if (c == q.c0) { // occlusion of the span: fills {a,r}.occ_next with sn planes
+        p.j0 = plan.start + q.s0 * plan.dir;
+        p.n_steps = q.sn;
+        p.occ_flags = nullptr;
+        p.occ_list = q.sparse && plan.work_list ? r->d_occ_list + (size_t) sp * plan.flags_per_span : nullptr;
+        p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
+        if (q.sparse && !plan.work_list) p.occ_flags = r->d_occ_zero + (size_t) sp * plan.flags_per_span;
+        HIP_TRY(launch_light_occlusion(p, plan.mode, r->stream));
+    }
     const int k0 = c * M - q.s0; // first slice of the chunk within the span
     p.n_steps = std::min(M, D - c * M);
     p.j0 = plan.start + c * M * plan.dir;
     p.first_chunk = c == 0 && plan.pass_begins_here;
     p.a.plane_in = plan_plane(r, c, 0); p.a.plane_out = plan_plane(r, c + 1, 0);
     p.r.plane_in = plan_plane(r, c, 1); p.r.plane_out = plan_plane(r, c + 1, 1);
-    p.occ_base = r->d_occ[buf];
     p.a.occ_off = (uint32_t) (plan.occ_off_a + (size_t) k0 * W * H);
     p.r.occ_off = (uint32_t) (plan.occ_off_r + (size_t) k0 * W * H);
     p.occ_phase = k0 % kOccSlices;
     p.occ_list = nullptr;
     p.occ_count = nullptr;
-    p.occ_flags = q.sparse ? r->d_occ_zero[plan.slot] + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
+    p.occ_flags = q.sparse ? r->d_occ_zero + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
     HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
     ++r->launches[0];
-    if (c == q.c1 - 1 && prefetch) HIP_TRY(hipEventRecord(r->ev_chain_done[buf], r->stream));
     return TBRM_OK;
 }
 
@@ -565,9 +475,8 @@ struct PassSpec {
     float b_added = 0.0f, b_added2 = 0.0f;
 };
 
-// Runs the axis passes of one operator in order. Every pass is planned before anything is enqueued — a pass the chunk
-// kernels decline takes the one-slice-per-launch path, any other planning failure leaves the light volume untouched — and
-// the plans are then run back to back, each prefetching the first occlusion span of the next.
+// Runs the axis passes of one operator in order. Every pass is planned before anything is enqueued: a pass the chunk
+// kernels decline takes the one-slice-per-launch path, any other planning failure leaves the light volume untouched.
 int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs)
 {
     std::vector<PassPlan> plans;
@@ -591,7 +500,6 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         plans.push_back(plan);
         chunked.push_back(e == TBRM_OK ? 1 : 0);
     }
-    if (int e = begin_operator(r)) return e;
     for (size_t i = 0; i < specs.size(); ++i) {
         const PassSpec& q = specs[i];
         if (!chunked[i]) {
@@ -600,11 +508,8 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             if (int e = enqueue_pass_sliced(r, p, q.a, q.two ? &q.r : nullptr)) return e;
             continue;
         }
-        PassPlan* next = nullptr;
-        for (size_t k = i + 1; k < specs.size() && !next; ++k)
-            if (chunked[k]) next = &plans[k];
         for (int c = 0; c < plans[i].n_chunks; ++c)
-            if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e;
+            if (int e = enqueue_plan_chunk(r, plans[i], c)) return e;
     }
     return TBRM_OK;
 }

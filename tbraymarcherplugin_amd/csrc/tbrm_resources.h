@@ -33,15 +33,6 @@ struct tbrm_resources {
     int lv_fmt = tbrm::FMT_U8;
     int n_cus = 256;               // compute units of the device (chunk length heuristics)
     hipStream_t stream = nullptr;
-    // Occlusion prefetch: the occlusion of span s+1 runs on a second, low-priority stream while the chain
-    // works through span s on `stream`. Two occlusion stacks alternate (span number & 1); ev_occ_done[b] is recorded on
-    // stream2 behind the launch that filled stack b, ev_chain_done[b] on `stream` behind the last chain chunk that read it.
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_occ_done[2]{}, ev_chain_done[2]{}, ev_ready = nullptr;
-    uint64_t occ_seq = 0;          // occlusion spans issued so far (stack = seq & 1)
-    uint64_t pass_seq = 0;         // chunked axis passes planned so far (flag / work-list slot = seq & 1)
-    uint32_t* d_stagger = nullptr; // experiment (chain_stagger tunable): per-CU arrival counters
-    unsigned long long* d_stamps = nullptr; // experiment (chain_stamps tunable): phase stamps of the LAST chain launch, [workgroup][8]
 
     void* d_data = nullptr;        // bricked data volume; slab-resident handles: rebased so that global brick offsets apply
     size_t data_bytes = 0;
@@ -70,10 +61,10 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
-    float* d_occ[2]{};             // chunk kernel: page of ones + the occlusion plane stacks of a span, twice (allocated on first use)
-    size_t occ_elems = 0;          // floats per stream and stack
-    uint8_t* d_occ_zero[2]{};      // empty-block flags of a whole pass, one buffer per pass slot
-    uint32_t* d_occ_list[2]{};     // work lists of a pass (one uint32 per flag) followed by 4096 per-span counts, per pass slot
+    float* d_occ = nullptr;        // chunk kernel: page of ones + the occlusion plane stacks of a span (allocated on first use)
+    size_t occ_elems = 0;          // floats per stream
+    uint8_t* d_occ_zero = nullptr; // empty-block flags of a whole pass
+    uint32_t* d_occ_list = nullptr; // work lists of the pass (one uint32 per flag) followed by 4096 per-span counts
     size_t occ_zero_bytes = 0;
 
     // empty-space-skipping metadata
@@ -125,7 +116,7 @@ int ensure_skipping(tbrm_resources* r);
 // kernel's own fp32 sequence (texel_split of ((c+0.5)/size + offset)); hi includes the +1 tap.
 struct TapRange { int lo = 0, hi = 0; bool ok = false; };
 
-struct ChunkFit { int M = 0, TY = 0; TapRange tx, ty; };
+struct ChunkFit { int M = 0; TapRange tx, ty; };
 
 // One axis pass (Add: stream a only; Change: a = added, r = removed) as a plan: everything that is constant over the
 // pass, worked out once, and the chunks then enqueued one by one (plan_pass / enqueue_plan_chunk). A single-GPU pass
@@ -142,9 +133,6 @@ struct PassPlan {
     bool pass_begins_here = true; // chunk 0 starts from the cleared buffers' value (else from imported planes)
     bool sparse = false, work_list = false;
     size_t flags_per_group = 0, flags_per_span = 0, occ_off_a = 0, occ_off_r = 0;
-    int slot = 0;               // which of the handle's two flag / work-list buffers this pass uses
-    int issued = 0;             // spans whose occlusion has been enqueued (in order, possibly one ahead of the chain)
-    uint64_t seq0 = 0;          // tbrm_resources::occ_seq of span 0 (span s fills occlusion stack (seq0 + s) & 1)
     // slab-partitioned passes
     bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
     int first_chunk_of_pass = 0, chunks_of_pass = 0;
@@ -162,8 +150,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
-int begin_operator(tbrm_resources* r); // orders the prefetch stream behind everything enqueued so far
-int enqueue_plan_chunk(tbrm_resources* r, PassPlan& plan, int c, PassPlan* next = nullptr);
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c);
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
 int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
                       int32_t* schedule, int32_t* n_entries);

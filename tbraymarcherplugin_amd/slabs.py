@@ -319,18 +319,30 @@ def gather_light_volume(members, fabric, all_gather_into=None):
     torch.cuda.synchronize()
 
 
-def dist_fabric(z_bounds, rank, world_size, group=None):
+def dist_fabric(z_bounds, rank, world_size, group=None, member=None):
     """One slab per process: slab k lives on rank k, planes move with torch.distributed point-to-point operations (RCCL
-    over xGMI on GPUs — run the driver inside `member.stream_context()` so that they are ordered with the library's
-    stream without a host synchronisation; gloo on CPU tensors in the tests)."""
+    over xGMI on GPUs; gloo on CPU tensors in the tests).
+
+    Device tensors alias buffers that the library's kernels read and write on the HANDLE's HIP stream, so the
+    point-to-point operations have to be enqueued relative to that stream: every batch is issued with torch's current
+    stream set to the handle's stream (`member`: the DeviceSlab of this rank — required for device tensors). A send is
+    then ordered behind the chunk that wrote the plane and the next chunk behind the receive, without a host
+    synchronisation and wherever the driver is called from."""
+    import contextlib
+
     import torch.distributed as dist
 
     if len(z_bounds) - 1 != world_size:
         raise ValueError("one slab per rank")
 
     def p2p(ops):
-        batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, group) for kind, t, peer in ops]
-        for w in dist.batch_isend_irecv(batch):
-            w.wait()
+        on_device = any(t.is_cuda for _, t, _ in ops)
+        if on_device and member is None:
+            raise ValueError("dist_fabric: device tensors need `member` (the rank's DeviceSlab) so that the transfers are "
+                             "ordered with the handle's stream")
+        with (member.stream_context() if on_device else contextlib.nullcontext()):
+            batch = [dist.P2POp(dist.isend if kind == "send" else dist.irecv, t, peer, group) for kind, t, peer in ops]
+            for w in dist.batch_isend_irecv(batch):
+                w.wait()
 
     return make_fabric(z_bounds, list(range(world_size)), rank, p2p, sync_local=False)

@@ -1,0 +1,143 @@
+"""BASELINE configs 3, 4 and 5 at their FULL sizes on one MI355X.
+
+Config 3 (the metric's config) is checked against the oracle itself: the whole operator sequence of SURVEY.md 8d at
+512^3 — four Adds, a fused Change, a Change across cube faces (remove + add) — leaves the oracle's UNORM8 light volume
+bit for bit, and the 1024^2 / 512-step frame is the oracle's within 1e-4 (about half a minute of oracle time on the GPU
+box's host cores). Configs 4 and 5 are quoted for 8 GPUs; here the whole job runs on one, and the checks are the
+size-independent ones: the production chunk kernels against the reference-structured one-slice-per-launch kernel, z slabs
+(2 and 8, several handles on this GPU) against the unpartitioned operator, skipping against no skipping, tiles against
+the frame.
+"""
+import numpy as np
+import pytest
+
+from tbraymarcherplugin_amd import abi, sharding, slabs, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def device_volume(config):
+    import torch
+
+    cfg = S.CONFIGS[config]
+    n = cfg["n"]
+    vol = S.make_volume_torch((n, n, n), cfg["dtype"], S.seed_for_config(config), torch.device("cuda", 0))
+    torch.cuda.synchronize()  # the library reads the tensor on its own stream
+    return cfg, vol
+
+
+def handle_for(cfg, vol):
+    n = cfg["n"]
+    res = abi.Resources((n, n, n), abi.DTYPE_FMT[np.dtype(cfg["dtype"])], cfg["light_32bit"])
+    res.upload_volume_device(vol.data_ptr(), vol.numel() * vol.element_size())
+    res.set_tf_lut(abi.color_curve_to_lut(S.tf_keys(cfg["tf"])))
+    res.set_windowing(abi.WindowingParams(*cfg["window"]))
+    return res
+
+
+def test_config3_operator_sequence_and_frame_against_the_oracle(gpu, oracle_mod):
+    cfg, vol = device_volume(3)
+    world = S.default_world()
+    lut = abi.color_curve_to_lut(S.tf_keys(cfg["tf"]))
+    win = abi.WindowingParams(*cfg["window"])
+    orc = oracle_mod.OracleScene(vol.cpu().numpy(), cfg["light_32bit"])
+    orc.set_tf_lut(lut)
+    orc.set_windowing(win)
+    fused = (S.light(1), abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1]))
+    across = (S.light(2), abi.DirLightParams(S.rotate_z(S.LIGHTS[2][0], 60.0), S.LIGHTS[2][1]))  # major axes differ: remove + add
+    pa, _ = abi.host_light_passes(across[0], world, (512, 512, 512))
+    pb, _ = abi.host_light_passes(across[1], world, (512, 512, 512))
+    assert (pa[0].face, pa[1].face) != (pb[0].face, pb[1].face), "the second change is meant to take the fallback path"
+    with handle_for(cfg, vol) as res:
+        res.clear_light_volume(0.0)
+        for i in cfg["lights"]:
+            res.add_dir_light(S.light(i), True, world)
+            orc.add_dir_light(S.light(i), True, world)
+        got = res.download_light_volume()
+        assert np.array_equal(got, orc.light), f"after the adds: {np.count_nonzero(got != orc.light)} of {got.size} UNORM8 light voxels differ"
+        for what, (old, new) in (("fused change", fused), ("change across faces", across)):
+            res.change_dir_light(old, new, world)
+            orc.change_dir_light(old, new, world)
+            got = res.download_light_volume()
+            assert np.array_equal(got, orc.light), f"after the {what}: {np.count_nonzero(got != orc.light)} of {got.size} voxels differ"
+        assert res.launch_counters()["slice"] == 0, "the production chunk kernels were meant to run every pass"
+        cam = S.default_camera(cfg["fb"], cfg["fb"])
+        tile = abi.Tile(0, 0, cfg["fb"], cfg["fb"], 1)
+        rp = abi.RaymarchParams(float(cfg["steps"]), -1, True)
+        frame = res.raymarch_lit(cam, tile, rp, world)
+        ref, n_ref = orc.raymarch_lit(cam, tile, rp, world)
+        assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
+        assert np.abs(frame - ref).max() <= 1e-4, float(np.abs(frame - ref).max())  # north_star's RGBA tolerance
+
+
+def test_config4_chunks_equal_slices_and_slabs_equal_one_handle(gpu, tunables):
+    """1024^3 UNORM16 data (2 GiB, brick offsets beyond 2^31 bytes), 1024^2 slice planes = four 32x32 tiles per CU, i.e. the
+    8-slice-chunks-when-tiles-outnumber-the-CUs branch of the planner: an Add and a fused Change."""
+    cfg, vol = device_volume(4)
+    world = S.default_world()
+    light0 = S.light(0)
+    old, new = S.light(1), abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1])
+    n_slab_handles = 8
+    handles = [handle_for(cfg, vol) for _ in range(1 + n_slab_handles)]
+    whole, parts = handles[0], handles[1:]
+    try:
+        whole.clear_light_volume(0.0)
+        whole.add_dir_light(light0, True, world)
+        whole.add_dir_light(old, True, world)
+        whole.change_dir_light(old, new, world)
+        c = whole.launch_counters()
+        assert c["chunk"] > 0 and c["slice"] == 0
+        ref = whole.download_light_volume()
+        assert ref.max() > 100 and ref.min() < 60
+        # the reference's structure, one launch per slice, on the same handle
+        tunables("force_slice_kernel", 1)
+        whole.clear_light_volume(0.0)
+        whole.add_dir_light(light0, True, world)
+        whole.add_dir_light(old, True, world)
+        whole.change_dir_light(old, new, world)
+        tunables("force_slice_kernel", 0)
+        assert whole.launch_counters()["slice"] > 0
+        sliced = whole.download_light_volume()
+        assert np.array_equal(sliced, ref), f"{np.count_nonzero(sliced != ref)} voxels differ between the chunk and the slice kernels"
+        del sliced
+        # z slabs: 2 and 8 (the same handles, re-partitioned)
+        depth = whole.light_dims[2]
+        for n_slabs in (2, 8):
+            bounds = slabs.slab_bounds(depth, n_slabs)
+            members = [slabs.DeviceSlab(res, k, *bounds[k]) for k, res in enumerate(parts[:n_slabs])]
+            fabric = slabs.make_fabric([b[0] for b in bounds] + [depth])
+            for m in members:
+                m.res.clear_light_volume(0.0)
+            slabs.add_dir_light(members, fabric, light0, True, world)
+            slabs.add_dir_light(members, fabric, old, True, world)
+            slabs.change_dir_light(members, fabric, old, new, world)
+            for m in members:
+                got = m.res.download_light_slices(m.z_begin, m.z_end - m.z_begin)
+                want = ref[m.z_begin:m.z_end]
+                assert np.array_equal(got, want), f"{n_slabs} slabs, slab {m.slab_index}: {np.count_nonzero(got != want)} voxels differ"
+    finally:
+        for h in handles:
+            h.close()
+
+
+def test_config5_skipping_and_tiles_at_2048(gpu):
+    """512^3, 2048^2 frame, TF-B with both cutoffs, 8 lights: empty-space skipping / leaping does not change a pixel, and the
+    8 interleaved row-group tiles of the tile-parallel renderer reassemble the frame."""
+    cfg, vol = device_volume(5)
+    world = S.default_world()
+    fb = cfg["fb"]
+    with handle_for(cfg, vol) as res:
+        res.clear_light_volume(0.0)
+        for i in cfg["lights"]:
+            res.add_dir_light(S.light(i), True, world)
+        res.change_dir_light(S.light(3), abi.DirLightParams(S.rotate_z(S.LIGHTS[3][0], 5.0), S.LIGHTS[3][1]), world)
+        cam = S.default_camera(fb, fb)
+        tile = abi.Tile(0, 0, fb, fb, 1)
+        plain = res.raymarch_lit(cam, tile, abi.RaymarchParams(float(cfg["steps"]), -1, False), world)
+        rp = abi.RaymarchParams(float(cfg["steps"]), -1, True)
+        skipped = res.raymarch_lit(cam, tile, rp, world)
+        assert np.array_equal(plain, skipped), "skipping / leaping changed the frame"
+        assert (skipped[..., 3] > 0.9).any() and (skipped[..., 3] == 0.0).any()
+        del plain
+        parts = np.stack([res.raymarch_lit(cam, sharding.rank_tile(fb, fb, r, 8), rp, world) for r in range(8)])
+        assert np.array_equal(sharding.assemble(parts, fb, 8), skipped)

@@ -92,7 +92,7 @@ def test_slab_partitioned_lights_equal_single_handle(gpu, n_slabs, dims, half_re
             h.close()
 
 
-@pytest.mark.parametrize("switch", ["occ_list=0", "sparse_occ=0", "chunk_steps=4", "tile_h=16", "tile_h=32", "occ_prefetch=0"])
+@pytest.mark.parametrize("switch", ["occ_list=0", "sparse_occ=0", "chunk_steps=4"])
 def test_slabs_with_the_diagnostic_kernel_paths(gpu, tunables, switch):
     """the occlusion launch without the work list / without the empty-block flags (block rows outside the slab's reach are
     then cut inside the kernel), and 4-slice chunks (four times the exchanges)"""

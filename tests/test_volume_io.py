@@ -52,14 +52,11 @@ def run(driver, path, normalize, to_float, out_bin):
 
 
 def normalized_reference(arr):
-    """ConvertArrayToNormalizedArray<In, Out> in numpy float32, including its start values for the running min / max."""
-    t = arr.dtype.type
+    """ConvertArrayToNormalizedArray<In, Out> in numpy float32. One deliberate deviation from the reference: the running
+    maximum starts at the LOWEST value of the type (the reference starts it at numeric_limits<T>::min(), which for float
+    is the smallest positive value, TextureUtilities.h:110 — an all-negative float volume then reports a maximum of ~0)."""
     flat = arr.reshape(-1)
-    if t is np.float32:
-        lo = min(np.float32(np.finfo(np.float32).max), flat.min())
-        hi = max(np.float32(np.finfo(np.float32).tiny), flat.max())  # numeric_limits<float>::min() is the smallest POSITIVE float
-    else:
-        lo, hi = flat.min(), flat.max()
+    lo, hi = flat.min(), flat.max()
     out_t = np.uint8 if arr.dtype.itemsize == 1 else np.uint16
     out_max = np.float32(np.iinfo(out_t).max)
     span = np.float32(hi) - np.float32(lo)
@@ -137,11 +134,12 @@ def test_mhd_header_rules_and_failures(driver, tmp_path):
     const = np.full((2, 2, 2), 7, dtype=np.int16)
     kv = run(driver, write_mhd(str(tmp_path), "f", const), True, False, out_bin)
     assert kv["ok"] == "1" and not np.fromfile(out_bin, dtype=np.uint16).any()
-    # all-negative float file: the running maximum never leaves FLT_MIN (reference quirk, TextureUtilities.h:113)
+    # all-negative float file: the true maximum (-1), not the reference's FLT_MIN start value (TextureUtilities.h:110)
     neg = -np.arange(1, 9, dtype=np.float32).reshape(2, 2, 2)
     kv = run(driver, write_mhd(str(tmp_path), "g", neg), True, False, out_bin)
     want, lo, hi = normalized_reference(neg)
-    assert np.array_equal(np.fromfile(out_bin, dtype=np.uint16).reshape(2, 2, 2), want) and hi == pytest.approx(1.17549435e-38)
+    got = np.fromfile(out_bin, dtype=np.uint16).reshape(2, 2, 2)
+    assert np.array_equal(got, want) and hi == -1.0 and lo == -8.0 and got.max() == 65535 and got.min() == 0
 
 
 def test_actor_level_loaders_compile(tmp_path):

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from tbraymarcherplugin_amd import abi, synthetic as S  # noqa: E402
 
-NAMES = ["tile_h", "chunk_steps", "occ_prefetch", "occ_slices", "sparse_occ", "occ_list", "chain_stagger"]
+NAMES = ["chunk_steps", "occ_slices", "sparse_occ", "occ_list"]
 
 
 def main():

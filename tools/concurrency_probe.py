@@ -52,8 +52,8 @@ def main():
         pairs.append((old, new))
     for h, (old, _) in zip((a, b), pairs):
         h.add_dir_light(old, True, world)
-    for env in ({}, {"chunk_steps": 8}, {"tile_h": 16}, {"tile_h": 16, "chunk_steps": 8}):
-        for k in ("chunk_steps", "tile_h"):
+    for env in ({}, {"chunk_steps": 8}):
+        for k in ("chunk_steps",):
             abi.set_tunable(k, env.get(k, 0))
         one_a = timed([a], [pairs[0]], world)
         one_b = timed([b], [pairs[1]], world)

@@ -27,5 +27,5 @@ for rep in range(int(os.environ.get("REPS", "6"))):
     res.change_dir_light(old, new, world)
     best = min(best, res.last_gpu_time_ms(0))
     old, new = new, old
-print(f"change L{li}: {best:.3f} ms (min)", {k: abi.get_tunable(k) for k in ("tile_h", "chunk_steps", "occ_prefetch")})
+print(f"change L{li}: {best:.3f} ms (min)", {k: abi.get_tunable(k) for k in ("chunk_steps", "occ_slices")})
 res.close()
