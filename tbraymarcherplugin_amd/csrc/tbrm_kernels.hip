@@ -721,27 +721,48 @@ hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// linear (UVolumeTexture mip, x fastest) <-> bricked. One workgroup per brick; the linear side is read/written as
-// eight-voxel rows, the bricked side as one contiguous 512-voxel run.
+// linear (UVolumeTexture mip, x fastest) <-> bricked. One workgroup moves a run of 16 bricks along x (128 x 8 x 8 voxels)
+// through LDS: the linear side is read / written as 64 rows of 128 consecutive voxels (128-512 bytes each, consecutive lanes
+// on consecutive voxels), the bricked side as ONE contiguous run of 16 bricks with 16-byte accesses (bricks that follow each
+// other along x follow each other in memory). (Round 1 moved one brick per workgroup, i.e. 8-voxel row fragments on the linear
+// side: 8x read amplification by the FETCH_SIZE counter.)
+constexpr int kRelayoutSeg = 16; // bricks per workgroup
 template <typename E>
 __global__ __launch_bounds__(256) void k_relayout(const RelayoutParams p)
 {
+    __shared__ __attribute__((aligned(16))) E s_run[kRelayoutSeg * 512];
+    const int segs = (p.bnx + kRelayoutSeg - 1) / kRelayoutSeg;
     const int b = blockIdx.x;
-    const int bx = b % p.bnx, by = (b / p.bnx) % (p.bnxy / p.bnx), bz = b / p.bnxy;
-    E* bricked = (E*) (p.to_bricks ? p.dst : const_cast<void*>(p.src)) + (size_t) b * 512;
+    const int seg = b % segs, by = (b / segs) % (p.bnxy / p.bnx), bz = b / (segs * (p.bnxy / p.bnx));
+    const int bx0 = seg * kRelayoutSeg, nb = min(kRelayoutSeg, p.bnx - bx0);
+    E* bricked = (E*) (p.to_bricks ? p.dst : const_cast<void*>(p.src)) + ((size_t) bz * p.bnxy + (size_t) by * p.bnx + bx0) * 512;
     E* linear = (E*) (p.to_bricks ? const_cast<void*>(p.src) : p.dst);
-    for (int t = threadIdx.x; t < 512; t += 256) {
-        const int x = bx * 8 + (t & 7), y = by * 8 + ((t >> 3) & 7), z = bz * 8 + (t >> 6);
+    constexpr int V = 16 / (int) sizeof(E); // voxels per 16-byte access
+    const int run = nb * 512;
+    if (!p.to_bricks) { // bricked -> LDS
+        for (int i = threadIdx.x * V; i < run; i += 256 * V) *(uint4*) (s_run + i) = *(const uint4*) (bricked + i);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < 64 * 128; i += 256) { // row (y, z) of the run, voxel xl along it
+        const int row = i >> 7, xl = i & 127;
+        const int x = bx0 * 8 + xl, y = by * 8 + (row & 7), z = bz * 8 + (row >> 3);
+        if ((xl >> 3) >= nb) continue;
         const bool in = x < p.nx && y < p.ny && z < p.nz;
         const size_t li = ((size_t) z * p.ny + y) * (size_t) p.nx + x;
-        if (p.to_bricks) bricked[t] = in ? linear[li] : E(0);
-        else if (in) linear[li] = bricked[t];
+        const int si = (xl >> 3) * 512 + (row << 3) + (xl & 7);
+        if (p.to_bricks) s_run[si] = in ? linear[li] : E(0); // padding voxels are zeroed
+        else if (in) linear[li] = s_run[si];
+    }
+    if (p.to_bricks) { // LDS -> bricked
+        __syncthreads();
+        for (int i = threadIdx.x * V; i < run; i += 256 * V) *(uint4*) (bricked + i) = *(const uint4*) (s_run + i);
     }
 }
 
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s)
 {
-    const int n = p.bnxy * p.bnz;
+    const int segs = (p.bnx + kRelayoutSeg - 1) / kRelayoutSeg;
+    const int n = segs * (p.bnxy / (p.bnx > 0 ? p.bnx : 1)) * p.bnz;
     if (n == 0) return hipSuccess;
     if (p.elem_bytes == 1) hipLaunchKernelGGL(k_relayout<uint8_t>, dim3(n), dim3(256), 0, s, p);
     else if (p.elem_bytes == 2) hipLaunchKernelGGL(k_relayout<uint16_t>, dim3(n), dim3(256), 0, s, p);

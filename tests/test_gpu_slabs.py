@@ -483,3 +483,42 @@ def test_slabs_run_steep_passes_slice_by_slice(gpu, dims, steep, light_32bit):
     finally:
         for h in handles:
             h.close()
+
+
+def test_dist_fabric_orders_rccl_transfers_with_the_handles_stream(gpu):
+    """dist_fabric over RCCL (backend nccl) with device tensors, called WITHOUT an outer stream context: the fabric itself
+    enqueues the point-to-point batch relative to the handle's stream, so a plane that a chunk kernel is still writing is
+    sent after the kernel, and what is received is in place before the next operation on that stream reads it. One rank on
+    this box's one GPU: the batch is a send to and a receive from rank 0 itself, which RCCL executes as a device copy."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        _, _, _, (res,) = make_handles(1, (128, 96, 64), np.uint16)
+        depth = res.light_dims[2]
+        member = slabs.DeviceSlab(res, 0, 0, depth)
+        fabric = slabs.dist_fabric([0, depth], 0, 1, member=member)
+        with pytest.raises(ValueError):  # device tensors and no member: refused instead of racing
+            slabs.dist_fabric([0, depth], 0, 1)._p2p([("send", torch.zeros(4, device="cuda"), 0), ("recv", torch.zeros(4, device="cuda"), 0)])
+        world = S.default_world()
+        light = abi.DirLightParams((1, .35, -.5), 0.5)
+        assert member.light_begin(None, light, True, world) >= 1
+        desc = member.pass_begin(0)
+        landing = torch.full((desc.plane_h, desc.plane_w), -1.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for c in range(desc.n_chunks):
+            member.pass_chunk(c)  # enqueued on the handle's stream, not waited for
+        final = member.plane(desc.n_chunks, 0)  # what the last chunk writes
+        fabric._p2p([("send", final, 0), ("recv", landing, 0)])  # no stream context around this call
+        res.flush()
+        torch.cuda.synchronize()
+        assert torch.equal(landing, final) and float(landing.min()) >= 0.0 and float(landing.max()) > 0.0
+        res.close()
+    finally:
+        dist.destroy_process_group()
