@@ -371,6 +371,15 @@ TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, s
 /* Kernel launches since creation: out[0] = chunked propagation launches, out[1] = slice-per-launch propagation
  * launches (fallback path), out[2] = raymarch launches. Lets tests assert which kernel actually ran. */
 TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
+/* The occlusion cache of the light operators (no counterpart in the reference, invisible in the results). The data
+ * sample of the Add / Change shaders (CurrentSample, AddDirLightShader.usf:85-114) does not depend on the light volume,
+ * only on the volume, transfer function, window, clip plane and the light's direction. The operators hand it from their
+ * occlusion kernels to their propagation kernels through HBM anyway; for a light that is ADDED that hand-off is kept
+ * (whole axis passes, nx*ny*nz floats each, least recently used first out, budget = tunable occ_cache_mb, default 16 GiB;
+ * 0 turns it off). When the same light is later the REMOVED side of a ChangeDirLight, or is removed, its samples are not
+ * recomputed. out[0] = stream-passes served from the cache, out[1] = stream-passes computed, out[2] = entries held,
+ * out[3] = their bytes. */
+TBRM_API int tbrm_occlusion_cache_stats(const tbrm_resources* res, uint64_t out[4]);
 TBRM_API int tbrm_flush(tbrm_resources* res);                 /* FlushRenderingCommands() */
 TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's

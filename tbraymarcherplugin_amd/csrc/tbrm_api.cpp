@@ -32,7 +32,7 @@ thread_local char g_error[512] = "";
 // ---- tunables (tbrm_internal.h): name, default; initialised from TBRM_<NAME> when the library is loaded ------------
 struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
-    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1},
+    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"occ_cache_mb", 16384},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0},
 };
 struct TunableStore {
@@ -405,9 +405,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
         for (void* b : axis) (void) hipFree(b);
     for (float* pl : r->d_plane) (void) hipFree(pl);
     delete r->slab_op;
-    (void) hipFree(r->d_occ);
-    (void) hipFree(r->d_occ_zero);
-    (void) hipFree(r->d_occ_list);
+    release_occ_stores(r);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     for (uint16_t* o : r->d_octree) (void) hipFree(o);
@@ -449,6 +447,7 @@ int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_byte
     r->has_volume = true;
     r->octree_valid = false;
     r->minmax_valid = false;
+    ++r->data_gen;
     return TBRM_OK;
 }
 
@@ -464,6 +463,7 @@ int tbrm_upload_volume_device(tbrm_resources* r, const void* device_voxels, size
     r->has_volume = true;
     r->octree_valid = false;
     r->minmax_valid = false;
+    ++r->data_gen;
     return TBRM_OK;
 }
 
@@ -476,6 +476,7 @@ int tbrm_set_tf_lut(tbrm_resources* r, const float* rgba_256x4)
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->has_tf = true;
     r->empty_valid = false;
+    ++r->tf_gen;
     return TBRM_OK;
 }
 
@@ -710,6 +711,7 @@ int tbrm_upload_volume_slices(tbrm_resources* r, int32_t z_begin, int32_t z_coun
     r->has_volume = true;
     r->octree_valid = false;
     r->minmax_valid = false;
+    ++r->data_gen;
     return TBRM_OK;
 }
 
@@ -1063,6 +1065,19 @@ int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     for (int k = 0; k < 3; ++k) out[k] = r->launches[k];
+    return TBRM_OK;
+}
+
+int tbrm_occlusion_cache_stats(const tbrm_resources* r, uint64_t out[4])
+{
+    if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    out[0] = r->occ_hits;
+    out[1] = r->occ_misses;
+    out[2] = r->occ_cache.size();
+    uint64_t bytes = 0;
+    for (const OccStore* st : r->occ_cache) // an axis pass covers the light volume once, whichever axis it runs along
+        if (st->base) bytes += ((uint64_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] + 2 * kPlaneGuard) * sizeof(float);
+    out[3] = bytes;
     return TBRM_OK;
 }
 

@@ -12,7 +12,9 @@ enum : int { ADDR_WRAP = 0, ADDR_CLAMP = 1, ADDR_BORDER = 2 };
 
 // what a chunked propagation pass does with its light stream(s): Add (one light, stream a), Change (a added, r removed,
 // ChangeDirLightShader.usf), or two lights added in one pass (a then r: AddDirLightShader.usf twice, sharing the slice loop)
-enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2 };
+// PASS_CHANGE_ONE: occlusion launches only — ONE stream of a Change (no Add guard), when the other stream's occlusion
+// factors are already at hand (tbrm_light_passes.cpp, the occlusion cache)
+enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3 };
 
 constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
 constexpr int kBrickShift = 3;
@@ -70,7 +72,11 @@ struct ChunkStream {
     float init_value;       // what the cleared read/write buffers decode to (first chunk)
     const float* plane_in;  // propagated light after the previous chunk (W x H floats); unused in the first chunk
     float* plane_out;       // propagated light after this chunk
-    uint32_t occ_off;       // chain: float index, relative to ChunkParams::occ_base, of the occlusion plane of the chunk's first slice
+    const float* occ_base;  // chain: the allocation holding this stream's occlusion planes. Its first 4 KiB are a page of ones: the copy
+                            // source for flagged-empty blocks, which keeps the copies per wave uniform
+    uint32_t occ_off;       // chain: float index, relative to occ_base, of the occlusion plane of the chunk's first slice
+    const uint8_t* occ_flags; // chain: this stream's empty-block flags from the slice group holding the chunk's first slice on:
+                            // [slice group][block y][block x]; null: none (the two streams of a jointly computed pass share one array)
     float* occ_next;        // occlusion launch: where the span's factors 1 - CurrentSample go, [span slices][H][W]
 };
 
@@ -102,14 +108,11 @@ struct ChunkParams {
     // samples can only touch data bricks that map every value to opacity 0. Such a workgroup exits at once and the chain
     // stages the factor 1 - 0 for its pixels from a page of ones instead of the plane stack.
     const uint32_t* empty_bits;   // per data brick (k_brick_empty); used by k_occ_flags only
-    const uint8_t* occ_flags;     // flags from the slice group holding the chunk's first slice on: [slice group][block y][block x];
-                                  // null: feature off for this chunk
-    int occ_phase;                // index of the chunk's first slice within that slice group
+    const uint8_t* occ_flags;     // occlusion launch without a work list: the span's flags (null: every block is computed)
+    int occ_phase;                // chain: index of the chunk's first slice within its slice group (ChunkStream::occ_flags)
     uint8_t* occ_flags_out;       // k_occ_flags: the whole pass, [chunk][slice group][block y][block x]
     int occ_blocks_x, occ_blocks_y, occ_groups; // blocks per plane row / column, slice groups per chunk
     int pass_start, pass_slices, chunk_slices;  // k_occ_flags: first slice, slices in the pass, slices per chunk
-    const float* occ_base;        // the allocation holding the page of ones (its first 4 KiB: the copy source for flagged
-                                  // blocks, which keeps the copies per wave uniform) and both streams' occlusion stacks
     // work list: the non-empty workgroups of each chunk in ascending order (k_occ_compact). The occlusion launch keeps its
     // full grid; workgroup i takes entry i of the list or exits, so the live ones are dealt evenly over the CUs instead
     // of landing wherever the dense part of the volume happens to map.
@@ -208,6 +211,7 @@ enum Tunable : int {
     TUNE_OCC_SLICES,         // slices per occlusion span (0: default)
     TUNE_SPARSE_OCC,         // 0: occlusion blocks that can only see empty bricks are computed like the others
     TUNE_OCC_LIST,           // 0: live occlusion blocks keep their grid position instead of being dealt from a work list
+    TUNE_OCC_CACHE_MB,       // HBM budget of the occlusion cache in MiB (0: off): whole-pass occlusion factors kept for reuse
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load

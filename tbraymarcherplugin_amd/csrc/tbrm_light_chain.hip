@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     int st_src[ROUNDS];   // pixel index of the group's first pixel inside a plane (may run off the row ends: guard bands)
     bool st_ok[ROUNDS];
     int st_dst[ROUNDS];   // this wave's 64 x 4 floats
-    bool st_one[ROUNDS][2] = {}; // the group's 4 pixels lie in empty blocks of slice group 0 / 1 of the chunk
+    bool st_one[NS][ROUNDS][2] = {}; // the group's 4 pixels lie in blocks of slice group 0 / 1 of the chunk that are empty for the stream
     int ndma = 0;         // copies this WAVE issues per staged slice (wave-uniform)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -74,35 +74,43 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NS;
         // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: their factor 1 - 0 is staged from
         // a page of ones
-        if (p.occ_flags && st_ok[rd]) {
+        if (st_ok[rd]) {
             const int x_first = base_x - g.padx + col, x_last = x_first + 3;
             const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = py >> 4;
 #pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                bool one = x_last >= 0 && x_first < p.W && z * kOccSlices < p.occ_phase + g.n;
-                if (one) {
-                    const uint8_t* frow = p.occ_flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
-                    one = frow[bx0] != 0 && frow[bx1] != 0;
+            for (int si = 0; si < NS; ++si) {
+                const uint8_t* flags = si == 0 ? p.a.occ_flags : p.r.occ_flags;
+                if (!flags) continue;
+                if constexpr (NS == 2)
+                    if (si == 1 && flags == p.a.occ_flags) { st_one[NS - 1][rd][0] = st_one[0][rd][0]; st_one[NS - 1][rd][1] = st_one[0][rd][1]; continue; } // computed jointly
+#pragma unroll
+                for (int z = 0; z < 2; ++z) {
+                    bool one = x_last >= 0 && x_first < p.W && z * kOccSlices < p.occ_phase + g.n;
+                    if (one) {
+                        const uint8_t* frow = flags + (z * p.occ_blocks_y + by) * p.occ_blocks_x;
+                        one = frow[bx0] != 0 && frow[bx1] != 0;
+                    }
+                    st_one[si][rd][z] = one;
                 }
-                st_one[rd][z] = one;
             }
         }
     }
-    // The occlusion stacks of both streams and the page of ones live in one allocation: a copy's source is the uniform
-    // base plus a 32-bit offset, and flagged-empty lanes only swap the offset (the same number of copy instructions per
-    // wave and slice either way, which the vmcnt bookkeeping of the slice loop relies on).
+    // A stream's occlusion planes and a page of ones live in one allocation: a copy's source is the stream's uniform base
+    // plus a 32-bit offset, and flagged-empty lanes only swap the offset (the same number of copy instructions per wave and
+    // slice either way, which the vmcnt bookkeeping of the slice loop relies on).
     auto stage_occ = [&](int sf, int q) {
         if (sf >= g.n) return;
         const int group = (p.occ_phase + sf) / kOccSlices;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
             if (!st_ok[rd]) continue;
-            const bool one = group == 0 ? st_one[rd][0] : st_one[rd][1];
             const uint32_t px = (uint32_t) (sf * plane_elems + st_src[rd]);
 #pragma unroll
             for (int si = 0; si < NS; ++si) {
-                const uint32_t off = one ? (uint32_t) lane * 4u : (si == 0 ? p.a.occ_off : p.r.occ_off) + px;
-                dma_16(p.occ_base + off, ring(q, si) + st_dst[rd]);
+                const ChunkStream& s = si == 0 ? p.a : p.r;
+                const bool one = group == 0 ? st_one[si][rd][0] : st_one[si][rd][1];
+                const uint32_t off = one ? (uint32_t) lane * 4u : s.occ_off + px;
+                dma_16(s.occ_base + off, ring(q, si) + st_dst[rd]);
             }
         }
     };

@@ -308,14 +308,16 @@ static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t 
 }
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s)
 {
-    return mode != PASS_ADD ? launch_flags2<PASS_CHANGE>(p, n_chunks, s) : launch_flags2<PASS_ADD>(p, n_chunks, s); // flags only depend on the stream count
+    const bool one = mode == PASS_ADD || mode == PASS_CHANGE_ONE;
+    return one ? launch_flags2<PASS_ADD>(p, n_chunks, s) : launch_flags2<PASS_CHANGE>(p, n_chunks, s); // flags only depend on the stream count
 }
 
 template <int DFMT, int MODE, int AXIS>
 __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NS = MODE != PASS_ADD ? 2 : 1;
+    constexpr int NS = (MODE == PASS_ADD || MODE == PASS_CHANGE_ONE) ? 1 : 2;
+    constexpr bool GUARD = MODE == PASS_ADD || MODE == PASS_ADD2; // all(uvw == saturate(uvw)): the Add shader only (AddDirLightShader.usf:98)
     constexpr int ESZ = DFMT == FMT_U8 ? 1 : (DFMT == FMT_U16 ? 2 : 4);
     __shared__ float s_alpha[256];
     __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                     aw = clip_alpha_weight(c0, c1, c2, p.cc, p.cd, p.lv_dims);
                 }
                 bool inside = true;
-                if constexpr (MODE != PASS_CHANGE) inside = guard_uv && (fl & 4); // all(uvw == saturate(uvw)): Add only
+                if constexpr (GUARD) inside = guard_uv && (fl & 4);
                 float occ = 0.0f;
                 if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
                 out[q * plane_elems] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
@@ -548,7 +550,8 @@ static hipError_t launch_occ2(const ChunkParams& p, hipStream_t s)
 template <int DFMT>
 static hipError_t launch_occ1(const ChunkParams& p, int mode, hipStream_t s)
 {
-    return mode == PASS_ADD ? launch_occ2<DFMT, PASS_ADD>(p, s) : (mode == PASS_CHANGE ? launch_occ2<DFMT, PASS_CHANGE>(p, s) : launch_occ2<DFMT, PASS_ADD2>(p, s));
+    return mode == PASS_ADD ? launch_occ2<DFMT, PASS_ADD>(p, s)
+           : (mode == PASS_CHANGE ? launch_occ2<DFMT, PASS_CHANGE>(p, s) : (mode == PASS_ADD2 ? launch_occ2<DFMT, PASS_ADD2>(p, s) : launch_occ2<DFMT, PASS_CHANGE_ONE>(p, s)));
 }
 // computes the occlusion of the chunk described by (j0, n_steps) into {a,r}.occ_next
 hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s)

@@ -10,6 +10,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace tbrm_host {
@@ -194,6 +195,161 @@ void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, 
     return si == 0 ? r->d_buf[ax][2 + e] : r->d_buf[ax][e];
 }
 
+struct SpanRange { int s0, sn, c0, c1; bool sparse; };
+static SpanRange span_range(const PassPlan& plan, int sp)
+{
+    const ChunkParams& p = plan.p;
+    const int M = plan.M, S = plan.S, D = plan.D;
+    SpanRange q;
+    q.s0 = sp * S;
+    q.sn = std::min(S, D - q.s0);
+    q.c0 = q.s0 / M;
+    q.c1 = ceil_div(q.s0 + q.sn, M);
+    // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple of 4
+    // does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
+    q.sparse = plan.sparse;
+    for (int cc = q.c0; cc < q.c1; ++cc) q.sparse = q.sparse && (std::min(M, D - cc * M) * -p.dx_lo) % 4 == 0; // else the whole span runs dense
+    return q;
+}
+
+// ---- occlusion stores (tbrm_resources.h OccStore) ----------------------------------------------------------------------
+
+static void free_store(OccStore* st)
+{
+    (void) hipFree(st->base);
+    (void) hipFree(st->flags);
+    (void) hipFree(st->list);
+    *st = OccStore{};
+}
+
+void release_occ_stores(tbrm_resources* r)
+{
+    for (OccStore& st : r->occ_tmp) free_store(&st);
+    for (OccStore* st : r->occ_cache) { free_store(st); delete st; }
+    r->occ_cache.clear();
+}
+
+// room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass
+static int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems, size_t flag_bytes)
+{
+    if (slices > st->capacity || !st->base) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(st->base);
+        st->base = nullptr;
+        st->capacity = 0;
+        HIP_TRY(hipMalloc((void**) &st->base, ((size_t) slices * slice_elems + 2 * kPlaneGuard) * sizeof(float)));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) st->base, 0x3f800000, 1024, r->stream)); // the page of ones
+        st->capacity = slices;
+    }
+    if (flag_bytes > st->flag_bytes) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(st->flags);
+        (void) hipFree(st->list);
+        st->flags = nullptr;
+        st->list = nullptr;
+        st->flag_bytes = 0;
+        HIP_TRY(hipMalloc((void**) &st->flags, flag_bytes));
+        HIP_TRY(hipMalloc((void**) &st->list, flag_bytes * sizeof(uint32_t) + 4096 * sizeof(int))); // lists + per-span counts
+        st->flag_bytes = flag_bytes;
+    }
+    return TBRM_OK;
+}
+
+static OccKey occ_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard, const PassPlan& plan)
+{
+    OccKey k;
+    memset(&k, 0, sizeof(k)); // compared bytewise
+    k.data_gen = r->data_gen;
+    k.tf_gen = r->tf_gen;
+    k.win[0] = base.win.center; k.win[1] = base.win.width; k.win[2] = base.win.low_cutoff; k.win[3] = base.win.high_cutoff;
+    for (int c = 0; c < 3; ++c) { k.cc[c] = base.cc[c]; k.cd[c] = base.cd[c]; k.uvw_off[c] = q.uvw_offset[c]; }
+    k.data_border = base.data_border;
+    k.clip_mode = base.clip_mode;
+    k.axis = q.axis; k.dir = plan.dir; k.start = plan.start; k.D = plan.D; k.W = plan.p.W; k.H = plan.p.H; k.S = plan.S;
+    k.guard = guard ? 1 : 0;
+    k.sparse = plan.sparse ? 1 : 0;
+    k.work_list = plan.work_list ? 1 : 0;
+    k.step100 = q.step_size * 100.0f;
+    return k;
+}
+
+static OccStore* cache_find(tbrm_resources* r, const OccKey& key)
+{
+    for (OccStore* st : r->occ_cache)
+        if (st->valid && !memcmp(&st->key, &key, sizeof(key))) return st;
+    return nullptr;
+}
+
+// A store for a new cache entry: a fresh one while the budget lasts, else the least recently used one that the operator
+// being planned does not use. null: the cache is off or full of pinned entries.
+static OccStore* cache_new(tbrm_resources* r, size_t entry_bytes)
+{
+    const size_t budget = (size_t) std::max(tune(TUNE_OCC_CACHE_MB), 0) << 20;
+    if (entry_bytes == 0 || entry_bytes > budget) return nullptr;
+    if ((r->occ_cache.size() + 1) * entry_bytes <= budget) {
+        r->occ_cache.push_back(new OccStore{});
+        return r->occ_cache.back();
+    }
+    OccStore* victim = nullptr;
+    for (OccStore* st : r->occ_cache)
+        if (!st->pinned && (!victim || st->last_use < victim->last_use)) victim = st;
+    if (victim) victim->valid = false;
+    return victim;
+}
+
+// Where the occlusion factors of the plan's stream(s) live and who computes them.
+static int plan_occlusion(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, bool slab,
+                          PassPlan& plan)
+{
+    const ChunkParams& p = plan.p;
+    const size_t slice_elems = (size_t) p.W * p.H;
+    const size_t flag_bytes = plan.sparse ? plan.flags_per_span * plan.n_spans : 0;
+    const int ns = plan.two_streams() ? 2 : 1;
+    // A whole pass in one store: an Add, or the streams of a Change (not a slab's share of a pass, not a paired Add, whose
+    // second stream differs from a lone Add's only in bookkeeping but whose flags are joint). The chain addresses a
+    // store's planes with 32-bit offsets, and a cached store written with blocks flagged empty left out is only good for
+    // a pass that can use the flags in every span.
+    bool all_spans_sparse = plan.sparse;
+    for (int sp = 0; sp < plan.n_spans && all_spans_sparse; ++sp) all_spans_sparse = span_range(plan, sp).sparse;
+    const size_t entry_elems = (size_t) plan.D * slice_elems + 2 * kPlaneGuard;
+    const bool cacheable = !slab && plan.mode != PASS_ADD2 && tune(TUNE_OCC_CACHE_MB) > 0 && entry_elems * sizeof(float) < ((size_t) 1 << 32) &&
+                           (all_spans_sparse || !plan.sparse);
+    const tbrm_light_pass* q[2] = {&pa, pr};
+    for (int si = 0; si < ns; ++si) {
+        OccStore* st = nullptr;
+        bool compute = true;
+        if (cacheable) {
+            const OccKey key = occ_key(r, base, *q[si], plan.mode == PASS_ADD, plan);
+            st = cache_find(r, key);
+            if (st) compute = false;
+            else if (si == 0 || plan.mode == PASS_ADD) { // what is added stays in the scene: worth keeping. What is removed is not.
+                st = cache_new(r, entry_elems * sizeof(float));
+                if (st) {
+                    if (int e = ensure_store(r, st, plan.D, slice_elems, flag_bytes)) return e;
+                    st->key = key;
+                }
+            }
+            if (st) {
+                st->pinned = true;
+                st->last_use = ++r->occ_clock;
+            }
+        }
+        if (!st) {
+            st = &r->occ_tmp[si];
+            if (int e = ensure_store(r, st, plan.S, slice_elems, flag_bytes)) return e;
+        }
+        plan.occ[si] = st;
+        plan.occ_compute[si] = compute;
+        ++(compute ? r->occ_misses : r->occ_hits);
+    }
+    return TBRM_OK;
+}
+
+static void unpin_occ_stores(tbrm_resources* r)
+{
+    for (OccStore* st : r->occ_cache) st->pinned = false;
+}
+
 // pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
 // pr, both added with b_added / b_added2).
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
@@ -295,25 +451,11 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     if (tune(TUNE_OCC_SLICES) > 0) S = tune(TUNE_OCC_SLICES);
     S = std::max(M, (S / M) * M);
 
-    // occlusion scratch, allocated on first use: ONE allocation = [page of ones | guard][stream a: S planes][guard]
-    // [stream r: S planes][guard], so that the chain addresses every copy source as base + 32-bit offset
-    size_t occ_elems = (size_t) S * W * H;
-    while (S > M && (2 * occ_elems + 3 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) { S -= M; occ_elems = (size_t) S * W * H; }
-    const size_t occ_total = 2 * occ_elems + 3 * kPlaneGuard;
-    if (occ_total * sizeof(float) >= ((size_t) 1 << 32)) return declined("slice plane too large for the occlusion scratch");
-    if (occ_elems > r->occ_elems) {
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        (void) hipFree(r->d_occ);
-        r->d_occ = nullptr;
-        r->occ_elems = 0;
-        HIP_TRY(hipMalloc((void**) &r->d_occ, occ_total * sizeof(float)));
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_occ, 0x3f800000, 1024, r->stream)); // the page of ones
-        r->occ_elems = occ_elems;
-    }
+    const size_t slice_elems = (size_t) W * H;
+    while (S > M && ((size_t) S * slice_elems + 2 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) S -= M;
+    if (((size_t) S * slice_elems + 2 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) return declined("slice plane too large for the occlusion scratch");
     plan.S = S;
     plan.n_spans = ceil_div(D, S);
-    plan.occ_off_a = kPlaneGuard;
-    plan.occ_off_r = kPlaneGuard + r->occ_elems + kPlaneGuard;
 
     // empty-block hand-off (needs the per-brick emptiness bits of the current TF/window): one flag per occlusion
     // workgroup of the whole pass and per span the ascending list of the workgroups with work, computed in front of the
@@ -326,46 +468,17 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     if (plan.sparse) {
         if (plan.n_spans > 4096) return declined("too many occlusion spans");
         if (int e = ensure_skipping(r)) return e;
-        const size_t zbytes = plan.flags_per_span * plan.n_spans;
-        if (zbytes > r->occ_zero_bytes) {
-            HIP_TRY(hipStreamSynchronize(r->stream));
-            (void) hipFree(r->d_occ_zero);
-            (void) hipFree(r->d_occ_list);
-            r->d_occ_zero = nullptr;
-            r->d_occ_list = nullptr;
-            r->occ_zero_bytes = 0;
-            HIP_TRY(hipMalloc((void**) &r->d_occ_zero, zbytes));
-            HIP_TRY(hipMalloc((void**) &r->d_occ_list, zbytes * sizeof(uint32_t) + 4096 * sizeof(int))); // lists + counts
-            r->occ_zero_bytes = zbytes;
-        }
         p.empty_bits = r->d_empty;
         p.pass_start = plan.start;
         p.pass_slices = D;
         p.chunk_slices = S;
     }
-    return TBRM_OK;
+    return plan_occlusion(r, base, pa, pr, slab != nullptr, plan);
 }
 
 // The plane holding the propagated light of stream `si` (0: a, 1: r) BEFORE chunk `boundary` (boundary = n_chunks: after
 // the last one): chunk c reads the planes of parity c & 1 and writes the others.
 float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_plane[2 * si + (boundary & 1)] + kPlaneGuard; }
-
-struct SpanRange { int s0, sn, c0, c1; bool sparse; };
-static SpanRange span_range(const PassPlan& plan, int sp)
-{
-    const ChunkParams& p = plan.p;
-    const int M = plan.M, S = plan.S, D = plan.D;
-    SpanRange q;
-    q.s0 = sp * S;
-    q.sn = std::min(S, D - q.s0);
-    q.c0 = q.s0 / M;
-    q.c1 = ceil_div(q.s0 + q.sn, M);
-    // the chain stages its window in groups of 4 pixels starting at tile_x - n*|dx_lo|: only when that is a multiple of 4
-    // does a group never straddle two 16-pixel occlusion blocks (always true for full chunks of 16/8/4 slices)
-    q.sparse = plan.sparse;
-    for (int cc = q.c0; cc < q.c1; ++cc) q.sparse = q.sparse && (std::min(M, D - cc * M) * -p.dx_lo) % 4 == 0; // else the whole span runs dense
-    return q;
-}
 
 // Enqueues chunk c of the plan: in front of the pass's first chunk the empty-block flags and work lists of the whole
 // pass, in front of a span's first chunk the occlusion of the span, then the chain.
@@ -393,37 +506,75 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
     const int M = plan.M, D = plan.D, W = p.W, H = p.H;
     const int sp = (c * M) / plan.S;
     const SpanRange q = span_range(plan, sp);
-    int* const counts = (int*) (r->d_occ_list + r->occ_zero_bytes);
-    p.occ_base = r->d_occ;
-    p.a.occ_next = r->d_occ + plan.occ_off_a;
-    p.r.occ_next = r->d_occ + plan.occ_off_r;
-    if (c == 0 && plan.sparse) {
-        p.occ_flags_out = r->d_occ_zero;
-        p.occ_list_out = plan.work_list ? r->d_occ_list : nullptr;
-        p.occ_count_out = counts;
-        HIP_TRY(launch_occ_flags(p, plan.mode, plan.n_spans, r->stream));
+    const size_t slice_elems = (size_t) W * H;
+    const int ns = plan.two_streams() ? 2 : 1;
+    // streams that are both computed are computed by one launch and share the first one's flags
+    const bool joint = ns == 2 && plan.occ_compute[0] && plan.occ_compute[1];
+    OccStore* const flag_store[2] = {plan.occ[0], joint ? plan.occ[0] : plan.occ[1]};
+    auto cached = [&](int si) { return plan.occ[si] != &r->occ_tmp[si]; };
+    // float offset, inside its store, of the plane of slice number `k` of the pass (a cached store holds the whole pass, a
+    // transient one the current span)
+    auto plane_off = [&](int si, int k) { return (size_t) kPlaneGuard + (size_t) (cached(si) ? k : k - q.s0) * slice_elems; };
+    ChunkStream* const streams[2] = {&p.a, &p.r};
+
+    // One occlusion launch computes stream si alone (as the kernel's stream a) or, si < 0, both streams of the plan.
+    auto occlusion_launch = [&](int si, bool flags_of_pass) -> int {
+        ChunkParams o = p;
+        int mode = plan.mode;
+        if (si >= 0 && ns == 2) { // one stream of a Change on its own
+            mode = PASS_CHANGE_ONE;
+            if (si == 1) o.a = p.r;
+        }
+        const int first = si < 0 ? 0 : si;
+        OccStore* const fs = flag_store[first];
+        int* const counts = (int*) (fs->list + fs->flag_bytes);
+        if (flags_of_pass) {
+            o.occ_flags_out = fs->flags;
+            o.occ_list_out = plan.work_list ? fs->list : nullptr;
+            o.occ_count_out = counts;
+            HIP_TRY(launch_occ_flags(o, mode, plan.n_spans, r->stream));
+            return TBRM_OK;
+        }
+        o.j0 = plan.start + q.s0 * plan.dir;
+        o.n_steps = q.sn;
+        o.a.occ_next = plan.occ[first]->base + plane_off(first, q.s0);
+        if (si < 0 && ns == 2) o.r.occ_next = plan.occ[1]->base + plane_off(1, q.s0);
+        o.occ_flags = nullptr;
+        o.occ_list = q.sparse && plan.work_list ? fs->list + (size_t) sp * plan.flags_per_span : nullptr;
+        o.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
+        if (q.sparse && !plan.work_list) o.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
+        HIP_TRY(launch_light_occlusion(o, mode, r->stream));
+        return TBRM_OK;
+    };
+    for (int phase = 0; phase < 2; ++phase) { // 0: the pass's flags and work lists (before its first chunk), 1: the span's occlusion
+        if (phase == 0 ? !(c == 0 && plan.sparse) : c != q.c0) continue;
+        if (joint || (ns == 1 && plan.occ_compute[0])) {
+            if (int e = occlusion_launch(-1, phase == 0)) return e;
+        } else {
+            for (int si = 0; si < ns; ++si)
+                if (plan.occ_compute[si])
+                    if (int e = occlusion_launch(si, phase == 0)) return e;
+        }
     }
-    if (c == q.c0) { // occlusion of the span: fills {a,r}.occ_next with sn planes
-        p.j0 = plan.start + q.s0 * plan.dir;
-        p.n_steps = q.sn;
-        p.occ_flags = nullptr;
-        p.occ_list = q.sparse && plan.work_list ? r->d_occ_list + (size_t) sp * plan.flags_per_span : nullptr;
-        p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
-        if (q.sparse && !plan.work_list) p.occ_flags = r->d_occ_zero + (size_t) sp * plan.flags_per_span;
-        HIP_TRY(launch_light_occlusion(p, plan.mode, r->stream));
-    }
+    if (c == q.c0 && sp == plan.n_spans - 1) // a cached store is complete once its last span is on the stream
+        for (int si = 0; si < ns; ++si)
+            if (cached(si) && plan.occ_compute[si]) plan.occ[si]->valid = true;
+
     const int k0 = c * M - q.s0; // first slice of the chunk within the span
     p.n_steps = std::min(M, D - c * M);
     p.j0 = plan.start + c * M * plan.dir;
     p.first_chunk = c == 0 && plan.pass_begins_here;
     p.a.plane_in = plan_plane(r, c, 0); p.a.plane_out = plan_plane(r, c + 1, 0);
     p.r.plane_in = plan_plane(r, c, 1); p.r.plane_out = plan_plane(r, c + 1, 1);
-    p.a.occ_off = (uint32_t) (plan.occ_off_a + (size_t) k0 * W * H);
-    p.r.occ_off = (uint32_t) (plan.occ_off_r + (size_t) k0 * W * H);
+    for (int si = 0; si < ns; ++si) {
+        streams[si]->occ_base = plan.occ[si]->base;
+        streams[si]->occ_off = (uint32_t) plane_off(si, q.s0 + k0);
+        streams[si]->occ_flags = q.sparse ? flag_store[si]->flags + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
+    }
     p.occ_phase = k0 % kOccSlices;
     p.occ_list = nullptr;
     p.occ_count = nullptr;
-    p.occ_flags = q.sparse ? r->d_occ_zero + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
+    p.occ_flags = nullptr;
     HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
     ++r->launches[0];
     return TBRM_OK;
@@ -509,8 +660,9 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             continue;
         }
         for (int c = 0; c < plans[i].n_chunks; ++c)
-            if (int e = enqueue_plan_chunk(r, plans[i], c)) return e;
+            if (int e = enqueue_plan_chunk(r, plans[i], c)) { unpin_occ_stores(r); return e; }
     }
+    unpin_occ_stores(r);
     return TBRM_OK;
 }
 

@@ -11,6 +11,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace tbrm_host {
 
@@ -26,6 +27,35 @@ inline size_t format_bytes(int fmt) { return fmt == TBRM_FMT_G8 ? 1 : (fmt == TB
             return tbrm_host::fail(e_ == hipErrorOutOfMemory ? TBRM_ERR_OUT_OF_MEMORY : TBRM_ERR_NO_DEVICE, "%s failed: %s", \
                 #expr, hipGetErrorString(e_));                                                                \
     } while (0)
+
+// The occlusion factors 1 - CurrentSample (AddDirLightShader.usf:85-117) of ONE light stream of an axis pass, as the chain
+// kernel consumes them: [page of ones | guard][slices x H x W floats][guard], plus the pass's empty-block flags and work
+// lists. Two kinds:
+//   transient   a span of S slices, overwritten span by span (tbrm_resources::occ_tmp, one per stream);
+//   cached      the WHOLE pass, kept under a key (everything the factors depend on: volume / TF generation, window, clip
+//               plane, the stream's axis, direction, UVW offset and step size, Add guard on / off). The next operator that
+//               needs the same stream — the removed light of a ChangeDirLight is the light an earlier Add / Change put
+//               there; a removed light was once added — takes them from here instead of recomputing them: the hand-off
+//               the chain reads anyway is simply not thrown away (no extra traffic).
+struct OccKey {
+    uint64_t data_gen, tf_gen;
+    float win[4];
+    float cc[3], cd[3], data_border;
+    int32_t clip_mode, axis, dir, start, D, W, H, S, guard, sparse, work_list;
+    float uvw_off[3], step100;
+};
+struct OccStore {
+    float* base = nullptr;          // the allocation
+    int capacity = 0;               // slices it holds
+    uint8_t* flags = nullptr;       // empty-block flags of the pass: [span][slice group][block y][block x]
+    uint32_t* list = nullptr;       // work lists of the pass (one uint32 per flag) followed by 4096 per-span counts
+    size_t flag_bytes = 0;
+    // cached stores
+    OccKey key{};
+    bool valid = false;             // every span has been enqueued
+    bool pinned = false;            // in use by the operator being planned
+    uint64_t last_use = 0;
+};
 
 struct tbrm_resources {
     tbrm_resources_desc desc{};
@@ -61,11 +91,11 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
-    float* d_occ = nullptr;        // chunk kernel: page of ones + the occlusion plane stacks of a span (allocated on first use)
-    size_t occ_elems = 0;          // floats per stream
-    uint8_t* d_occ_zero = nullptr; // empty-block flags of a whole pass
-    uint32_t* d_occ_list = nullptr; // work lists of the pass (one uint32 per flag) followed by 4096 per-span counts
-    size_t occ_zero_bytes = 0;
+    OccStore occ_tmp[2];           // chunk kernels: the transient occlusion stores of the two streams (allocated on first use)
+    std::vector<OccStore*> occ_cache; // ... and the cached ones (every one nx*ny*nz floats: an axis pass covers the volume)
+    uint64_t occ_clock = 0;        // LRU clock of the cache
+    uint64_t occ_hits = 0, occ_misses = 0; // stream-passes served from the cache / computed (tbrm_occlusion_cache_stats)
+    uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
 
     // empty-space-skipping metadata
     int bn[3]{};
@@ -132,7 +162,12 @@ struct PassPlan {
     int n_chunks = 0, n_spans = 0;
     bool pass_begins_here = true; // chunk 0 starts from the cleared buffers' value (else from imported planes)
     bool sparse = false, work_list = false;
-    size_t flags_per_group = 0, flags_per_span = 0, occ_off_a = 0, occ_off_r = 0;
+    size_t flags_per_group = 0, flags_per_span = 0;
+    // occlusion of the two streams: where the factors live, and whether this pass has to compute them (a cached store that
+    // already holds them: no). Streams that are both computed are computed by ONE launch per span and share the flags of
+    // occ[0] (a block is flagged when it is empty for both).
+    OccStore* occ[2] = {nullptr, nullptr};
+    bool occ_compute[2] = {false, false};
     // slab-partitioned passes
     bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
     int first_chunk_of_pass = 0, chunks_of_pass = 0;
@@ -151,6 +186,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c);
+void release_occ_stores(tbrm_resources* r); // frees the transient and cached occlusion stores (the stream must be idle)
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
 int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
                       int32_t* schedule, int32_t* n_entries);

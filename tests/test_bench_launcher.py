@@ -3,6 +3,7 @@ driver's contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1). Runs
 they were started with (TBRM_BENCH_LAUNCH_CHECK=1) and never touch a device."""
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -15,7 +16,7 @@ def run_bench(argv, extra_env=None):
     env.update(extra_env or {})
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    return [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+    return [json.loads(obj) for obj in re.findall(r"\{[^{}]*\}", out.stdout)]  # (two ranks may share a line)
 
 
 def test_one_gpu_needs_no_launcher():

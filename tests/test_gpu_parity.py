@@ -701,3 +701,79 @@ def test_random_render_scenes_against_oracle(gpu, oracle_mod, seed, tunables):
             mip = int(rng.integers(0, 4))
             worst = max(worst, float(np.abs(res.raymarch_octree(cam, tile, rp, world, mip) - orc.raymarch_octree(cam, tile, rp, world, mip)).max()))
         assert worst <= TIGHT_TOL, worst
+
+
+@pytest.mark.parametrize("light_32bit", [False, True])
+def test_occlusion_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_32bit, tunables):
+    """The occlusion cache (tbrm.h tbrm_occlusion_cache_stats) never shows in the results: a sequence of operators that hits it
+    (the removed side of a ChangeDirLight was the added side of the previous one; a light that oscillates between two
+    directions; a removal of a light that was added), misses it (first change after an add: the Add shader's guard differs
+    from the Change shader's), and invalidates it (new window, new transfer function, new volume) follows the oracle step by
+    step, and leaves the same light volume as the same sequence with the cache turned off."""
+    dims = (104, 88, 72)
+    world = S.default_world()
+    vol = small_volume(dims, np.uint16)
+    vol2 = small_volume(dims, np.uint16, seed=0x5EED0777)
+    lut_a, lut_b = abi.color_curve_to_lut(S.TF_A_KEYS), abi.color_curve_to_lut(S.TF_B_KEYS)
+    win_a, win_b = abi.WindowingParams(0.5, 0.9, True, False), abi.WindowingParams(0.45, 0.7, True, True)
+
+    def rot(i, deg):
+        return abi.DirLightParams(S.rotate_z(S.LIGHTS[i][0], deg), S.LIGHTS[i][1])
+
+    l0, l1 = S.light(0), S.light(1)
+    steps = [("add", l0), ("add", l1),
+             ("change", l1, rot(1, 5)),           # miss + miss: the Add's stream carries the Add shader's guard
+             ("change", rot(1, 5), rot(1, 10)),   # hit on the removed side
+             ("change", rot(1, 10), rot(1, 5)),   # both sides cached: no occlusion launch at all
+             ("change", rot(1, 5), rot(1, 10)),
+             ("remove", l0),                      # hit: the stream the add computed
+             ("window", win_b), ("change", rot(1, 10), rot(1, 15)),   # everything cached is stale
+             ("change", rot(1, 15), rot(1, 20)),
+             ("tf", lut_b), ("change", rot(1, 20), rot(1, 25)), ("add", l0),
+             ("volume", vol2), ("change", rot(1, 25), rot(1, 30)), ("remove", l0), ("change", rot(1, 30), rot(1, 90))]  # last: across faces
+    finals, stats = [], []
+    for cache_mb in (16384, 0):
+        tunables("occ_cache_mb", cache_mb)
+        orc = oracle_mod.OracleScene(vol, light_32bit)
+        orc.set_tf_lut(lut_a)
+        orc.set_windowing(win_a)
+        with abi.Resources(dims, abi.FMT_G16, light_32bit) as res:
+            res.upload_volume(vol)
+            res.set_tf_lut(lut_a)
+            res.set_windowing(win_a)
+            res.clear_light_volume(0.0)
+            for i, step in enumerate(steps):
+                kind = step[0]
+                if kind in ("add", "remove"):
+                    res.add_dir_light(step[1], kind == "add", world)
+                    orc.add_dir_light(step[1], kind == "add", world)
+                elif kind == "change":
+                    res.change_dir_light(step[1], step[2], world)
+                    orc.change_dir_light(step[1], step[2], world)
+                elif kind == "window":
+                    res.set_windowing(step[1])
+                    orc.set_windowing(step[1])
+                    continue
+                elif kind == "tf":
+                    res.set_tf_lut(step[1])
+                    orc.set_tf_lut(step[1])
+                    continue
+                else:
+                    res.upload_volume(step[1])
+                    orc2 = oracle_mod.OracleScene(step[1], light_32bit)
+                    orc2.set_tf_lut(lut_b)
+                    orc2.set_windowing(win_b)
+                    orc2.light[...] = orc.light
+                    orc = orc2
+                    continue
+                assert_light_equal(res, orc)
+                if cache_mb and i == 4:
+                    before = res.occlusion_cache_stats()
+                if cache_mb and i == 5:
+                    after = res.occlusion_cache_stats()
+                    assert after["hits"] - before["hits"] == 4 and after["computed"] == before["computed"], (before, after)
+            finals.append(res.download_light_volume())
+            stats.append(res.occlusion_cache_stats())
+            assert res.launch_counters()["slice"] == 0
+    assert stats[0]["hits"] >= 10 and stats[0]["entries"] > 0 and stats[1]["hits"] == 0 and stats[1]["entries"] == 0, stats
+    assert np.array_equal(finals[0], finals[1]) if not light_32bit else np.abs(finals[0] - finals[1]).max() == 0.0
