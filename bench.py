@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N>1: grow the framebuffer with N (~N x fb^2 pixels) instead of splitting one frame")
     ap.add_argument("--fixed-frame", action="store_true", help="N>1: split ONE frame of the config's size over the GPUs (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling runs: leave out the extra operator timings (reset, fallback change, one-GPU reference), so that every "
+                         "step of the process is one ChangeDirLight + one raymarch")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     ap.add_argument("--no-skipping", action="store_true")
     ap.add_argument("--raymarch-only", action="store_true", help="diagnostic: leave the light update out of the step")
@@ -386,7 +389,7 @@ def main():
     # Every rank runs the same operators, so the replicated light volumes stay identical.
     ops_ms = {}
     one_gpu = None
-    if not args.raymarch_only and slab_member is None:
+    if not args.raymarch_only and slab_member is None and not args.timed_only:
         res.flush()
         full_tile = abi.Tile(0, 0, fb_w, fb_h, 1)
         full = torch.empty((fb_h, fb_w, 4), dtype=torch.float32, device=device)

@@ -363,8 +363,12 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     if (hipDeviceGetAttribute(&r->n_cus, hipDeviceAttributeMultiprocessorCount, desc->device) != hipSuccess || r->n_cus <= 0) r->n_cus = 256;
     {
         tbrm_resources::Residency& q = r->res_data;
-        CREATE_TRY(hipMalloc(&q.alloc, (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0)) * q.layer_bytes));
+        const size_t bytes = (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0)) * q.layer_bytes;
+        CREATE_TRY(hipMalloc(&q.alloc, bytes));
         r->d_data = (char*) q.alloc - (size_t) q.lo * q.layer_bytes;
+        // a slab-resident handle is filled layer by layer (tbrm_upload_volume_slices): what has not arrived yet reads as 0,
+        // not as whatever the allocation held
+        if (r->resident) CREATE_TRY(hipMemsetAsync(q.alloc, 0, bytes, r->stream));
     }
     CREATE_TRY(hipMalloc((void**) &r->d_tf, 256 * sizeof(float4)));
     {

@@ -232,14 +232,15 @@ void release_occ_stores(tbrm_resources* r)
 // room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass
 static int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems, size_t flag_bytes)
 {
-    if (slices > st->capacity || !st->base) {
+    const size_t elems = (size_t) slices * slice_elems; // (the passes of a non-cubic volume have planes of different sizes)
+    if (elems > st->capacity || !st->base) {
         HIP_TRY(hipStreamSynchronize(r->stream));
         (void) hipFree(st->base);
         st->base = nullptr;
         st->capacity = 0;
-        HIP_TRY(hipMalloc((void**) &st->base, ((size_t) slices * slice_elems + 2 * kPlaneGuard) * sizeof(float)));
+        HIP_TRY(hipMalloc((void**) &st->base, (elems + 2 * kPlaneGuard) * sizeof(float)));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) st->base, 0x3f800000, 1024, r->stream)); // the page of ones
-        st->capacity = slices;
+        st->capacity = elems;
     }
     if (flag_bytes > st->flag_bytes) {
         HIP_TRY(hipStreamSynchronize(r->stream));

@@ -46,7 +46,7 @@ struct OccKey {
 };
 struct OccStore {
     float* base = nullptr;          // the allocation
-    int capacity = 0;               // slices it holds
+    size_t capacity = 0;            // floats of planes it holds (slices x H x W of the pass it was sized for)
     uint8_t* flags = nullptr;       // empty-block flags of the pass: [span][slice group][block y][block x]
     uint32_t* list = nullptr;       // work lists of the pass (one uint32 per flag) followed by 4096 per-span counts
     size_t flag_bytes = 0;

@@ -8,25 +8,30 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 (timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > "$OUT/tests.txt"
 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python bench.py --no-cpu-baseline > "$OUT/bench_n1_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python bench.py --no-cpu-baseline --timed-only > "$OUT/bench_n1_under_rocprof.json" 2> /dev/null
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench_n1.csv" \;
 find /tmp/prof_stats -name "*kernel_trace.csv" -exec cp {} /tmp/kt.csv \;
 python tools/trace_kernels.py /tmp/kt.csv > "$OUT/kernel_durations_bench_n1.txt" 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o p -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o p -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o p -- python bench.py --no-cpu-baseline --timed-only --steps 20 --warmup 4 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o p -- python bench.py --no-cpu-baseline --timed-only --steps 20 --warmup 4 > /dev/null 2>&1
 find /tmp/prof_fetch -name "*counter_collection.csv" -exec cp {} /tmp/pmc_fetch.csv \;
 find /tmp/prof_write -name "*counter_collection.csv" -exec cp {} /tmp/pmc_write.csv \;
 python tools/pmc_traffic.py /tmp/pmc_fetch.csv /tmp/pmc_write.csv "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
 python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only.json" 2> /dev/null
 python tools/prof_light.py 2>&1 | grep -v amdgpu.ids > "$OUT/operators.txt"
+python tools/change_sweep.py "" "occ_cache_mb=0" 2>&1 | grep -v amdgpu.ids >> "$OUT/operators.txt"
+for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
+TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"
 cat "$OUT/tests.txt" "$OUT/operators.txt"
 python - "$OUT" <<'PY'
 import json, sys
 out = sys.argv[1]
-for f in ("bench_n1.json", "bench_n1_under_rocprof.json", "bench_n1_raymarch_only.json"):
+for f in ("bench_n1.json", "bench_n1_under_rocprof.json", "bench_n1_raymarch_only.json", "bench_n1_config1.json", "bench_n1_config2.json",
+          "bench_n1_config4.json", "bench_n1_config5.json", "bench_dry_run_2_ranks_on_one_gpu.json"):
     try:
         d = json.load(open(f"{out}/{f}"))
-        print(f, d["value"], d["ms_per_step"], d["gpu_ms"], d["roofline"]["achieved"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"))
+        print(f, d["value"], d["ms_per_step"], d["gpu_ms"], d["roofline"]["achieved"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"),
+              d.get("full_size_parity"), d.get("gathered_frame_equals_single_gpu_render"))
     except Exception as e:
         print(f, "unreadable:", e)
 PY

@@ -35,14 +35,15 @@ def main():
         wr = w * 1024 / max(nw, 1)
         out[name] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                      "hbm_bytes_per_launch": rd + wr, "fetch_size_raw_kib": f / max(nf, 1), "write_size_raw_kib": w / max(nw, 1)}
-    # per operator call: every step of the profiled bench command makes one ChangeDirLight and one raymarch, so the number
-    # of raymarch launches is the number of Change calls; the Change's kernels are the MODE = 1 (PASS_CHANGE) instantiations:
-    # k_light_occlusion<DFMT, MODE, AXIS>, k_light_chain<LFMT, MODE, AXIS, KH, RS>, k_occ_flags<MODE, AXIS>
+    # per operator call: every step of the profiled bench command (bench.py --timed-only) makes one ChangeDirLight and one
+    # raymarch, so the number of raymarch launches is the number of Change calls; the Change's kernels are
+    # k_light_chain<LFMT, MODE = 1, AXIS, KH, RS> and k_light_occlusion<DFMT, MODE, AXIS> with MODE = 1 (both streams) or 3
+    # (the added stream alone: the removed one came from the occlusion cache); the flag kernels move < 0.2 MB per pass
     ray = [v for k, v in out.items() if "k_raymarch_lit" in k]
     if ray:
         calls = sum(v["launches"] for v in ray)
         change = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items()
-                     if re.search(r"k_light_(chain|occlusion)<\d+, 1,", k) or "k_occ_flags<1," in k)
+                     if re.search(r"k_light_chain<\d+, 1,", k) or re.search(r"k_light_occlusion<\d+, [13],", k))
         out["_per_operator_call"] = {"calls": calls, "change_dir_light_hbm_bytes": change / calls,
                                      "raymarch_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ray) / calls}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
