@@ -501,6 +501,7 @@ def main():
                            **{k: round(v, 4) for k, v in ops_ms.items()},
                            first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
+            "light_cache": res.light_cache_stats(),  # contribution cache (include/tbrm.h tbrm_light_cache_stats)
             "scaling_detail": scaling_note,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -168,7 +168,7 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
 /* Process-wide tunables: A/B switches for measurements and parity tests (no counterpart in the reference; nothing a
  * host needs to call). Each starts from the environment variable TBRM_<NAME IN CAPITALS>, read once when the library is
  * loaded; no operator reads the environment. Names (default): force_slice_kernel (0), chunk_steps (0 = by fit),
- * occ_slices (0 = 128), sparse_occ (1), occ_list (1), light_batching (1; 0 never, 2 always), share_grid (1),
+ * occ_slices (0 = 128), sparse_occ (1), occ_list (1), light_cache_mb (16384), light_batching (1; 0 never, 2 always), share_grid (1),
  * ray_lanes (0 = by load; 4 / 8). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
@@ -371,15 +371,16 @@ TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, s
 /* Kernel launches since creation: out[0] = chunked propagation launches, out[1] = slice-per-launch propagation
  * launches (fallback path), out[2] = raymarch launches. Lets tests assert which kernel actually ran. */
 TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
-/* The occlusion cache of the light operators (no counterpart in the reference, invisible in the results). The data
- * sample of the Add / Change shaders (CurrentSample, AddDirLightShader.usf:85-114) does not depend on the light volume,
- * only on the volume, transfer function, window, clip plane and the light's direction. The operators hand it from their
- * occlusion kernels to their propagation kernels through HBM anyway; for a light that is ADDED that hand-off is kept
- * (whole axis passes, nx*ny*nz floats each, least recently used first out, budget = tunable occ_cache_mb, default 16 GiB;
- * 0 turns it off). When the same light is later the REMOVED side of a ChangeDirLight, or is removed, its samples are not
- * recomputed. out[0] = stream-passes served from the cache, out[1] = stream-passes computed, out[2] = entries held,
- * out[3] = their bytes. */
-TBRM_API int tbrm_occlusion_cache_stats(const tbrm_resources* res, uint64_t out[4]);
+/* The contribution cache of the light operators (no counterpart in the reference, invisible in the results). What an
+ * axis pass of the Add / Change shaders does to the light volume is a function of L, the light's propagated value per
+ * voxel (AddDirLightShader.usf:117-126, ChangeDirLightShader.usf:140-154), and L depends on the volume, the transfer
+ * function, the window, the clip plane and the light — not on the light volume. A pass that propagates a light which
+ * stays in the scene keeps its L (nx*ny*nz floats per axis pass, least recently used first out, budget = tunable
+ * light_cache_mb, default 16 GiB; 0 turns the cache off). Later operators on the same light then skip its propagation:
+ * removing it, or adding it again after ClearResourceLightVolumes, applies the kept L; ChangeDirLight propagates only the
+ * NEW light and reads the old one's L. out[0] = stream-passes served from the cache, out[1] = stream-passes propagated,
+ * out[2] = entries held, out[3] = their bytes. */
+TBRM_API int tbrm_light_cache_stats(const tbrm_resources* res, uint64_t out[4]);
 TBRM_API int tbrm_flush(tbrm_resources* res);                 /* FlushRenderingCommands() */
 TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's

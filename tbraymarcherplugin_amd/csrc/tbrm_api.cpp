@@ -32,7 +32,7 @@ thread_local char g_error[512] = "";
 // ---- tunables (tbrm_internal.h): name, default; initialised from TBRM_<NAME> when the library is loaded ------------
 struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
-    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"occ_cache_mb", 16384},
+    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", 16384},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0},
 };
 struct TunableStore {
@@ -1072,16 +1072,14 @@ int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
     return TBRM_OK;
 }
 
-int tbrm_occlusion_cache_stats(const tbrm_resources* r, uint64_t out[4])
+int tbrm_light_cache_stats(const tbrm_resources* r, uint64_t out[4])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    out[0] = r->occ_hits;
-    out[1] = r->occ_misses;
-    out[2] = r->occ_cache.size();
-    uint64_t bytes = 0;
-    for (const OccStore* st : r->occ_cache) // an axis pass covers the light volume once, whichever axis it runs along
-        if (st->base) bytes += ((uint64_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] + 2 * kPlaneGuard) * sizeof(float);
-    out[3] = bytes;
+    out[0] = r->kept_hits;
+    out[1] = r->kept_computed;
+    out[2] = r->kept.size();
+    // an axis pass covers the light volume once, whichever axis it runs along
+    out[3] = (uint64_t) r->kept.size() * ((uint64_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] + 2 * kPlaneGuard) * sizeof(float);
     return TBRM_OK;
 }
 

@@ -12,9 +12,10 @@ enum : int { ADDR_WRAP = 0, ADDR_CLAMP = 1, ADDR_BORDER = 2 };
 
 // what a chunked propagation pass does with its light stream(s): Add (one light, stream a), Change (a added, r removed,
 // ChangeDirLightShader.usf), or two lights added in one pass (a then r: AddDirLightShader.usf twice, sharing the slice loop)
-// PASS_CHANGE_ONE: occlusion launches only — ONE stream of a Change (no Add guard), when the other stream's occlusion
-// factors are already at hand (tbrm_light_passes.cpp, the occlusion cache)
-enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3 };
+// PASS_CHANGE_CACHED: a Change whose removed light's propagated values L are at hand, voxel by voxel (the contribution
+// cache, tbrm_light_passes.cpp): only the added light is propagated, the removed light's L is read. Its occlusion launches
+// run in mode PASS_CHANGE_ONE (ONE stream with the Change shader's rules, i.e. without the Add shader's guard).
+enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3, PASS_CHANGE_CACHED = 4 };
 
 constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
 constexpr int kBrickShift = 3;
@@ -78,6 +79,8 @@ struct ChunkStream {
     const uint8_t* occ_flags; // chain: this stream's empty-block flags from the slice group holding the chunk's first slice on:
                             // [slice group][block y][block x]; null: none (the two streams of a jointly computed pass share one array)
     float* occ_next;        // occlusion launch: where the span's factors 1 - CurrentSample go, [span slices][H][W]
+    float* l_out;           // chain: where the stream's unquantised L of every pixel of the chunk's slices is kept, [chunk slices][H][W]
+                            // (null: not kept). PASS_CHANGE_CACHED: stream r is not propagated — r.occ_base / r.occ_off address its kept L
 };
 
 // Parameters of the chunked propagation kernels (tbrm_light_kernels.hip). One struct serves the per-pass
@@ -197,6 +200,19 @@ struct RelayoutParams {
     int to_bricks; // 1: linear -> bricked (padding voxels are zeroed); 0: bricked -> linear
 };
 
+// k_apply_kept: the light-volume update of one axis pass from kept L values alone (tbrm_light_passes.cpp, contribution cache)
+struct ApplyParams {
+    void* light;            // bricked
+    int lv_dims[3];
+    int lv_bnx, lv_bnxy, lv_bnz;
+    int lv_fmt;
+    int axis, W, H;         // the pass: propagation axis, plane size (TD.X, TD.Y)
+    int start, dir;         // its first slice and direction: plane k of a kept pass is slice start + k*dir
+    const float* la;        // L of the added light (Add / Remove: the light), [pass slices][H][W]
+    const float* lr;        // L of the removed light; null: Add / Remove
+    float b_added;          // Add / Remove: +1 / -1
+};
+
 constexpr int kOccSlices = 8;      // slices per occlusion workgroup (kOccDepth in tbrm_light_kernels.hip)
 constexpr int kChunkTile = 32;      // core tile edge of the chunked propagation kernel (pixels)
 constexpr int kChunkThreads = 1024;
@@ -211,7 +227,7 @@ enum Tunable : int {
     TUNE_OCC_SLICES,         // slices per occlusion span (0: default)
     TUNE_SPARSE_OCC,         // 0: occlusion blocks that can only see empty bricks are computed like the others
     TUNE_OCC_LIST,           // 0: live occlusion blocks keep their grid position instead of being dealt from a work list
-    TUNE_OCC_CACHE_MB,       // HBM budget of the occlusion cache in MiB (0: off): whole-pass occlusion factors kept for reuse
+    TUNE_LIGHT_CACHE_MB,     // HBM budget of the contribution cache in MiB (0: off): a light's propagated values L, kept per axis pass
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
@@ -223,13 +239,14 @@ int tune(Tunable t);
 hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
-size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt);
+size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt);
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s); // + the work lists
 hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
+hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
 hipError_t launch_raymarch_intensity(const RayParams& p, hipStream_t s);
 hipError_t launch_raymarch_octree(const RayParams& p, hipStream_t s);

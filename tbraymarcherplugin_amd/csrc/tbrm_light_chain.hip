@@ -30,7 +30,9 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     constexpr int TX = kChunkTile, TY = kChunkTile, RR = RS;
     constexpr int NT = kChunkThreads;                                    // one thread per tile pixel
     constexpr int BY = TY / 8;                                           // light-volume bricks under the tile along v (4 along u)
-    constexpr int NS = MODE != PASS_ADD ? 2 : 1;
+    constexpr bool CACHED = MODE == PASS_CHANGE_CACHED;                  // the removed light's L is read, not propagated
+    constexpr int NS = (MODE == PASS_ADD || CACHED) ? 1 : 2;             // streams propagated (windows)
+    constexpr int NR = MODE == PASS_ADD ? 1 : 2;                         // planes staged per slice: occlusion factors, or (CACHED) factors + L
     constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KS = 1 + KH; // + the owned pixel
     constexpr int PLANE = chain_plane_elems(RS);
@@ -50,18 +52,18 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
     const int base_x = tile_x * TX, base_y = (p.tile_row0 + tile_y) * TY;
 
-    // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, ring slot q at ((2 + q)*NS + si)*PLANE; then the
-    // light-volume tile (bytes)
+    // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, staged plane si of ring slot q at (2*NS + q*NR + si)*PLANE;
+    // then the light-volume tile (bytes)
     float* const lds = (float*) smem;
-    uint8_t* const lv_tile = (uint8_t*) (lds + (2 + kOccRing) * NS * PLANE);
+    uint8_t* const lv_tile = (uint8_t*) (lds + (2 * NS + kOccRing * NR) * PLANE);
     auto window = [&](int w, int si) -> float* { return lds + (w * NS + si) * PLANE; };
-    auto ring = [&](int q, int si) -> float* { return lds + ((2 + q) * NS + si) * PLANE; };
+    auto ring = [&](int q, int si) -> float* { return lds + (2 * NS + q * NR + si) * PLANE; };
 
     // ---- 16-byte staging pattern: copy group i = floats [4i, 4i+4) of an LDS plane = 4 pixels of one hull row ------
     int st_src[ROUNDS];   // pixel index of the group's first pixel inside a plane (may run off the row ends: guard bands)
     bool st_ok[ROUNDS];
     int st_dst[ROUNDS];   // this wave's 64 x 4 floats
-    bool st_one[NS][ROUNDS][2] = {}; // the group's 4 pixels lie in blocks of slice group 0 / 1 of the chunk that are empty for the stream
+    bool st_one[NR][ROUNDS][2] = {}; // the group's 4 pixels lie in blocks of slice group 0 / 1 of the chunk that are empty for the stream
     int ndma = 0;         // copies this WAVE issues per staged slice (wave-uniform)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -71,18 +73,18 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         st_src[rd] = py * p.W + base_x - g.padx + col;
         st_ok[rd] = gi < GROUPS && row < g.HY && col < g.HX && (unsigned) py < (unsigned) p.H;
         st_dst[rd] = (wave * 64 + rd * NT) * 4;
-        if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NS;
+        if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NR;
         // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: their factor 1 - 0 is staged from
         // a page of ones
         if (st_ok[rd]) {
             const int x_first = base_x - g.padx + col, x_last = x_first + 3;
             const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = py >> 4;
 #pragma unroll
-            for (int si = 0; si < NS; ++si) {
+            for (int si = 0; si < NR; ++si) {
                 const uint8_t* flags = si == 0 ? p.a.occ_flags : p.r.occ_flags;
                 if (!flags) continue;
-                if constexpr (NS == 2)
-                    if (si == 1 && flags == p.a.occ_flags) { st_one[NS - 1][rd][0] = st_one[0][rd][0]; st_one[NS - 1][rd][1] = st_one[0][rd][1]; continue; } // computed jointly
+                if constexpr (NR == 2)
+                    if (si == 1 && flags == p.a.occ_flags) { st_one[NR - 1][rd][0] = st_one[0][rd][0]; st_one[NR - 1][rd][1] = st_one[0][rd][1]; continue; } // computed jointly
 #pragma unroll
                 for (int z = 0; z < 2; ++z) {
                     bool one = x_last >= 0 && x_first < p.W && z * kOccSlices < p.occ_phase + g.n;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if (!st_ok[rd]) continue;
             const uint32_t px = (uint32_t) (sf * plane_elems + st_src[rd]);
 #pragma unroll
-            for (int si = 0; si < NS; ++si) {
+            for (int si = 0; si < NR; ++si) {
                 const ChunkStream& s = si == 0 ? p.a : p.r;
                 const bool one = group == 0 ? st_one[si][rd][0] : st_one[si][rd][1];
                 const uint32_t off = one ? (uint32_t) lane * 4u : s.occ_off + px;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         // issued after a write would wait for it: issued up front, their latencies overlap instead of adding up)
         bool act[KS];
         float t00[KS][NS], t01[KS][NS], t10[KS][NS], t11[KS][NS], fac[KS][NS];
-        float lv_old = 0.0f;
+        float lv_old = 0.0f, l_removed = 0.0f;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             act[k] = r >= rmin[k];
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if (k == 0) {
                 if constexpr (LV_LDS) lv_old = decode_u8(lv_tile[vi]);
                 else lv_old = load_voxel<LFMT>(p.light, vi);
+                if constexpr (CACHED) l_removed = ring(q, 1)[li[0]]; // the removed light's L of this voxel, as its own pass left it
             }
         }
 #pragma unroll
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 bool write;
                 if constexpr (MODE == PASS_ADD) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; } // :123-126
                 else if constexpr (MODE == PASS_CHANGE) { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; } // Change :152-154
+                else if constexpr (CACHED) { nv = lv_old + lval[0] - l_removed; write = fabsf(lval[0] - l_removed) > 1e-3f; }
                 else { // two lights added in one pass: light a's read-modify-write, then light r's on its result (:123-126 twice)
                     const bool wa = fabsf(lval[0]) > 1e-3f, wb = fabsf(lval[NS - 1]) > 1e-3f;
                     nv = wa ? through_format<LFMT>(lv_old + lval[0] * p.b_added) : lv_old;
@@ -315,6 +319,11 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 if (r == 0) {
 #pragma unroll
                     for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[own_idx] = through_format<LFMT>(lval[si]);
+                }
+#pragma unroll
+                for (int si = 0; si < NS; ++si) { // the contribution cache keeps what this light adds to every voxel
+                    float* const keep = (si == 0 ? p.a : p.r).l_out;
+                    if (keep) keep[(size_t) s * plane_elems + own_idx] = lval[si];
                 }
             }
         }
@@ -360,7 +369,7 @@ static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
     constexpr int LFMT = TBRM_CHAIN_LFMT;
     static std::atomic<uint64_t> attr_done{0};
     if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS>, attr_done, 160 * 1024); e != hipSuccess) return e;
-    const size_t lds = chunk_lds_bytes(p, MODE != PASS_ADD, LFMT);
+    const size_t lds = chunk_lds_bytes(p, MODE, LFMT);
     hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
@@ -373,7 +382,10 @@ static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
     const ChunkGeom g = chunk_geometry(p);
     const int halo = g.HX * g.HY - kChunkTile * kChunkTile;
     const int kh = (halo + kChunkThreads - 1) / kChunkThreads; // <= 3 for hulls up to 64 x 64
-    if constexpr (MODE != PASS_ADD) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
+    if constexpr (MODE == PASS_CHANGE_CACHED) { // one stream propagated, two planes staged: the Add's kernels up to RS 56
+        if (g.RS == 40) return launch_chain4<MODE, AXIS, 1, 40>(p, s);
+        if (g.RS == 56) return launch_chain4<MODE, AXIS, 3, 56>(p, s);
+    } else if constexpr (MODE != PASS_ADD) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
         if (g.RS == 40) return launch_chain4<MODE, AXIS, 1, 40>(p, s);
         if (g.RS == 56) {
             if (kh <= 1) return launch_chain4<MODE, AXIS, 1, 56>(p, s);
@@ -399,7 +411,8 @@ hipError_t launch_light_chain_u8(const ChunkParams& p, int mode, hipStream_t s)
 hipError_t launch_light_chain_f32(const ChunkParams& p, int mode, hipStream_t s)
 #endif
 {
-    return mode == PASS_ADD ? launch_chain2<PASS_ADD>(p, s) : (mode == PASS_CHANGE ? launch_chain2<PASS_CHANGE>(p, s) : launch_chain2<PASS_ADD2>(p, s));
+    return mode == PASS_ADD ? launch_chain2<PASS_ADD>(p, s)
+           : (mode == PASS_CHANGE ? launch_chain2<PASS_CHANGE>(p, s) : (mode == PASS_ADD2 ? launch_chain2<PASS_ADD2>(p, s) : launch_chain2<PASS_CHANGE_CACHED>(p, s)));
 }
 
 } // namespace tbrm

@@ -122,19 +122,66 @@ hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t 
     }
 }
 
+// ---- k_apply_kept: an axis pass whose propagated values are all at hand --------------------------------------------------
+// What an axis pass does to the light volume is a function of L, the light's propagated value per voxel, alone
+// (AddDirLightShader.usf:123-126: LV += L * bAdded where |L| > 1e-3; ChangeDirLightShader.usf:152-154: LV += La - Lr where
+// |La - Lr| > 1e-3). When the pass that computed L kept it (ChunkStream::l_out), a later pass over the same light — its
+// removal, a re-add after a reset, the removed side of a ChangeDirLight — needs no propagation: one thread per voxel of the
+// bricked light volume (coalesced read-modify-write) looks its L up in the kept pass's plane order and applies the same
+// arithmetic.
+template <int LFMT, bool CHANGE>
+__global__ __launch_bounds__(256) void k_apply_kept(const ApplyParams p)
+{
+    const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b = (uint32_t) (t >> 9), o = (uint32_t) t & 511u;
+    const int bny = p.lv_bnxy / p.lv_bnx;
+    if (b >= (uint32_t) (p.lv_bnxy * p.lv_bnz)) return;
+    const int x = (int) (b % (uint32_t) p.lv_bnx) * 8 + (int) (o & 7u);
+    const int y = (int) ((b / (uint32_t) p.lv_bnx) % (uint32_t) bny) * 8 + (int) ((o >> 3) & 7u);
+    const int z = (int) (b / (uint32_t) p.lv_bnxy) * 8 + (int) (o >> 6);
+    if (x >= p.lv_dims[0] || y >= p.lv_dims[1] || z >= p.lv_dims[2]) return; // padding voxels of the last bricks
+    int j, px, py; // slice and plane pixel of the voxel (the permutation of k_propagate_slice)
+    if (p.axis == 0) { j = x; px = y; py = z; } else if (p.axis == 1) { j = y; px = x; py = z; } else { j = z; px = x; py = y; }
+    const size_t li = ((size_t) ((j - p.start) * p.dir) * p.H + py) * (size_t) p.W + px;
+    const float la = p.la[li];
+    if constexpr (!CHANGE) {
+        if (fabsf(la) > 1e-3f) store_voxel<LFMT>(p.light, t, load_voxel<LFMT>(p.light, t) + (la * p.b_added));
+    } else {
+        const float lr = p.lr[li];
+        if (fabsf(la - lr) > 1e-3f) store_voxel<LFMT>(p.light, t, load_voxel<LFMT>(p.light, t) + la - lr);
+    }
+}
+
+hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s)
+{
+    const size_t n = (size_t) p.lv_bnxy * p.lv_bnz * 512;
+    if (n == 0) return hipSuccess;
+    const dim3 grid((unsigned) ((n + 255) / 256)), block(256);
+    const bool change = p.lr != nullptr;
+    if (p.lv_fmt == FMT_U8) {
+        if (change) hipLaunchKernelGGL((k_apply_kept<FMT_U8, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((k_apply_kept<FMT_U8, false>), grid, block, 0, s, p);
+    } else {
+        if (change) hipLaunchKernelGGL((k_apply_kept<FMT_F32, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((k_apply_kept<FMT_F32, false>), grid, block, 0, s, p);
+    }
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // a chunk of slices per launch pair
 
 // LDS bytes of a chain workgroup; 1 GiB when no instantiated kernel shape holds the chunk's hull
-// (tbrm_light_chain.hip launch_chain3 lists the shapes: Change runs RS 40/56 — two streams of 72 x 72 planes exceed the
-// LDS — Add RS 40/56/72)
-size_t chunk_lds_bytes(const ChunkParams& p, bool change, int lv_fmt)
+// (tbrm_light_chain.hip launch_chain3 lists the shapes: everything but a plain Add runs RS 40/56 — ten or eight 72 x 72
+// planes exceed the LDS — an Add RS 40/56/72)
+size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
-    if (g.RS == 0 || (change && g.RS > 56)) return (size_t) 1 << 30;
-    const int ns = change ? 2 : 1;
-    size_t total = (size_t) ns * (2 + kOccRing) * chain_plane_elems(g.RS) * 4; // windows + staged occlusion ring
-    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;             // light-volume tile
+    const int ns = (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2; // streams propagated
+    const int nr = mode == PASS_ADD ? 1 : 2;                                  // planes staged per slice
+    if (g.RS == 0 || (mode != PASS_ADD && g.RS > 56)) return (size_t) 1 << 30;
+    size_t total = (size_t) (2 * ns + kOccRing * nr) * chain_plane_elems(g.RS) * 4; // windows + staged ring
+    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;                // light-volume tile
     return total;
 }
 

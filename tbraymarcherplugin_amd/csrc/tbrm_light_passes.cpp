@@ -65,8 +65,9 @@ int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; 
 
 // Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
 // 16/8/4/2 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
-bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit)
+bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit, int mode)
 {
+    if (mode < 0) mode = pr ? PASS_CHANGE : PASS_ADD; // (PASS_ADD2 has PASS_CHANGE's shapes)
     g_plan_note = "";
     if (force_slice_kernel()) return declined("the force_slice_kernel tunable is set"), false;
     const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
@@ -97,7 +98,7 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         if (chunk_steps_override() > 0 && cand != chunk_steps_override()) continue;
         if (cand == 16 && many_tiles && chunk_steps_override() == 0) continue;
         p.n_steps = std::min(cand, D_pass);
-        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, pr != nullptr, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
+        if (kChunkTile + cand * g <= kChunkMaxHull && chunk_lds_bytes(p, mode, r->lv_fmt) <= 156 * 1024) { fit.M = cand; break; }
     }
     if (fit.M <= 0) return declined("the previous-slice taps reach too far for a 2-slice chunk"), false;
     fit.tx = tx;
@@ -212,21 +213,21 @@ static SpanRange span_range(const PassPlan& plan, int sp)
     return q;
 }
 
-// ---- occlusion stores (tbrm_resources.h OccStore) ----------------------------------------------------------------------
-
-static void free_store(OccStore* st)
-{
-    (void) hipFree(st->base);
-    (void) hipFree(st->flags);
-    (void) hipFree(st->list);
-    *st = OccStore{};
-}
+// ---- occlusion stores and the contribution cache (tbrm_resources.h) ----------------------------------------------------
 
 void release_occ_stores(tbrm_resources* r)
 {
-    for (OccStore& st : r->occ_tmp) free_store(&st);
-    for (OccStore* st : r->occ_cache) { free_store(st); delete st; }
-    r->occ_cache.clear();
+    for (OccStore& st : r->occ_tmp) {
+        (void) hipFree(st.base);
+        (void) hipFree(st.flags);
+        (void) hipFree(st.list);
+        st = OccStore{};
+    }
+    for (KeptPass* e : r->kept) {
+        (void) hipFree(e->base);
+        delete e;
+    }
+    r->kept.clear();
 }
 
 // room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass
@@ -256,9 +257,9 @@ static int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slic
     return TBRM_OK;
 }
 
-static OccKey occ_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard, const PassPlan& plan)
+static KeptKey kept_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard)
 {
-    OccKey k;
+    KeptKey k;
     memset(&k, 0, sizeof(k)); // compared bytewise
     k.data_gen = r->data_gen;
     k.tf_gen = r->tf_gen;
@@ -266,89 +267,60 @@ static OccKey occ_key(const tbrm_resources* r, const PropParams& base, const tbr
     for (int c = 0; c < 3; ++c) { k.cc[c] = base.cc[c]; k.cd[c] = base.cd[c]; k.uvw_off[c] = q.uvw_offset[c]; }
     k.data_border = base.data_border;
     k.clip_mode = base.clip_mode;
-    k.axis = q.axis; k.dir = plan.dir; k.start = plan.start; k.D = plan.D; k.W = plan.p.W; k.H = plan.p.H; k.S = plan.S;
+    k.axis = q.axis; k.dir = q.dir; k.start = q.start; k.D = q.td[2]; k.W = q.td[0]; k.H = q.td[1];
     k.guard = guard ? 1 : 0;
-    k.sparse = plan.sparse ? 1 : 0;
-    k.work_list = plan.work_list ? 1 : 0;
     k.step100 = q.step_size * 100.0f;
+    k.prev_off[0] = q.prev_pixel_offset[0]; k.prev_off[1] = q.prev_pixel_offset[1];
+    k.light_alpha = q.light_alpha;
+    k.border_light = q.border_light;
     return k;
 }
 
-static OccStore* cache_find(tbrm_resources* r, const OccKey& key)
+static size_t kept_elems(const tbrm_resources* r) { return (size_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] + 2 * kPlaneGuard; }
+
+static KeptPass* kept_find(tbrm_resources* r, const KeptKey& key)
 {
-    for (OccStore* st : r->occ_cache)
-        if (st->valid && !memcmp(&st->key, &key, sizeof(key))) return st;
+    for (KeptPass* e : r->kept)
+        if (e->valid && !memcmp(&e->key, &key, sizeof(key))) return e;
     return nullptr;
 }
 
-// A store for a new cache entry: a fresh one while the budget lasts, else the least recently used one that the operator
-// being planned does not use. null: the cache is off or full of pinned entries.
-static OccStore* cache_new(tbrm_resources* r, size_t entry_bytes)
+// An entry for a pass about to be propagated: a fresh allocation while the budget (light_cache_mb) lasts, else the least
+// recently used entry that the operator being planned does not use. null: the cache is off, or full of pinned entries.
+static KeptPass* kept_new(tbrm_resources* r, const KeptKey& key)
 {
-    const size_t budget = (size_t) std::max(tune(TUNE_OCC_CACHE_MB), 0) << 20;
-    if (entry_bytes == 0 || entry_bytes > budget) return nullptr;
-    if ((r->occ_cache.size() + 1) * entry_bytes <= budget) {
-        r->occ_cache.push_back(new OccStore{});
-        return r->occ_cache.back();
+    const size_t budget = (size_t) std::max(tune(TUNE_LIGHT_CACHE_MB), 0) << 20, bytes = kept_elems(r) * sizeof(float);
+    KeptPass* e = nullptr;
+    if (bytes > budget) return nullptr;
+    if ((r->kept.size() + 1) * bytes <= budget) {
+        e = new KeptPass{};
+        if (hipMalloc((void**) &e->base, bytes) != hipSuccess) { // out of HBM: do without
+            (void) hipGetLastError();
+            delete e;
+            return nullptr;
+        }
+        r->kept.push_back(e);
+    } else {
+        for (KeptPass* c : r->kept)
+            if (!c->pinned && (!e || c->last_use < e->last_use)) e = c;
+        if (!e) return nullptr;
     }
-    OccStore* victim = nullptr;
-    for (OccStore* st : r->occ_cache)
-        if (!st->pinned && (!victim || st->last_use < victim->last_use)) victim = st;
-    if (victim) victim->valid = false;
-    return victim;
+    e->valid = false;
+    e->key = key;
+    e->pinned = true;
+    e->last_use = ++r->kept_clock;
+    return e;
 }
 
-// Where the occlusion factors of the plan's stream(s) live and who computes them.
-static int plan_occlusion(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, bool slab,
-                          PassPlan& plan)
+static void use_kept(tbrm_resources* r, KeptPass* e)
 {
-    const ChunkParams& p = plan.p;
-    const size_t slice_elems = (size_t) p.W * p.H;
-    const size_t flag_bytes = plan.sparse ? plan.flags_per_span * plan.n_spans : 0;
-    const int ns = plan.two_streams() ? 2 : 1;
-    // A whole pass in one store: an Add, or the streams of a Change (not a slab's share of a pass, not a paired Add, whose
-    // second stream differs from a lone Add's only in bookkeeping but whose flags are joint). The chain addresses a
-    // store's planes with 32-bit offsets, and a cached store written with blocks flagged empty left out is only good for
-    // a pass that can use the flags in every span.
-    bool all_spans_sparse = plan.sparse;
-    for (int sp = 0; sp < plan.n_spans && all_spans_sparse; ++sp) all_spans_sparse = span_range(plan, sp).sparse;
-    const size_t entry_elems = (size_t) plan.D * slice_elems + 2 * kPlaneGuard;
-    const bool cacheable = !slab && plan.mode != PASS_ADD2 && tune(TUNE_OCC_CACHE_MB) > 0 && entry_elems * sizeof(float) < ((size_t) 1 << 32) &&
-                           (all_spans_sparse || !plan.sparse);
-    const tbrm_light_pass* q[2] = {&pa, pr};
-    for (int si = 0; si < ns; ++si) {
-        OccStore* st = nullptr;
-        bool compute = true;
-        if (cacheable) {
-            const OccKey key = occ_key(r, base, *q[si], plan.mode == PASS_ADD, plan);
-            st = cache_find(r, key);
-            if (st) compute = false;
-            else if (si == 0 || plan.mode == PASS_ADD) { // what is added stays in the scene: worth keeping. What is removed is not.
-                st = cache_new(r, entry_elems * sizeof(float));
-                if (st) {
-                    if (int e = ensure_store(r, st, plan.D, slice_elems, flag_bytes)) return e;
-                    st->key = key;
-                }
-            }
-            if (st) {
-                st->pinned = true;
-                st->last_use = ++r->occ_clock;
-            }
-        }
-        if (!st) {
-            st = &r->occ_tmp[si];
-            if (int e = ensure_store(r, st, plan.S, slice_elems, flag_bytes)) return e;
-        }
-        plan.occ[si] = st;
-        plan.occ_compute[si] = compute;
-        ++(compute ? r->occ_misses : r->occ_hits);
-    }
-    return TBRM_OK;
+    e->pinned = true;
+    e->last_use = ++r->kept_clock;
 }
 
-static void unpin_occ_stores(tbrm_resources* r)
+static void unpin_kept(tbrm_resources* r)
 {
-    for (OccStore* st : r->occ_cache) st->pinned = false;
+    for (KeptPass* e : r->kept) e->pinned = false;
 }
 
 // pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
@@ -357,15 +329,65 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode, float b_added2)
 {
     g_plan_note = "";
-    ChunkFit fit;
-    if (!chunk_fit(r, pa, pr, fit)) {
-        if (!slab || two_stream_mode == PASS_ADD2) return TBRM_ERR_UNSUPPORTED;
-        return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
-    }
     const bool change = pr != nullptr;
+    int mode = change ? two_stream_mode : PASS_ADD;
+    // Contribution cache (tbrm_resources.h KeptPass): is this light's L — and, for a Change, the removed light's — at hand?
+    // Whole, unpartitioned passes only; the chain addresses the removed light's L with 32-bit offsets.
+    KeptPass *have_a = nullptr, *have_r = nullptr;
+    const bool cache_on = !slab && mode != PASS_ADD2 && !force_slice_kernel() && tune(TUNE_LIGHT_CACHE_MB) > 0 &&
+                          kept_elems(r) * sizeof(float) < ((size_t) 1 << 34) && kept_elems(r) < ((size_t) 1 << 32);
+    KeptKey key_a{};
+    if (cache_on) {
+        key_a = kept_key(r, base, pa, mode == PASS_ADD);
+        have_a = kept_find(r, key_a);
+        if (change) have_r = kept_find(r, kept_key(r, base, *pr, false));
+    }
+    if (have_a && (!change || have_r)) { // nothing to propagate: one k_apply_kept launch
+        plan = PassPlan{};
+        plan.mode = mode;
+        plan.apply = true;
+        plan.kept_a = have_a;
+        plan.kept_r = change ? have_r : nullptr;
+        plan.apply_b = b_added;
+        plan.p.axis = pa.axis;
+        plan.p.W = pa.td[0];
+        plan.p.H = pa.td[1];
+        plan.start = pa.start;
+        plan.dir = pa.dir;
+        plan.D = pa.td[2];
+        plan.n_chunks = 1;
+        plan.chunks_of_pass = 1;
+        use_kept(r, have_a);
+        if (have_r) use_kept(r, have_r);
+        r->kept_hits += change ? 2 : 1;
+        return TBRM_OK;
+    }
+    if (change && have_r) mode = PASS_CHANGE_CACHED; // only the new light is propagated; its windows follow its taps alone
+    ChunkFit fit;
+    if (!chunk_fit(r, pa, mode == PASS_CHANGE_CACHED ? nullptr : pr, fit, mode)) {
+        if (mode == PASS_CHANGE_CACHED) { // (an Add-sized hull that the cached shapes lack: propagate both lights)
+            mode = two_stream_mode;
+            have_r = nullptr;
+            if (!chunk_fit(r, pa, pr, fit, mode)) {
+                if (!slab) return TBRM_ERR_UNSUPPORTED;
+                return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
+            }
+        } else {
+            if (!slab || two_stream_mode == PASS_ADD2) return TBRM_ERR_UNSUPPORTED;
+            return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
+        }
+    }
     const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
     plan = PassPlan{};
-    plan.mode = change ? two_stream_mode : PASS_ADD;
+    plan.mode = mode;
+    if (mode == PASS_CHANGE_CACHED) {
+        plan.kept_r = have_r;
+        use_kept(r, have_r);
+        ++r->kept_hits;
+    }
+    // what is added stays in the scene: its L is worth keeping (null: no room). What is removed does not.
+    if (cache_on && !have_a && !(mode == PASS_ADD && b_added < 0.0f)) plan.keep[0] = kept_new(r, key_a);
+    r->kept_computed += (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2;
     ChunkParams& p = plan.p;
     p.data = base.data;
     p.data_border = base.data_border;
@@ -382,7 +404,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     p.b_added = b_added;
     p.b_added2 = b_added2;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
-    if (change) fill_chunk_stream(p.r, *pr, r->lv_fmt);
+    if (change && mode != PASS_CHANGE_CACHED) fill_chunk_stream(p.r, *pr, r->lv_fmt);
     const int M = fit.M;
     plan.M = M;
 
@@ -474,7 +496,11 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
         p.pass_slices = D;
         p.chunk_slices = S;
     }
-    return plan_occlusion(r, base, pa, pr, slab != nullptr, plan);
+    // the occlusion stores of the stream(s) this pass propagates
+    const size_t flag_bytes = plan.sparse ? plan.flags_per_span * plan.n_spans : 0;
+    for (int si = 0; si < (plan.two_streams() ? 2 : 1); ++si)
+        if (int e = ensure_store(r, &r->occ_tmp[si], S, slice_elems, flag_bytes)) return e;
+    return TBRM_OK;
 }
 
 // The plane holding the propagated light of stream `si` (0: a, 1: r) BEFORE chunk `boundary` (boundary = n_chunks: after
@@ -503,74 +529,69 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
         ++r->launches[1];
         return TBRM_OK;
     }
+    if (plan.apply) { // every L of the pass is at hand: the light-volume update alone
+        ApplyParams ap{};
+        ap.light = r->d_light;
+        for (int k = 0; k < 3; ++k) ap.lv_dims[k] = r->lv_dims[k];
+        ap.lv_bnx = r->lbn[0]; ap.lv_bnxy = r->lbn[0] * r->lbn[1]; ap.lv_bnz = r->lbn[2];
+        ap.lv_fmt = r->lv_fmt;
+        ap.axis = plan.p.axis; ap.W = plan.p.W; ap.H = plan.p.H;
+        ap.start = plan.start; ap.dir = plan.dir;
+        ap.la = plan.kept_a->base + kPlaneGuard;
+        ap.lr = plan.kept_r ? plan.kept_r->base + kPlaneGuard : nullptr;
+        ap.b_added = plan.apply_b;
+        HIP_TRY(launch_apply_kept(ap, r->stream));
+        ++r->launches[0];
+        return TBRM_OK;
+    }
     ChunkParams p = plan.p;
     const int M = plan.M, D = plan.D, W = p.W, H = p.H;
     const int sp = (c * M) / plan.S;
     const SpanRange q = span_range(plan, sp);
     const size_t slice_elems = (size_t) W * H;
-    const int ns = plan.two_streams() ? 2 : 1;
-    // streams that are both computed are computed by one launch and share the first one's flags
-    const bool joint = ns == 2 && plan.occ_compute[0] && plan.occ_compute[1];
-    OccStore* const flag_store[2] = {plan.occ[0], joint ? plan.occ[0] : plan.occ[1]};
-    auto cached = [&](int si) { return plan.occ[si] != &r->occ_tmp[si]; };
-    // float offset, inside its store, of the plane of slice number `k` of the pass (a cached store holds the whole pass, a
-    // transient one the current span)
-    auto plane_off = [&](int si, int k) { return (size_t) kPlaneGuard + (size_t) (cached(si) ? k : k - q.s0) * slice_elems; };
-    ChunkStream* const streams[2] = {&p.a, &p.r};
-
-    // One occlusion launch computes stream si alone (as the kernel's stream a) or, si < 0, both streams of the plan.
-    auto occlusion_launch = [&](int si, bool flags_of_pass) -> int {
-        ChunkParams o = p;
-        int mode = plan.mode;
-        if (si >= 0 && ns == 2) { // one stream of a Change on its own
-            mode = PASS_CHANGE_ONE;
-            if (si == 1) o.a = p.r;
-        }
-        const int first = si < 0 ? 0 : si;
-        OccStore* const fs = flag_store[first];
-        int* const counts = (int*) (fs->list + fs->flag_bytes);
-        if (flags_of_pass) {
-            o.occ_flags_out = fs->flags;
-            o.occ_list_out = plan.work_list ? fs->list : nullptr;
-            o.occ_count_out = counts;
-            HIP_TRY(launch_occ_flags(o, mode, plan.n_spans, r->stream));
-            return TBRM_OK;
-        }
-        o.j0 = plan.start + q.s0 * plan.dir;
-        o.n_steps = q.sn;
-        o.a.occ_next = plan.occ[first]->base + plane_off(first, q.s0);
-        if (si < 0 && ns == 2) o.r.occ_next = plan.occ[1]->base + plane_off(1, q.s0);
-        o.occ_flags = nullptr;
-        o.occ_list = q.sparse && plan.work_list ? fs->list + (size_t) sp * plan.flags_per_span : nullptr;
-        o.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
-        if (q.sparse && !plan.work_list) o.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
-        HIP_TRY(launch_light_occlusion(o, mode, r->stream));
-        return TBRM_OK;
-    };
-    for (int phase = 0; phase < 2; ++phase) { // 0: the pass's flags and work lists (before its first chunk), 1: the span's occlusion
-        if (phase == 0 ? !(c == 0 && plan.sparse) : c != q.c0) continue;
-        if (joint || (ns == 1 && plan.occ_compute[0])) {
-            if (int e = occlusion_launch(-1, phase == 0)) return e;
-        } else {
-            for (int si = 0; si < ns; ++si)
-                if (plan.occ_compute[si])
-                    if (int e = occlusion_launch(si, phase == 0)) return e;
-        }
+    const int ns = plan.n_streams();
+    // the propagated streams' occlusion: one launch per span computes both (a block is flagged empty when it is empty for
+    // both), or the added light alone with the Change shader's rules when the removed light's L is kept
+    const int occ_mode = plan.mode == PASS_CHANGE_CACHED ? PASS_CHANGE_ONE : plan.mode;
+    OccStore* const fs = &r->occ_tmp[0];
+    int* const counts = (int*) (fs->list + fs->flag_bytes);
+    p.a.occ_next = r->occ_tmp[0].base + kPlaneGuard;
+    p.r.occ_next = ns == 2 ? r->occ_tmp[1].base + kPlaneGuard : nullptr;
+    if (c == 0 && plan.sparse) {
+        p.occ_flags_out = fs->flags;
+        p.occ_list_out = plan.work_list ? fs->list : nullptr;
+        p.occ_count_out = counts;
+        HIP_TRY(launch_occ_flags(p, occ_mode, plan.n_spans, r->stream));
     }
-    if (c == q.c0 && sp == plan.n_spans - 1) // a cached store is complete once its last span is on the stream
-        for (int si = 0; si < ns; ++si)
-            if (cached(si) && plan.occ_compute[si]) plan.occ[si]->valid = true;
-
+    if (c == q.c0) { // occlusion of the span: fills {a,r}.occ_next with sn planes
+        p.j0 = plan.start + q.s0 * plan.dir;
+        p.n_steps = q.sn;
+        p.occ_flags = nullptr;
+        p.occ_list = q.sparse && plan.work_list ? fs->list + (size_t) sp * plan.flags_per_span : nullptr;
+        p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
+        if (q.sparse && !plan.work_list) p.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
+        HIP_TRY(launch_light_occlusion(p, occ_mode, r->stream));
+    }
     const int k0 = c * M - q.s0; // first slice of the chunk within the span
     p.n_steps = std::min(M, D - c * M);
     p.j0 = plan.start + c * M * plan.dir;
     p.first_chunk = c == 0 && plan.pass_begins_here;
     p.a.plane_in = plan_plane(r, c, 0); p.a.plane_out = plan_plane(r, c + 1, 0);
     p.r.plane_in = plan_plane(r, c, 1); p.r.plane_out = plan_plane(r, c + 1, 1);
+    ChunkStream* const streams[2] = {&p.a, &p.r};
+    const uint8_t* const chunk_flags = q.sparse ? fs->flags + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
     for (int si = 0; si < ns; ++si) {
-        streams[si]->occ_base = plan.occ[si]->base;
-        streams[si]->occ_off = (uint32_t) plane_off(si, q.s0 + k0);
-        streams[si]->occ_flags = q.sparse ? flag_store[si]->flags + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
+        streams[si]->occ_base = r->occ_tmp[si].base;
+        streams[si]->occ_off = (uint32_t) (kPlaneGuard + (size_t) k0 * slice_elems);
+        streams[si]->occ_flags = chunk_flags;
+        // the contribution cache keeps L in pass order: plane k of an entry is the pass's k-th slice
+        streams[si]->l_out = plan.keep[si] ? plan.keep[si]->base + kPlaneGuard + (size_t) c * M * slice_elems : nullptr;
+    }
+    if (plan.mode == PASS_CHANGE_CACHED) { // the removed light's L is staged like a second plane of occlusion factors (no flags)
+        p.r.occ_base = plan.kept_r->base;
+        p.r.occ_off = (uint32_t) (kPlaneGuard + (size_t) c * M * slice_elems);
+        p.r.occ_flags = nullptr;
+        p.r.l_out = nullptr;
     }
     p.occ_phase = k0 % kOccSlices;
     p.occ_list = nullptr;
@@ -578,6 +599,9 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
     p.occ_flags = nullptr;
     HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
     ++r->launches[0];
+    if (c == plan.n_chunks - 1) // an entry is complete once the last chunk that fills it is on the stream
+        for (int si = 0; si < ns; ++si)
+            if (plan.keep[si]) plan.keep[si]->valid = true;
     return TBRM_OK;
 }
 
@@ -661,9 +685,9 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             continue;
         }
         for (int c = 0; c < plans[i].n_chunks; ++c)
-            if (int e = enqueue_plan_chunk(r, plans[i], c)) { unpin_occ_stores(r); return e; }
+            if (int e = enqueue_plan_chunk(r, plans[i], c)) { unpin_kept(r); return e; }
     }
-    unpin_occ_stores(r);
+    unpin_kept(r);
     return TBRM_OK;
 }
 

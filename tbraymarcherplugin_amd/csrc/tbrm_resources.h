@@ -28,31 +28,36 @@ inline size_t format_bytes(int fmt) { return fmt == TBRM_FMT_G8 ? 1 : (fmt == TB
                 #expr, hipGetErrorString(e_));                                                                \
     } while (0)
 
-// The occlusion factors 1 - CurrentSample (AddDirLightShader.usf:85-117) of ONE light stream of an axis pass, as the chain
-// kernel consumes them: [page of ones | guard][slices x H x W floats][guard], plus the pass's empty-block flags and work
-// lists. Two kinds:
-//   transient   a span of S slices, overwritten span by span (tbrm_resources::occ_tmp, one per stream);
-//   cached      the WHOLE pass, kept under a key (everything the factors depend on: volume / TF generation, window, clip
-//               plane, the stream's axis, direction, UVW offset and step size, Add guard on / off). The next operator that
-//               needs the same stream — the removed light of a ChangeDirLight is the light an earlier Add / Change put
-//               there; a removed light was once added — takes them from here instead of recomputing them: the hand-off
-//               the chain reads anyway is simply not thrown away (no extra traffic).
-struct OccKey {
-    uint64_t data_gen, tf_gen;
-    float win[4];
-    float cc[3], cd[3], data_border;
-    int32_t clip_mode, axis, dir, start, D, W, H, S, guard, sparse, work_list;
-    float uvw_off[3], step100;
-};
+// The occlusion factors 1 - CurrentSample (AddDirLightShader.usf:85-117) of ONE light stream for a span of S slices of an
+// axis pass, as the chain kernel consumes them: [page of ones | guard][S x H x W floats][guard], plus the pass's
+// empty-block flags and work lists. Overwritten span by span.
 struct OccStore {
     float* base = nullptr;          // the allocation
     size_t capacity = 0;            // floats of planes it holds (slices x H x W of the pass it was sized for)
     uint8_t* flags = nullptr;       // empty-block flags of the pass: [span][slice group][block y][block x]
     uint32_t* list = nullptr;       // work lists of the pass (one uint32 per flag) followed by 4096 per-span counts
     size_t flag_bytes = 0;
-    // cached stores
-    OccKey key{};
-    bool valid = false;             // every span has been enqueued
+};
+
+// The contribution cache: what ONE light adds to every voxel of the light volume in ONE of its axis passes — L, the
+// propagated value before it is quantised into the read/write buffers — kept as [guard][pass slices x H x W floats][guard]
+// under a key that holds everything L depends on (volume / transfer-function generation, window, clip plane, the pass's
+// axis, direction, offsets, step size, initial and border light, and which shader's rules produced it). What an axis pass
+// does to the light volume is a function of L alone, so a later pass over the same light needs no propagation: a removal
+// or a re-add applies the kept L (k_apply_kept), and a ChangeDirLight propagates only the NEW light and reads the old
+// one's L (PASS_CHANGE_CACHED). This is the Sunden / Ropinski selective update taken one step further than the reference
+// takes it: the reference recomputes the removed light; here a light is propagated once.
+struct KeptKey {
+    uint64_t data_gen, tf_gen;
+    float win[4];
+    float cc[3], cd[3], data_border;
+    int32_t clip_mode, axis, dir, start, D, W, H, guard;
+    float uvw_off[3], step100, prev_off[2], light_alpha, border_light;
+};
+struct KeptPass {
+    float* base = nullptr;
+    KeptKey key{};
+    bool valid = false;             // every chunk of the pass that fills it has been enqueued
     bool pinned = false;            // in use by the operator being planned
     uint64_t last_use = 0;
 };
@@ -91,10 +96,10 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
-    OccStore occ_tmp[2];           // chunk kernels: the transient occlusion stores of the two streams (allocated on first use)
-    std::vector<OccStore*> occ_cache; // ... and the cached ones (every one nx*ny*nz floats: an axis pass covers the volume)
-    uint64_t occ_clock = 0;        // LRU clock of the cache
-    uint64_t occ_hits = 0, occ_misses = 0; // stream-passes served from the cache / computed (tbrm_occlusion_cache_stats)
+    OccStore occ_tmp[2];           // chunk kernels: the occlusion stores of the two streams (allocated on first use)
+    std::vector<KeptPass*> kept;   // the contribution cache (every entry nx*ny*nz floats: an axis pass covers the light volume once)
+    uint64_t kept_clock = 0;       // its LRU clock
+    uint64_t kept_hits = 0, kept_computed = 0; // stream-passes served from the cache / propagated (tbrm_light_cache_stats)
     uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
 
     // empty-space-skipping metadata
@@ -155,7 +160,8 @@ struct ChunkFit { int M = 0; TapRange tx, ty; };
 struct PassPlan {
     ChunkParams p{};
     int mode = PASS_ADD;        // PASS_ADD / PASS_CHANGE / PASS_ADD2
-    bool two_streams() const { return mode != PASS_ADD; }
+    int n_streams() const { return (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2; } // streams propagated
+    bool two_streams() const { return n_streams() == 2; }
     int M = 0, S = 0;           // slices per chain chunk / per occlusion span
     int D = 0;                  // slices this handle runs (the whole pass, or its slab's part of a pass along z)
     int start = 0, dir = 1;     // first of them
@@ -163,11 +169,13 @@ struct PassPlan {
     bool pass_begins_here = true; // chunk 0 starts from the cleared buffers' value (else from imported planes)
     bool sparse = false, work_list = false;
     size_t flags_per_group = 0, flags_per_span = 0;
-    // occlusion of the two streams: where the factors live, and whether this pass has to compute them (a cached store that
-    // already holds them: no). Streams that are both computed are computed by ONE launch per span and share the flags of
-    // occ[0] (a block is flagged when it is empty for both).
-    OccStore* occ[2] = {nullptr, nullptr};
-    bool occ_compute[2] = {false, false};
+    // contribution cache: apply = the pass is one k_apply_kept launch over kept L (no chunks); keep[si] = where the chain
+    // stores stream si's L (null: not kept); kept_r = PASS_CHANGE_CACHED: the removed light's L
+    bool apply = false;
+    KeptPass* keep[2] = {nullptr, nullptr};
+    KeptPass* kept_a = nullptr;
+    KeptPass* kept_r = nullptr;
+    float apply_b = 0.0f;
     // slab-partitioned passes
     bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
     int first_chunk_of_pass = 0, chunks_of_pass = 0;
@@ -179,14 +187,14 @@ struct PassPlan {
 };
 
 extern thread_local const char* g_plan_note; // why chunk_fit / plan_pass last declined a pass
-bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit);
+bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit, int mode = -1);
 int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr);
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c);
-void release_occ_stores(tbrm_resources* r); // frees the transient and cached occlusion stores (the stream must be idle)
+void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the contribution cache (the stream must be idle)
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
 int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
                       int32_t* schedule, int32_t* n_entries);

@@ -704,12 +704,13 @@ def test_random_render_scenes_against_oracle(gpu, oracle_mod, seed, tunables):
 
 
 @pytest.mark.parametrize("light_32bit", [False, True])
-def test_occlusion_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_32bit, tunables):
-    """The occlusion cache (tbrm.h tbrm_occlusion_cache_stats) never shows in the results: a sequence of operators that hits it
-    (the removed side of a ChangeDirLight was the added side of the previous one; a light that oscillates between two
-    directions; a removal of a light that was added), misses it (first change after an add: the Add shader's guard differs
-    from the Change shader's), and invalidates it (new window, new transfer function, new volume) follows the oracle step by
-    step, and leaves the same light volume as the same sequence with the cache turned off."""
+def test_contribution_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_32bit, tunables):
+    """The contribution cache (tbrm.h tbrm_light_cache_stats) never shows in the results: a sequence of operators that hits it
+    (the removed side of a ChangeDirLight was the added side of the previous one: only the new light is propagated; a light
+    that oscillates between two directions: nothing is propagated; the removal of a light that was added), misses it (first
+    change after an add: the Add shader's guard differs from the Change shader's), and invalidates it (new window, new
+    transfer function, new volume) follows the oracle step by step, and leaves the same light volume as the same sequence
+    with the cache turned off."""
     dims = (104, 88, 72)
     world = S.default_world()
     vol = small_volume(dims, np.uint16)
@@ -733,7 +734,7 @@ def test_occlusion_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_32b
              ("volume", vol2), ("change", rot(1, 25), rot(1, 30)), ("remove", l0), ("change", rot(1, 30), rot(1, 90))]  # last: across faces
     finals, stats = [], []
     for cache_mb in (16384, 0):
-        tunables("occ_cache_mb", cache_mb)
+        tunables("light_cache_mb", cache_mb)
         orc = oracle_mod.OracleScene(vol, light_32bit)
         orc.set_tf_lut(lut_a)
         orc.set_windowing(win_a)
@@ -768,12 +769,12 @@ def test_occlusion_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_32b
                     continue
                 assert_light_equal(res, orc)
                 if cache_mb and i == 4:
-                    before = res.occlusion_cache_stats()
+                    before = res.light_cache_stats()
                 if cache_mb and i == 5:
-                    after = res.occlusion_cache_stats()
-                    assert after["hits"] - before["hits"] == 4 and after["computed"] == before["computed"], (before, after)
+                    after = res.light_cache_stats()
+                    assert after["hits"] - before["hits"] == 4 and after["propagated"] == before["propagated"], (before, after)
             finals.append(res.download_light_volume())
-            stats.append(res.occlusion_cache_stats())
+            stats.append(res.light_cache_stats())
             assert res.launch_counters()["slice"] == 0
     assert stats[0]["hits"] >= 10 and stats[0]["entries"] > 0 and stats[1]["hits"] == 0 and stats[1]["entries"] == 0, stats
     assert np.array_equal(finals[0], finals[1]) if not light_32bit else np.abs(finals[0] - finals[1]).max() == 0.0

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 from tbraymarcherplugin_amd import abi, synthetic as S  # noqa: E402
 
-NAMES = ["chunk_steps", "occ_slices", "sparse_occ", "occ_list"]
+NAMES = ["chunk_steps", "occ_slices", "sparse_occ", "occ_list", "light_cache_mb"]
 
 
 def main():

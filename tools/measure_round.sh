@@ -19,7 +19,7 @@ find /tmp/prof_write -name "*counter_collection.csv" -exec cp {} /tmp/pmc_write.
 python tools/pmc_traffic.py /tmp/pmc_fetch.csv /tmp/pmc_write.csv "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
 python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only.json" 2> /dev/null
 python tools/prof_light.py 2>&1 | grep -v amdgpu.ids > "$OUT/operators.txt"
-python tools/change_sweep.py "" "occ_cache_mb=0" 2>&1 | grep -v amdgpu.ids >> "$OUT/operators.txt"
+python tools/change_sweep.py "" "light_cache_mb=0" 2>&1 | grep -v amdgpu.ids >> "$OUT/operators.txt"
 for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
 TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"
 cat "$OUT/tests.txt" "$OUT/operators.txt"
