@@ -33,7 +33,7 @@ thread_local char g_error[512] = "";
 struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", 16384},
-    {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0},
+    {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];

@@ -79,6 +79,7 @@ struct ChunkStream {
     const uint8_t* occ_flags; // chain: this stream's empty-block flags from the slice group holding the chunk's first slice on:
                             // [slice group][block y][block x]; null: none (the two streams of a jointly computed pass share one array)
     float* occ_next;        // occlusion launch: where the span's factors 1 - CurrentSample go, [span slices][H][W]
+    float* l_dump;          // chain: 1024 floats nobody reads (kept L of tile pixels outside the buffer; the entry's guard band)
     float* l_out;           // chain: where the stream's unquantised L of every pixel of the chunk's slices is kept, [chunk slices][H][W]
                             // (null: not kept). PASS_CHANGE_CACHED: stream r is not propagated — r.occ_base / r.occ_off address its kept L
 };
@@ -231,6 +232,7 @@ enum Tunable : int {
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
+    TUNE_CHAIN_FAST_LOOP,    // 0: full, aligned chunks run the generic slice loop too (A/B of the unrolled, branch-free loop)
     TUNE_COUNT
 };
 int tune(Tunable t);

@@ -6,6 +6,9 @@
 #include "tbrm_device_sampling.h"
 #include "tbrm_light_chain.h"
 
+#include <type_traits>
+#include <utility>
+
 #ifndef TBRM_CHAIN_LFMT
 #error "compile with -DTBRM_CHAIN_LFMT=0 (UNORM8 light volume) or 2 (R32F)"
 #endif
@@ -22,8 +25,16 @@ namespace tbrm {
 // wave's 8x8 patch fall on disjoint groups of eight banks. Per slice: refill the ring slot read in the previous slice
 // with the slice two ahead, issue every LDS read of the slice, compute, write, and meet ONCE at a barrier.
 
-// KH = halo pixels per thread: ceil((hull area - tile area) / threads)
-template <int LFMT, int MODE, int AXIS, int KH, int RS>
+// compile-time loop over 0 .. N-1 (the fast slice loop: slice number, window parity and ring slot are immediates)
+template <class F, int... S>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
+
+// KH = halo pixels per thread: ceil((hull area - tile area) / threads).
+// M > 0: the chunk has exactly M slices (8 or 16), starts on a brick layer of the light volume (occ_phase 0) and its planes
+// are staged in one round (RS <= 56), UNORM8 light volume: the slice loop is fully unrolled with every slice-dependent
+// quantity an immediate, no per-lane branches and KEEP (the contribution cache takes L) a compile-time fact — see "fast
+// slice loop" below. M == 0: any chunk.
+template <int LFMT, int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false>
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -41,7 +52,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     constexpr int ROUNDS = (GROUPS + NT - 1) / NT;                       // copy groups per thread
     static_assert(RS % 16 == 8 && ROUNDS <= 2, "row stride must be an odd multiple of 8");
     const ChunkGeom g = chunk_geometry(p);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
     const int plane_elems = p.H * p.W;
     // Tile of this workgroup. Workgroups go to the 8 XCDs round-robin by linear id (an affinity used for speed only): XCD x
     // takes the x-th eighth of the row-major tile list — a band of neighbouring tiles whose overlapping halo reads of the
@@ -329,7 +340,155 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         }
     };
 
-    static_assert(kOccRing == 3, "the slice loop below is unrolled for a ring of three");
+    static_assert(kOccRing == 3, "the slice loops below are unrolled for a ring of three");
+    if constexpr (M > 0) {
+        // ---- fast slice loop ------------------------------------------------------------------------------------------
+        // tools/ubench/slice_loop.hip reproduces a slice of the generic loop below (16 reads, 96 VALU, 4 writes, 64 scalar
+        // instructions per wave and one barrier: 1950 cycles) and prices its parts: with one barrier per slice all 16 waves
+        // of the CU are in the same phase at the same time, so the phases add up, and a SCALAR instruction costs the slice
+        // as much as a vector one (~10 cycles each: 64 -> 16 scalars per wave: -470 cycles). The generic loop spends 74
+        // scalar instructions per wave and slice on exec masks, loop and ring bookkeeping, runtime vmcnt selection and
+        // brick addressing. Here the chunk length is a template parameter and the loop is unrolled, so slice number,
+        // remaining slices, window parity, ring slot and the voxel's offset in the light-volume tile are immediates;
+        // a pixel outside the plane or outside the current window is still computed but written to the plane's slack
+        // word (one v_cndmask instead of an exec-mask region); every wave issues the same number of vector-memory
+        // operations per slice, so the copy counter's operand is an immediate too.
+        static_assert(ROUNDS == 1 && LV_LDS && (M == 8 || M == 16), "fast slice loop: one staging round, UNORM8 light volume");
+        constexpr int DUMMY = RS * RS; // the plane's slack word: nobody reads it
+        // staging: every lane with a group inside the plane copies (rows beyond the hull / the buffer copy a clamped row:
+        // the pixels they feed are never valid); per stream the source offset of slice 0 and its advance per slice
+        const bool st_in = (int) threadIdx.x < GROUPS;
+        uint32_t st_off[NR], st_adv[NR][2];
+        {
+            const int gi = (int) threadIdx.x, row = gi / GPR, col = (gi - row * GPR) * 4;
+            const int py = min(max(base_y - g.pady + row, 0), p.H - 1);
+            const uint32_t src = (uint32_t) (py * p.W + base_x - g.padx + col);
+#pragma unroll
+            for (int si = 0; si < NR; ++si) {
+                const ChunkStream& st = si == 0 ? p.a : p.r;
+#pragma unroll
+                for (int z = 0; z < 2; ++z) st_adv[si][z] = (st_ok[0] && st_one[si][0][z]) ? 0u : (uint32_t) plane_elems;
+                st_off[si] = st.occ_off + src;
+            }
+        }
+        auto stage_fast = [&](auto sfc, auto qc) { // the planes of slice SF into ring slot Q
+            constexpr int SF = decltype(sfc)::value, Q = decltype(qc)::value;
+            if constexpr (SF < M) {
+                if (st_in) {
+#pragma unroll
+                    for (int si = 0; si < NR; ++si) {
+                        const ChunkStream& st = si == 0 ? p.a : p.r;
+                        const bool one = st_adv[si][SF / kOccSlices] == 0u;
+                        const uint32_t off = one ? (uint32_t) lane * 4u : st_off[si] + (uint32_t) SF * (uint32_t) plane_elems;
+                        dma_16(st.occ_base + off, ring(Q, si) + st_dst[0]);
+                    }
+                }
+            }
+        };
+        // slot 0 never branches: a pixel outside the buffer is computed like any other and lands in the slack word
+        const bool own_in = rmin[0] < INT32_MAX / 2;
+        const int liw0 = own_in ? li[0] : DUMMY;
+        // kept L: an owned pixel's value goes to its place in the pass's plane, that of a pixel outside the buffer to the entry's
+        // guard band (l_dump) — every lane stores, every slice
+        float* keep_at[NS];
+        uint32_t keep_step = own_in ? (uint32_t) plane_elems : 0u;
+#pragma unroll
+        for (int si = 0; si < NS; ++si) {
+            const ChunkStream& st = si == 0 ? p.a : p.r;
+            keep_at[si] = KEEP && st.l_out ? (own_in ? st.l_out + own_idx : st.l_dump + threadIdx.x) : nullptr;
+        }
+        // the owned voxel's offset in the light-volume tile: slice S of an aligned chunk is row S & 7 of layer S >> 3 (counted
+        // from the chunk's last layer when the pass runs downwards)
+        constexpr uint32_t kLvStep = AXIS == 0 ? 1u : (AXIS == 1 ? 8u : 64u);
+        const bool down = p.dir < 0;
+        const uint32_t lv_first = lv_const + (down ? (uint32_t) (M / 8 - 1) * 16u * 512u + 7u * kLvStep : 0u);
+        auto slice_fast = [&](auto sc) {
+            constexpr int S = decltype(sc)::value, R = M - 1 - S, CUR = S & 1, Q = S % 3;
+            stage_fast(std::integral_constant<int, S + 2>{}, std::integral_constant<int, (S + 2) % 3>{});
+            constexpr uint32_t lv_delta = (uint32_t) (S >> 3) * 16u * 512u + (uint32_t) (S & 7) * kLvStep;
+            const uint32_t vi = down ? lv_first - lv_delta : lv_first + lv_delta;
+            // owned pixel
+            float t00[NS], t01[NS], t10[NS], t11[NS], fac0[NS];
+#pragma unroll
+            for (int si = 0; si < NS; ++si) {
+                const float* pw = window(CUR, si) + ti[si][0];
+                t00[si] = pw[0]; t01[si] = pw[1]; t10[si] = pw[RS]; t11[si] = pw[RS + 1];
+                fac0[si] = ring(Q, si)[li[0]];
+            }
+            const uint32_t code_old = lv_tile[vi];
+            float l_removed = 0.0f;
+            if constexpr (CACHED) l_removed = ring(Q, 1)[li[0]];
+            // halo pixels: a wave none of whose lanes has a pixel inside the window skips the slot
+            bool act[KS];
+            float h00[KS][NS], h01[KS][NS], h10[KS][NS], h11[KS][NS], hfac[KS][NS];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) {
+                act[k] = R >= rmin[k];
+                if (__builtin_amdgcn_ballot_w64(act[k]) == 0) continue;
+#pragma unroll
+                for (int si = 0; si < NS; ++si) {
+                    const float* pw = window(CUR, si) + ti[si][k];
+                    h00[k][si] = pw[0]; h01[k][si] = pw[1]; h10[k][si] = pw[RS]; h11[k][si] = pw[RS + 1];
+                    hfac[k][si] = ring(Q, si)[li[k]];
+                }
+            }
+            float lval[NS];
+#pragma unroll
+            for (int si = 0; si < NS; ++si) {
+                const float prev = lerp_(lerp_(t00[si], t01[si], wfx[si][0]), lerp_(t10[si], t11[si], wfx[si][0]), wfy[si][0]);
+                lval[si] = prev * fac0[si];
+                window(CUR ^ 1, si)[liw0] = through_format<LFMT>(lval[si]);
+            }
+            {
+                const float lv_old = decode_u8(code_old);
+                float nv;
+                bool write;
+                if constexpr (MODE == PASS_ADD) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }
+                else if constexpr (MODE == PASS_CHANGE) { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }
+                else if constexpr (CACHED) { nv = lv_old + lval[0] - l_removed; write = fabsf(lval[0] - l_removed) > 1e-3f; }
+                else {
+                    const bool wa = fabsf(lval[0]) > 1e-3f, wb = fabsf(lval[NS - 1]) > 1e-3f;
+                    nv = wa ? through_format<LFMT>(lv_old + lval[0] * p.b_added) : lv_old;
+                    if (wb) nv = nv + lval[NS - 1] * p.b_added2;
+                    write = wa || wb;
+                }
+                lv_tile[vi] = (uint8_t) ((write && own_in) ? encode_u8(nv) : code_old); // always stored: no exec-mask region
+            }
+            if constexpr (R == 0) {
+                if (own_in) {
+#pragma unroll
+                    for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[own_idx] = through_format<LFMT>(lval[si]);
+                }
+            }
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int si = 0; si < NS; ++si) {
+                    if (si == 0 || (si == 0 ? p.a : p.r).l_out) keep_at[si][(size_t) S * keep_step] = lval[si];
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < KS; ++k) {
+                if (__builtin_amdgcn_ballot_w64(act[k]) == 0) continue;
+                const int liw = act[k] ? li[k] : DUMMY;
+#pragma unroll
+                for (int si = 0; si < NS; ++si) {
+                    const float prev = lerp_(lerp_(h00[k][si], h01[k][si], wfx[si][k]), lerp_(h10[k][si], h11[k][si], wfx[si][k]), wfy[si][k]);
+                    window(CUR ^ 1, si)[liw] = through_format<LFMT>(prev * hfac[k][si]);
+                }
+            }
+            // copies of slice S+1 (issued a slice ago) have to have landed; this slice's own (slice S+2's planes, the kept L,
+            // the last slice's planes) may stay in flight
+            constexpr int in_flight = (S + 2 < M ? NR : 0) + (KEEP ? 1 : 0) + (R == 0 ? NS : 0);
+            if constexpr (in_flight == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (in_flight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if constexpr (in_flight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (in_flight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr (in_flight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            lds_barrier();
+        };
+        for_each_const(slice_fast, std::make_integer_sequence<int, M>{});
+    } else
     // Per slice: refill the ring slot the PREVIOUS slice read (every wave left that slice at the barrier) with the slice
     // two ahead, compute, then wait until only that refill may still be in flight — the copies of slice s+1, issued a
     // whole slice ago, have landed — and meet at the barrier that also publishes this slice's window writes. Copies
@@ -363,25 +522,52 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
 }
 
 
-template <int MODE, int AXIS, int KH, int RS>
+template <int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false>
 static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 {
     constexpr int LFMT = TBRM_CHAIN_LFMT;
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS>, attr_done, 160 * 1024); e != hipSuccess) return e;
+    if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP>, attr_done, 160 * 1024); e != hipSuccess) return e;
     const size_t lds = chunk_lds_bytes(p, MODE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
+    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
 
-// The instantiated shapes (chunk_lds_bytes tells the planner which hulls have one): two streams RS 40 (1 halo slot per
-// thread) / 56 (1, 2, 3); one stream RS 40 (1) / 56 (3) / 72 (3)
+// The fast slice loop (k_light_chain, M > 0) is instantiated for the shapes the planner produces for full chunks of light
+// passes with taps one or two texels wide: 16 slices in 56 x 56 planes with 2 halo pixels per thread, 8 slices in 40 x 40
+// planes (1) or 56 x 56 planes (1, 2) — for a UNORM8 light volume. false: not one of them (the generic loop runs).
+template <int MODE, int AXIS>
+static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, hipStream_t s, hipError_t& err)
+{
+#if TBRM_CHAIN_LFMT == 0
+    const bool aligned = p.occ_phase == 0 && (p.j0 & 7) == (p.dir > 0 ? 0 : 7) && g.lv_layers == g.n / 8;
+    if (!aligned || tune(TUNE_CHAIN_FAST_LOOP) == 0) return false;
+    const bool keep = p.a.l_out != nullptr;
+    auto go = [&](auto khc, auto rsc, auto mc) {
+        constexpr int KH = decltype(khc)::value, RS = decltype(rsc)::value, M = decltype(mc)::value;
+        if constexpr (MODE == PASS_ADD2) err = launch_chain4<MODE, AXIS, KH, RS, M, false>(p, s); // (pairs are not kept)
+        else err = keep ? launch_chain4<MODE, AXIS, KH, RS, M, true>(p, s) : launch_chain4<MODE, AXIS, KH, RS, M, false>(p, s);
+        return true;
+    };
+    using std::integral_constant;
+    if (g.n == 16 && g.RS == 56 && kh == 2) return go(integral_constant<int, 2>{}, integral_constant<int, 56>{}, integral_constant<int, 16>{});
+    if (g.n == 8 && g.RS == 40 && kh <= 1) return go(integral_constant<int, 1>{}, integral_constant<int, 40>{}, integral_constant<int, 8>{});
+    if (g.n == 8 && g.RS == 56 && kh <= 1) return go(integral_constant<int, 1>{}, integral_constant<int, 56>{}, integral_constant<int, 8>{});
+    if (g.n == 8 && g.RS == 56 && kh == 2) return go(integral_constant<int, 2>{}, integral_constant<int, 56>{}, integral_constant<int, 8>{});
+#endif
+    return false;
+}
+
+// The instantiated shapes of the generic loop (chunk_lds_bytes tells the planner which hulls have one): two streams RS 40
+// (1 halo slot per thread) / 56 (1, 2, 3); one stream RS 40 (1) / 56 (3) / 72 (3)
 template <int MODE, int AXIS>
 static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
 {
     const ChunkGeom g = chunk_geometry(p);
     const int halo = g.HX * g.HY - kChunkTile * kChunkTile;
     const int kh = (halo + kChunkThreads - 1) / kChunkThreads; // <= 3 for hulls up to 64 x 64
+    hipError_t err = hipSuccess;
+    if (launch_chain_fast<MODE, AXIS>(p, g, kh, s, err)) return err;
     if constexpr (MODE == PASS_CHANGE_CACHED) { // one stream propagated, two planes staged: the Add's kernels up to RS 56
         if (g.RS == 40) return launch_chain4<MODE, AXIS, 1, 40>(p, s);
         if (g.RS == 56) return launch_chain4<MODE, AXIS, 3, 56>(p, s);

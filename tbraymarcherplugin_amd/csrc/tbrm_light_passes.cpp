@@ -586,6 +586,7 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
         streams[si]->occ_flags = chunk_flags;
         // the contribution cache keeps L in pass order: plane k of an entry is the pass's k-th slice
         streams[si]->l_out = plan.keep[si] ? plan.keep[si]->base + kPlaneGuard + (size_t) c * M * slice_elems : nullptr;
+        streams[si]->l_dump = plan.keep[si] ? plan.keep[si]->base : nullptr;
     }
     if (plan.mode == PASS_CHANGE_CACHED) { // the removed light's L is staged like a second plane of occlusion factors (no flags)
         p.r.occ_base = plan.kept_r->base;
