@@ -34,6 +34,7 @@ struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", 16384},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
+    {"occ_overlap", 2},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -412,6 +413,11 @@ int tbrm_resources_destroy(tbrm_resources* r)
     release_occ_stores(r);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
+    if (r->occ_stream) {
+        (void) hipStreamSynchronize(r->occ_stream);
+        (void) hipStreamDestroy(r->occ_stream);
+        for (int b = 0; b < 2; ++b) { (void) hipEventDestroy(r->occ_ev_fork[b]); (void) hipEventDestroy(r->occ_ev_ready[b]); }
+    }
     for (uint16_t* o : r->d_octree) (void) hipFree(o);
     for (uint8_t* d : r->d_dist) (void) hipFree(d);
     (void) hipFree(r->d_alpha_prefix);

@@ -122,6 +122,7 @@ struct ChunkParams {
     // of landing wherever the dense part of the volume happens to map.
     const uint32_t* occ_list;     // this chunk's list; null: every workgroup takes its own grid position
     const int* occ_count;         // this chunk's number of list entries
+    int occ_grid_cap;             // occlusion launch: at most this many workgroups, each walking several blocks (0: one per block)
     uint32_t* occ_list_out;       // k_occ_compact: the whole pass, [chunk][per-chunk capacity]
     int* occ_count_out;           // k_occ_compact: [chunk]
     ChunkStream a, r;
@@ -202,16 +203,21 @@ struct RelayoutParams {
 };
 
 // k_apply_kept: the light-volume update of one axis pass from kept L values alone (tbrm_light_passes.cpp, contribution cache)
+constexpr int kApplyMaxPasses = 8; // axis passes one k_apply_kept launch applies, in order
+struct ApplyPass {
+    int axis, W, H;         // the pass: propagation axis, plane size (TD.X, TD.Y)
+    int start, dir;         // its first slice and direction: plane k of a kept pass is slice start + k*dir
+    float b_added;          // Add / Remove: +1 / -1
+    const float* la;        // L of the added light (Add / Remove: the light), [pass slices][H][W]
+    const float* lr;        // L of the removed light; null: Add / Remove
+};
 struct ApplyParams {
     void* light;            // bricked
     int lv_dims[3];
     int lv_bnx, lv_bnxy, lv_bnz;
     int lv_fmt;
-    int axis, W, H;         // the pass: propagation axis, plane size (TD.X, TD.Y)
-    int start, dir;         // its first slice and direction: plane k of a kept pass is slice start + k*dir
-    const float* la;        // L of the added light (Add / Remove: the light), [pass slices][H][W]
-    const float* lr;        // L of the removed light; null: Add / Remove
-    float b_added;          // Add / Remove: +1 / -1
+    int n_passes;
+    ApplyPass pass[kApplyMaxPasses];
 };
 
 constexpr int kOccSlices = 8;      // slices per occlusion workgroup (kOccDepth in tbrm_light_kernels.hip)
@@ -233,6 +239,7 @@ enum Tunable : int {
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
     TUNE_CHAIN_FAST_LOOP,    // 0: full, aligned chunks run the generic slice loop too (A/B of the unrolled, branch-free loop)
+    TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
     TUNE_COUNT
 };
 int tune(Tunable t);

@@ -122,49 +122,102 @@ hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t 
     }
 }
 
-// ---- k_apply_kept: an axis pass whose propagated values are all at hand --------------------------------------------------
+// ---- k_apply_kept: axis passes whose propagated values are all at hand ----------------------------------------------------
 // What an axis pass does to the light volume is a function of L, the light's propagated value per voxel, alone
 // (AddDirLightShader.usf:123-126: LV += L * bAdded where |L| > 1e-3; ChangeDirLightShader.usf:152-154: LV += La - Lr where
 // |La - Lr| > 1e-3). When the pass that computed L kept it (ChunkStream::l_out), a later pass over the same light — its
-// removal, a re-add after a reset, the removed side of a ChangeDirLight — needs no propagation: one thread per voxel of the
-// bricked light volume (coalesced read-modify-write) looks its L up in the kept pass's plane order and applies the same
-// arithmetic.
-template <int LFMT, bool CHANGE>
+// removal, a re-add after a reset, the removed side of a ChangeDirLight — needs no propagation, and neither do the passes
+// that follow it while their L is at hand too: one launch applies up to kApplyMaxPasses passes in their order.
+//
+// A workgroup takes a region of 32 x 32 x 8 voxels (4 x 4 x 1 bricks of the light volume) into LDS with whole-brick
+// copies, then walks it once per pass in THAT pass's plane order — 32 consecutive floats of L per row whichever axis the
+// pass ran along — applying the shader's arithmetic to the cell in LDS (the UNORM8 code is re-quantised after every pass, as
+// separate launches would), and writes the bricks back: L is read once in 128-byte runs, the light volume once.
+constexpr int kApplyX = 32, kApplyY = 32, kApplyZ = 8;
+
+template <int LFMT>
 __global__ __launch_bounds__(256) void k_apply_kept(const ApplyParams p)
 {
-    const size_t t = (size_t) blockIdx.x * 256 + threadIdx.x;
-    const uint32_t b = (uint32_t) (t >> 9), o = (uint32_t) t & 511u;
+    using Cell = std::conditional_t<LFMT == FMT_U8, uint8_t, float>;
+    constexpr int CELLS_PER_WORD = 4 / (int) sizeof(Cell);              // 4 (UNORM8) / 1
+    constexpr int ROW_WORDS = kApplyX / CELLS_PER_WORD;                 // 8 / 32
+    constexpr int BRICK_WORDS = 512 / CELLS_PER_WORD;
+    __shared__ uint32_t s_words[kApplyZ * kApplyY * ROW_WORDS];
+    Cell* const s_lv = (Cell*) s_words;
+    // cell (x, y, z) of the region; the words of a row are rotated by a function of y so that lanes that differ in y (a
+    // pass along x has y as its fastest plane axis) fall into different banks
+    auto cell_of = [&](int x, int y, int z) -> int {
+        const int rot = LFMT == FMT_U8 ? (y >> 3) : y;
+        const int word = ((x / CELLS_PER_WORD) + rot) & (ROW_WORDS - 1);
+        return ((z * kApplyY + y) * ROW_WORDS + word) * CELLS_PER_WORD + (x & (CELLS_PER_WORD - 1));
+    };
     const int bny = p.lv_bnxy / p.lv_bnx;
-    if (b >= (uint32_t) (p.lv_bnxy * p.lv_bnz)) return;
-    const int x = (int) (b % (uint32_t) p.lv_bnx) * 8 + (int) (o & 7u);
-    const int y = (int) ((b / (uint32_t) p.lv_bnx) % (uint32_t) bny) * 8 + (int) ((o >> 3) & 7u);
-    const int z = (int) (b / (uint32_t) p.lv_bnxy) * 8 + (int) (o >> 6);
-    if (x >= p.lv_dims[0] || y >= p.lv_dims[1] || z >= p.lv_dims[2]) return; // padding voxels of the last bricks
-    int j, px, py; // slice and plane pixel of the voxel (the permutation of k_propagate_slice)
-    if (p.axis == 0) { j = x; px = y; py = z; } else if (p.axis == 1) { j = y; px = x; py = z; } else { j = z; px = x; py = y; }
-    const size_t li = ((size_t) ((j - p.start) * p.dir) * p.H + py) * (size_t) p.W + px;
-    const float la = p.la[li];
-    if constexpr (!CHANGE) {
-        if (fabsf(la) > 1e-3f) store_voxel<LFMT>(p.light, t, load_voxel<LFMT>(p.light, t) + (la * p.b_added));
-    } else {
-        const float lr = p.lr[li];
-        if (fabsf(la - lr) > 1e-3f) store_voxel<LFMT>(p.light, t, load_voxel<LFMT>(p.light, t) + la - lr);
+    const int gx = (p.lv_bnx + 3) >> 2, gy = (bny + 3) >> 2;
+    const int rx = (int) blockIdx.x % gx, ry = ((int) blockIdx.x / gx) % gy, bz = (int) blockIdx.x / (gx * gy);
+    const int x0 = rx * kApplyX, y0 = ry * kApplyY, z0 = bz * kApplyZ;
+    uint32_t* const lv_words = (uint32_t*) p.light;
+
+    auto copy = [&](auto to_lds) {
+#pragma unroll 4
+        for (int w = threadIdx.x; w < 16 * BRICK_WORDS; w += 256) {
+            const int brick = w / BRICK_WORDS, wi = w % BRICK_WORDS, e = wi * CELLS_PER_WORD;
+            const int bx = rx * 4 + (brick & 3), by = ry * 4 + (brick >> 2);
+            if (bx >= p.lv_bnx || by >= bny) continue;
+            const size_t g = ((size_t) bz * p.lv_bnxy + (size_t) by * p.lv_bnx + bx) * BRICK_WORDS + wi;
+            const int c = cell_of((brick & 3) * 8 + (e & 7), (brick >> 2) * 8 + ((e >> 3) & 7), e >> 6);
+            if constexpr (decltype(to_lds)::value) s_words[c / CELLS_PER_WORD] = lv_words[g];
+            else lv_words[g] = s_words[c / CELLS_PER_WORD];
+        }
+    };
+    copy(std::true_type{});
+    __syncthreads();
+
+    for (int n = 0; n < p.n_passes; ++n) {
+        const ApplyPass& q = p.pass[n];
+        constexpr int BATCH = 8;
+        for (int it0 = 0; it0 < kApplyX * kApplyY * kApplyZ / 256; it0 += BATCH) {
+            float la[BATCH], lr[BATCH];
+            int cell[BATCH];
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                const int id = (it0 + k) * 256 + (int) threadIdx.x;
+                int x, y, z, j, px, py; // region cell in the pass's plane order (plane x fastest), and its slice / plane pixel
+                if (q.axis == 0) { y = id & 31; z = (id >> 5) & 7; x = id >> 8; j = x0 + x; px = y0 + y; py = z0 + z; }
+                else if (q.axis == 1) { x = id & 31; z = (id >> 5) & 7; y = id >> 8; j = y0 + y; px = x0 + x; py = z0 + z; }
+                else { x = id & 31; y = (id >> 5) & 31; z = id >> 10; j = z0 + z; px = x0 + x; py = y0 + y; }
+                const bool in = x0 + x < p.lv_dims[0] && y0 + y < p.lv_dims[1] && z0 + z < p.lv_dims[2]; // not brick padding
+                cell[k] = in ? cell_of(x, y, z) : -1;
+                const size_t li = in ? ((size_t) ((j - q.start) * q.dir) * q.H + py) * (size_t) q.W + px : 0;
+                la[k] = q.la[li];
+                lr[k] = q.lr ? q.lr[li] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) {
+                if (cell[k] < 0) continue;
+                float lv;
+                if constexpr (LFMT == FMT_U8) lv = decode_u8(s_lv[cell[k]]); else lv = s_lv[cell[k]];
+                float out = lv;
+                bool write;
+                if (q.lr) { write = fabsf(la[k] - lr[k]) > 1e-3f; out = lv + la[k] - lr[k]; }
+                else { write = fabsf(la[k]) > 1e-3f; out = lv + (la[k] * q.b_added); }
+                if (write) {
+                    if constexpr (LFMT == FMT_U8) s_lv[cell[k]] = (uint8_t) encode_u8(out); else s_lv[cell[k]] = out;
+                }
+            }
+        }
+        __syncthreads();
     }
+    copy(std::false_type{});
 }
 
 hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s)
 {
-    const size_t n = (size_t) p.lv_bnxy * p.lv_bnz * 512;
-    if (n == 0) return hipSuccess;
-    const dim3 grid((unsigned) ((n + 255) / 256)), block(256);
-    const bool change = p.lr != nullptr;
-    if (p.lv_fmt == FMT_U8) {
-        if (change) hipLaunchKernelGGL((k_apply_kept<FMT_U8, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_apply_kept<FMT_U8, false>), grid, block, 0, s, p);
-    } else {
-        if (change) hipLaunchKernelGGL((k_apply_kept<FMT_F32, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((k_apply_kept<FMT_F32, false>), grid, block, 0, s, p);
-    }
+    const int bny = p.lv_bnx > 0 ? p.lv_bnxy / p.lv_bnx : 0;
+    const size_t n = (size_t) ((p.lv_bnx + 3) / 4) * ((bny + 3) / 4) * p.lv_bnz;
+    if (n == 0 || p.n_passes <= 0) return hipSuccess;
+    const dim3 grid((unsigned) n), block(256);
+    if (p.lv_fmt == FMT_U8) hipLaunchKernelGGL(k_apply_kept<FMT_U8>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(k_apply_kept<FMT_F32>, grid, block, 0, s, p);
     return hipGetLastError();
 }
 
@@ -379,17 +432,25 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     // The launch is a 1-D grid rounded up to a multiple of 8 workgroups. Workgroups are dealt to the 8 XCDs round-robin by
     // id (an affinity used for speed only): XCD x takes the x-th eighth of the work, so blocks that are neighbours in the
     // volume — and stage the same halo bricks — run behind the same L2.
+    //
+    // The grid may be smaller than the work (a launch that runs beside the chain of the previous span on the occlusion
+    // stream, tbrm_light_passes.cpp, holds only as many workgroups as fit next to the chain's on every CU, all resident from
+    // the start, so none is ever waiting to take a slot the next chain launch needs): a workgroup then walks its XCD's
+    // eighth with the stride of the grid.
     const int groups = (p.n_steps + kOccDepth - 1) / kOccDepth;
     const int total = p.occ_list ? *p.occ_count : groups * p.occ_blocks_y * p.occ_blocks_x;
     const int per_xcd = (total + 7) >> 3;
-    const int entry = ((int) blockIdx.x & 7) * per_xcd + ((int) blockIdx.x >> 3);
-    if (((int) blockIdx.x >> 3) >= per_xcd || entry >= total) return;
+    const int xcd_stride = (int) gridDim.x >> 3;
+  for (int slot = (int) blockIdx.x >> 3; slot < per_xcd; slot += xcd_stride) {
+    const int entry = ((int) blockIdx.x & 7) * per_xcd + slot;
+    if (entry >= total) break;
+    if (slot != ((int) blockIdx.x >> 3)) __syncthreads(); // the previous block's tables and staged bricks are done with
     // which block of the span: the entry itself, or (sparse spans) that entry of the span's work list — workgroups flagged
     // empty by k_occ_flags (every CurrentSample exactly 0, and the chain knows it) are not on the list
     const int id = p.occ_list ? (int) p.occ_list[entry] : entry;
     const int gx = id % p.occ_blocks_x, gy = (id / p.occ_blocks_x) % p.occ_blocks_y, gz = id / (p.occ_blocks_x * p.occ_blocks_y);
-    if (!p.occ_list && p.occ_flags && p.occ_flags[id]) return; // list off (A/B runs)
-    if (gy < p.roi_by0 || gy >= p.roi_by1) return;             // dense span of a slab-partitioned pass
+    if (!p.occ_list && p.occ_flags && p.occ_flags[id]) continue; // list off (A/B runs)
+    if (gy < p.roi_by0 || gy >= p.roi_by1) continue;             // dense span of a slab-partitioned pass
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
     const int nk = min(kOccDepth, p.n_steps - k0);
 
@@ -494,7 +555,6 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!pixel_ok) return;
 
     // the sample loop, specialised on workgroup-uniform facts so the common case carries no dead branches:
     //   STAGED   taps come from LDS (else from global memory: a workgroup whose bricks did not fit)
@@ -571,17 +631,21 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
     };
     using T_ = std::true_type; using F_ = std::false_type;
     const bool interior = s_interior != 0;
+    if (!pixel_ok) continue;
     if (staged && interior && !p.clip_mode) run(T_{}, T_{}, F_{});       // the common case
     else if (staged && !p.clip_mode) run(T_{}, F_{}, F_{});               // shell of the volume
     else if (staged) run(T_{}, F_{}, T_{});                               // clip plane active
     else run(F_{}, F_{}, T_{});                                           // bricks did not fit in LDS
+  }
 }
 
 template <int DFMT, int MODE, int AXIS>
 static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
 {
     const int blocks = ((p.W + kOccTile - 1) / kOccTile) * ((p.H + kOccTile - 1) / kOccTile) * ((p.n_steps + kOccDepth - 1) / kOccDepth);
-    const dim3 grid(8 * ((blocks + 7) / 8)), block(256);
+    int wgs = 8 * ((blocks + 7) / 8);
+    if (p.occ_grid_cap > 0) wgs = std::min(wgs, 8 * ((p.occ_grid_cap + 7) / 8));
+    const dim3 grid(wgs), block(256);
     size_t lds = occlusion_lds_bytes(p);
     if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
     static std::atomic<uint64_t> attr_done{0};

@@ -217,12 +217,15 @@ static SpanRange span_range(const PassPlan& plan, int sp)
 
 void release_occ_stores(tbrm_resources* r)
 {
-    for (OccStore& st : r->occ_tmp) {
-        (void) hipFree(st.base);
-        (void) hipFree(st.flags);
-        (void) hipFree(st.list);
-        st = OccStore{};
-    }
+    if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
+    for (auto& buf : r->occ_tmp)
+        for (OccStore& st : buf) {
+            (void) hipFree(st.base);
+            (void) hipFree(st.flags);
+            (void) hipFree(st.list);
+            st = OccStore{};
+        }
+    for (auto& slot : r->occ_slot) slot = tbrm_resources::OccSlot{};
     for (KeptPass* e : r->kept) {
         (void) hipFree(e->base);
         delete e;
@@ -236,6 +239,7 @@ static int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slic
     const size_t elems = (size_t) slices * slice_elems; // (the passes of a non-cubic volume have planes of different sizes)
     if (elems > st->capacity || !st->base) {
         HIP_TRY(hipStreamSynchronize(r->stream));
+        if (r->occ_stream) HIP_TRY(hipStreamSynchronize(r->occ_stream));
         (void) hipFree(st->base);
         st->base = nullptr;
         st->capacity = 0;
@@ -245,6 +249,7 @@ static int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slic
     }
     if (flag_bytes > st->flag_bytes) {
         HIP_TRY(hipStreamSynchronize(r->stream));
+        if (r->occ_stream) HIP_TRY(hipStreamSynchronize(r->occ_stream));
         (void) hipFree(st->flags);
         (void) hipFree(st->list);
         st->flags = nullptr;
@@ -323,6 +328,13 @@ static void unpin_kept(tbrm_resources* r)
     for (KeptPass* e : r->kept) e->pinned = false;
 }
 
+// whole, unpartitioned passes of this handle can keep / use L (the chain addresses a kept L with 32-bit offsets)
+static bool cache_usable(const tbrm_resources* r)
+{
+    return !force_slice_kernel() && tune(TUNE_LIGHT_CACHE_MB) > 0 && kept_elems(r) * sizeof(float) < ((size_t) 1 << 34) &&
+           kept_elems(r) < ((size_t) 1 << 32);
+}
+
 // pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
 // pr, both added with b_added / b_added2).
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
@@ -334,8 +346,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     // Contribution cache (tbrm_resources.h KeptPass): is this light's L — and, for a Change, the removed light's — at hand?
     // Whole, unpartitioned passes only; the chain addresses the removed light's L with 32-bit offsets.
     KeptPass *have_a = nullptr, *have_r = nullptr;
-    const bool cache_on = !slab && mode != PASS_ADD2 && !force_slice_kernel() && tune(TUNE_LIGHT_CACHE_MB) > 0 &&
-                          kept_elems(r) * sizeof(float) < ((size_t) 1 << 34) && kept_elems(r) < ((size_t) 1 << 32);
+    const bool cache_on = !slab && mode != PASS_ADD2 && cache_usable(r);
     KeptKey key_a{};
     if (cache_on) {
         key_a = kept_key(r, base, pa, mode == PASS_ADD);
@@ -498,8 +509,10 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     }
     // the occlusion stores of the stream(s) this pass propagates
     const size_t flag_bytes = plan.sparse ? plan.flags_per_span * plan.n_spans : 0;
-    for (int si = 0; si < (plan.two_streams() ? 2 : 1); ++si)
-        if (int e = ensure_store(r, &r->occ_tmp[si], S, slice_elems, flag_bytes)) return e;
+    for (int b = 0; b < 2; ++b)
+        for (int si = 0; si < (plan.two_streams() ? 2 : 1); ++si)
+            if (int e = ensure_store(r, &r->occ_tmp[b][si], S, slice_elems, si == 0 ? flag_bytes : 0)) return e;
+    plan.serial = ++r->plan_serial;
     return TBRM_OK;
 }
 
@@ -507,9 +520,86 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 // the last one): chunk c reads the planes of parity c & 1 and writes the others.
 float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_plane[2 * si + (boundary & 1)] + kPlaneGuard; }
 
-// Enqueues chunk c of the plan: in front of the pass's first chunk the empty-block flags and work lists of the whole
-// pass, in front of a span's first chunk the occlusion of the span, then the chain.
-int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
+// The occlusion of span sp of the plan into buffer b ({a,r}.occ_next = that buffer's stores), with — in front of the pass's
+// first span — the empty-block flags and work lists of the whole pass. beside: on occ_stream, ordered behind everything
+// enqueued on the handle's stream so far (the data volume, the transfer function's tables, the chains that read the
+// buffer's previous contents), with a grid small enough to be resident beside the chain's workgroups; the chain waits for
+// occ_ev_ready[b] (enqueue_plan_chunk).
+static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, int b, bool beside)
+{
+    hipStream_t s = r->stream;
+    if (beside) {
+        if (!r->occ_stream) {
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least));
+            for (int k = 0; k < 2; ++k) {
+                HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], hipEventDisableTiming));
+            }
+        }
+        s = r->occ_stream;
+        HIP_TRY(hipEventRecord(r->occ_ev_fork[b], r->stream));
+        HIP_TRY(hipStreamWaitEvent(s, r->occ_ev_fork[b], 0));
+    }
+    ChunkParams p = plan.p;
+    const SpanRange q = span_range(plan, sp);
+    // the propagated streams' occlusion: one launch per span computes both (a block is flagged empty when it is empty for
+    // both), or the added light alone with the Change shader's rules when the removed light's L is kept
+    const int occ_mode = plan.mode == PASS_CHANGE_CACHED ? PASS_CHANGE_ONE : plan.mode;
+    OccStore* const fs = &r->occ_tmp[plan.serial & 1][0];
+    int* const counts = (int*) (fs->list + fs->flag_bytes);
+    p.a.occ_next = r->occ_tmp[b][0].base + kPlaneGuard;
+    p.r.occ_next = plan.n_streams() == 2 ? r->occ_tmp[b][1].base + kPlaneGuard : nullptr;
+    if (sp == 0 && plan.sparse) {
+        p.occ_flags_out = fs->flags;
+        p.occ_list_out = plan.work_list ? fs->list : nullptr;
+        p.occ_count_out = counts;
+        HIP_TRY(launch_occ_flags(p, occ_mode, plan.n_spans, s));
+    }
+    p.j0 = plan.start + q.s0 * plan.dir;
+    p.n_steps = q.sn;
+    p.occ_flags = nullptr;
+    p.occ_list = q.sparse && plan.work_list ? fs->list + (size_t) sp * plan.flags_per_span : nullptr;
+    p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
+    if (q.sparse && !plan.work_list) p.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
+    p.occ_grid_cap = beside ? tune(TUNE_OCC_OVERLAP) * r->n_cus : 0;
+    HIP_TRY(launch_light_occlusion(p, occ_mode, s));
+    if (beside) HIP_TRY(hipEventRecord(r->occ_ev_ready[b], s));
+    r->occ_slot[b].plan_serial = plan.serial;
+    r->occ_slot[b].span = sp;
+    r->occ_slot_async[b] = beside;
+    return TBRM_OK;
+}
+
+// The light-volume updates of n (<= kApplyMaxPasses) consecutive plans whose L is all kept, as one launch
+static int enqueue_apply(tbrm_resources* r, const PassPlan* const* plans, int n)
+{
+    ApplyParams ap{};
+    ap.light = r->d_light;
+    for (int k = 0; k < 3; ++k) ap.lv_dims[k] = r->lv_dims[k];
+    ap.lv_bnx = r->lbn[0]; ap.lv_bnxy = r->lbn[0] * r->lbn[1]; ap.lv_bnz = r->lbn[2];
+    ap.lv_fmt = r->lv_fmt;
+    ap.n_passes = n;
+    for (int i = 0; i < n; ++i) {
+        const PassPlan& plan = *plans[i];
+        ApplyPass& q = ap.pass[i];
+        q.axis = plan.p.axis; q.W = plan.p.W; q.H = plan.p.H;
+        q.start = plan.start; q.dir = plan.dir;
+        q.la = plan.kept_a->base + kPlaneGuard;
+        q.lr = plan.kept_r ? plan.kept_r->base + kPlaneGuard : nullptr;
+        q.b_added = plan.apply_b;
+    }
+    HIP_TRY(launch_apply_kept(ap, r->stream));
+    ++r->launches[0];
+    return TBRM_OK;
+}
+
+static bool plan_has_occlusion(const PassPlan& plan) { return !plan.sliced && !plan.apply && plan.n_chunks > 0; }
+
+// Enqueues chunk c of the plan: in front of a span's first chunk the occlusion of the span unless it is already under way,
+// and the occlusion of the span after it (of this plan, or the first of `next`) beside this span's chain; then the chain.
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next)
 {
     if (plan.sliced) {
         PropParams sp = plan.slice_params;
@@ -530,19 +620,8 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
         return TBRM_OK;
     }
     if (plan.apply) { // every L of the pass is at hand: the light-volume update alone
-        ApplyParams ap{};
-        ap.light = r->d_light;
-        for (int k = 0; k < 3; ++k) ap.lv_dims[k] = r->lv_dims[k];
-        ap.lv_bnx = r->lbn[0]; ap.lv_bnxy = r->lbn[0] * r->lbn[1]; ap.lv_bnz = r->lbn[2];
-        ap.lv_fmt = r->lv_fmt;
-        ap.axis = plan.p.axis; ap.W = plan.p.W; ap.H = plan.p.H;
-        ap.start = plan.start; ap.dir = plan.dir;
-        ap.la = plan.kept_a->base + kPlaneGuard;
-        ap.lr = plan.kept_r ? plan.kept_r->base + kPlaneGuard : nullptr;
-        ap.b_added = plan.apply_b;
-        HIP_TRY(launch_apply_kept(ap, r->stream));
-        ++r->launches[0];
-        return TBRM_OK;
+        const PassPlan* one[1] = {&plan};
+        return enqueue_apply(r, one, 1);
     }
     ChunkParams p = plan.p;
     const int M = plan.M, D = plan.D, W = p.W, H = p.H;
@@ -550,28 +629,28 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
     const SpanRange q = span_range(plan, sp);
     const size_t slice_elems = (size_t) W * H;
     const int ns = plan.n_streams();
-    // the propagated streams' occlusion: one launch per span computes both (a block is flagged empty when it is empty for
-    // both), or the added light alone with the Change shader's rules when the removed light's L is kept
-    const int occ_mode = plan.mode == PASS_CHANGE_CACHED ? PASS_CHANGE_ONE : plan.mode;
-    OccStore* const fs = &r->occ_tmp[0];
-    int* const counts = (int*) (fs->list + fs->flag_bytes);
-    p.a.occ_next = r->occ_tmp[0].base + kPlaneGuard;
-    p.r.occ_next = ns == 2 ? r->occ_tmp[1].base + kPlaneGuard : nullptr;
-    if (c == 0 && plan.sparse) {
-        p.occ_flags_out = fs->flags;
-        p.occ_list_out = plan.work_list ? fs->list : nullptr;
-        p.occ_count_out = counts;
-        HIP_TRY(launch_occ_flags(p, occ_mode, plan.n_spans, r->stream));
+    OccStore* const fs = &r->occ_tmp[plan.serial & 1][0];
+    auto holds = [&](int b) { return r->occ_slot[b].plan_serial == plan.serial && r->occ_slot[b].span == sp; };
+    int ob = holds(0) ? 0 : (holds(1) ? 1 : -1); // the buffer with this span's occlusion
+    if (c == q.c0) {
+        if (ob < 0) {
+            ob = r->occ_last ^ 1;
+            if (int e = enqueue_occlusion(r, plan, sp, ob, false)) return e;
+        }
+        if (r->occ_slot_async[ob]) {
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->occ_ev_ready[ob], 0));
+            r->occ_slot_async[ob] = false;
+        }
+        r->occ_last = ob;
+        // the span after this one — beside a chain that propagates one stream: the LDS of a two-stream chain leaves an
+        // occlusion workgroup no room on its CU
+        if (tune(TUNE_OCC_OVERLAP) > 0 && ns == 1) {
+            const PassPlan* np = sp + 1 < plan.n_spans ? &plan : (next && plan_has_occlusion(*next) ? next : nullptr);
+            if (np)
+                if (int e = enqueue_occlusion(r, *np, np == &plan ? sp + 1 : 0, ob ^ 1, true)) return e;
+        }
     }
-    if (c == q.c0) { // occlusion of the span: fills {a,r}.occ_next with sn planes
-        p.j0 = plan.start + q.s0 * plan.dir;
-        p.n_steps = q.sn;
-        p.occ_flags = nullptr;
-        p.occ_list = q.sparse && plan.work_list ? fs->list + (size_t) sp * plan.flags_per_span : nullptr;
-        p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
-        if (q.sparse && !plan.work_list) p.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
-        HIP_TRY(launch_light_occlusion(p, occ_mode, r->stream));
-    }
+    if (ob < 0) return fail(TBRM_ERR_INVALID_ARG, "chunk %d enqueued before the first chunk of its span", c);
     const int k0 = c * M - q.s0; // first slice of the chunk within the span
     p.n_steps = std::min(M, D - c * M);
     p.j0 = plan.start + c * M * plan.dir;
@@ -581,7 +660,7 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c)
     ChunkStream* const streams[2] = {&p.a, &p.r};
     const uint8_t* const chunk_flags = q.sparse ? fs->flags + (size_t) sp * plan.flags_per_span + (size_t) (k0 / kOccSlices) * plan.flags_per_group : nullptr;
     for (int si = 0; si < ns; ++si) {
-        streams[si]->occ_base = r->occ_tmp[si].base;
+        streams[si]->occ_base = r->occ_tmp[ob][si].base;
         streams[si]->occ_off = (uint32_t) (kPlaneGuard + (size_t) k0 * slice_elems);
         streams[si]->occ_flags = chunk_flags;
         // the contribution cache keeps L in pass order: plane k of an entry is the pass's k-th slice
@@ -685,8 +764,17 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             if (int e = enqueue_pass_sliced(r, p, q.a, q.two ? &q.r : nullptr)) return e;
             continue;
         }
+        if (plans[i].apply) { // a run of passes that only update the light volume: one launch
+            const PassPlan* run[kApplyMaxPasses];
+            int n = 0;
+            while (i + n < specs.size() && n < kApplyMaxPasses && chunked[i + n] && plans[i + n].apply) { run[n] = &plans[i + n]; ++n; }
+            if (int e = enqueue_apply(r, run, n)) { unpin_kept(r); return e; }
+            i += (size_t) n - 1;
+            continue;
+        }
+        const PassPlan* next = i + 1 < specs.size() && chunked[i + 1] ? &plans[i + 1] : nullptr;
         for (int c = 0; c < plans[i].n_chunks; ++c)
-            if (int e = enqueue_plan_chunk(r, plans[i], c)) { unpin_kept(r); return e; }
+            if (int e = enqueue_plan_chunk(r, plans[i], c, next)) { unpin_kept(r); return e; }
     }
     unpin_kept(r);
     return TBRM_OK;
@@ -749,14 +837,16 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         // only pays when the union of the two tap ranges is no wider than the wider of the two — then 0.3 to 0.5 ms per
         // paired pass (lights 1 and 7: 3.61 -> 2.53 ms for both passes); with diverging directions the wider windows and
         // shorter chunks cost up to 0.2 ms more than they save.
+        // A pass whose L is kept is applied without propagation (k_apply_kept), which beats any pairing.
+        auto kept = [&](const tbrm_light_pass& q) { return cache_usable(r) && kept_find(r, kept_key(r, base, q, true)) != nullptr; };
         Entry* partner = nullptr;
         ChunkFit fa;
-        if (pairing && chunk_fit(r, a.p, nullptr, fa)) {
+        if (pairing && !kept(a.p) && chunk_fit(r, a.p, nullptr, fa)) {
             int best_area = INT32_MAX;
             for (size_t ib = ia + 1; ib < all.size(); ++ib) {
                 Entry& b2 = all[ib];
                 ChunkFit fb, fp;
-                if (b2.done || b2.light == a.light || b2.p.face != a.p.face) continue;
+                if (b2.done || b2.light == a.light || b2.p.face != a.p.face || kept(b2.p)) continue;
                 if (!chunk_fit(r, b2.p, nullptr, fb) || !chunk_fit(r, a.p, &b2.p, fp)) continue;
                 if (tune(TUNE_LIGHT_BATCHING) == 2) { partner = &b2; break; } // diagnostics: pair whatever fits
                 const int sx = fp.tx.hi - fp.tx.lo, sy = fp.ty.hi - fp.ty.lo;

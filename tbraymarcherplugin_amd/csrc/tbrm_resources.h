@@ -96,7 +96,16 @@ struct tbrm_resources {
     int lbn[3]{};                  // light volume bricks per axis
     void* d_buf[3][4]{};           // the reference's read/write buffers (slice-per-launch fallback path)
     float* d_plane[4]{};           // chunk kernel: propagated-light planes, 2 per stream
-    OccStore occ_tmp[2];           // chunk kernels: the occlusion stores of the two streams (allocated on first use)
+    // chunk kernels: the occlusion stores, [buffer][stream] (allocated on first use). Spans alternate between the two
+    // buffers so that the occlusion of the next span — which depends on the data volume alone — can run on occ_stream beside
+    // the chain of the current one (enqueue_plan_chunk); the flags / work lists of a pass live in occ_tmp[pass serial & 1][0].
+    OccStore occ_tmp[2][2];
+    struct OccSlot { uint64_t plan_serial = 0; int span = -1; } occ_slot[2]; // what each buffer holds (or will, once occ_ev_ready fires)
+    bool occ_slot_async[2] = {false, false};                                 // ... computed on occ_stream
+    int occ_last = 1;              // buffer of the most recent span
+    uint64_t plan_serial = 0;      // PassPlan::serial of the last plan made
+    hipStream_t occ_stream = nullptr; // low priority; created with the first overlapped launch
+    hipEvent_t occ_ev_fork[2]{}, occ_ev_ready[2]{};
     std::vector<KeptPass*> kept;   // the contribution cache (every entry nx*ny*nz floats: an axis pass covers the light volume once)
     uint64_t kept_clock = 0;       // its LRU clock
     uint64_t kept_hits = 0, kept_computed = 0; // stream-passes served from the cache / propagated (tbrm_light_cache_stats)
@@ -160,6 +169,7 @@ struct ChunkFit { int M = 0; TapRange tx, ty; };
 struct PassPlan {
     ChunkParams p{};
     int mode = PASS_ADD;        // PASS_ADD / PASS_CHANGE / PASS_ADD2
+    uint64_t serial = 0;        // identifies the plan (occlusion buffers are labelled with it)
     int n_streams() const { return (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2; } // streams propagated
     bool two_streams() const { return n_streams() == 2; }
     int M = 0, S = 0;           // slices per chain chunk / per occlusion span
@@ -193,7 +203,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
-int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c);
+int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next = nullptr); // next: the plan enqueued after this one
 void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the contribution cache (the stream must be idle)
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
 int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,

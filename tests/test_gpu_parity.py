@@ -508,6 +508,71 @@ def test_batched_light_removal_matches_oracle_replay(gpu, oracle_mod):
         assert_light_equal(res, orc)
 
 
+@pytest.mark.parametrize("light_32bit", [False, True])
+def test_reset_all_lights_from_kept_passes_is_one_launch_and_bit_exact(gpu, oracle_mod, light_32bit):
+    """ResetAllLights (RaymarchVolume.cpp:418-451: clear, then every light again) when every light's L is kept: the batched
+    call applies all axis passes with ONE k_apply_kept launch (ragged dimensions: regions of 32 x 32 x 8 voxels overhang the
+    volume on every axis; passes along all three axes), no pass is paired or propagated, and the light volume follows the
+    oracle's replay of the reported order."""
+    dims = (70, 45, 52)
+    res, orc = make_pair(gpu, oracle_mod, dims, np.uint16, light_32bit, seed=0x5EED0502)
+    world = S.default_world()
+    lights = [S.light(i) for i in (0, 1, 2, 5)]
+    axes = {abi.host_light_passes(l, world, dims)[0][k].axis for l in lights for k in range(abi.host_light_passes(l, world, dims)[1])}
+    assert axes == {0, 1, 2}
+    n_passes = sum(abi.host_light_passes(l, world, dims)[1] for l in lights)
+    assert 4 < n_passes <= 8
+    with res:
+        for l in lights:  # one by one: every pass propagated and kept
+            res.add_dir_light(l, True, world)
+        res.clear_light_volume(0.0)
+        orc.clear_light_volume(0.0)
+        before, launches = res.light_cache_stats(), res.launch_counters()["chunk"]
+        sched = res.add_dir_lights(lights, True, world)
+        after = res.light_cache_stats()
+        assert all(b < 0 for _, _, b, _ in sched) and len(sched) == n_passes, sched
+        assert after["hits"] - before["hits"] == n_passes and after["propagated"] == before["propagated"], (before, after)
+        assert res.launch_counters()["chunk"] - launches == 1
+        for la, pa, _, _ in sched:
+            orc.add_dir_light_pass(lights[la], True, world, pa)
+        assert_light_equal(res, orc)
+        # and the removal of two of them, again from what is kept
+        res.add_dir_lights(lights[1:3], False, world)
+        for l in lights[1:3]:
+            orc.add_dir_light(l, False, world)
+        assert_light_equal(res, orc)
+
+
+def test_occlusion_beside_the_chain_changes_nothing(gpu, tunables):
+    """occ_overlap (tbrm.h): the occlusion of the next span — of the same pass or the first of the next pass — runs on a
+    second stream beside the current span's propagation, into the other of two buffers. Several spans per pass (depth over
+    128 slices), several passes and operators back to back: the light volume is the one of the serial schedule, bit for bit."""
+    dims = (150, 96, 140)
+    vol = small_volume(dims, np.uint16, seed=0x5EED0503)
+    world = S.default_world()
+    results = []
+    for overlap in (0, 2, 1):
+        tunables("occ_overlap", overlap)
+        with abi.Resources(dims, abi.FMT_G16, False) as res:
+            res.upload_volume(vol)
+            res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
+            res.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+            res.clear_light_volume(0.0)
+            for i in range(4):
+                res.add_dir_light(S.light(i), True, world)
+            cur = S.light(1)
+            for k in range(1, 4):  # both lights, then twice the new light alone (the kept L of the old one)
+                new = abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0 * k), S.LIGHTS[1][1])
+                res.change_dir_light(cur, new, world)
+                cur = new
+            res.add_dir_lights([S.light(4), S.light(6)], True, world)
+            res.add_dir_light(S.light(0), False, world)
+            results.append(res.download_light_volume())
+            assert res.launch_counters()["slice"] == 0
+    assert results[0].max() > 60
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+
+
 # ---- randomized sweep of the light operators --------------------------------------------------------------------------
 
 @pytest.mark.parametrize("seed", list(range(24)) + [100, 101, 102, 103])
