@@ -137,8 +137,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if constexpr (NS == 2) dma_16(p.r.plane_in + st_src[rd], window(0, 1) + st_dst[rd]);
         }
     }
-    stage_occ(0, 0);
-    stage_occ(1, 1);
 
     // ---- light-volume tile: the 4x4 brick columns under the tile, every brick layer the chunk touches --------------
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
@@ -260,6 +258,10 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         }
     };
 
+    // the first two slices' occlusion planes, last: the flag loads they select their source with have had the slot set-up
+    // above to arrive in
+    stage_occ(0, 0);
+    stage_occ(1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's copies (input window, first occlusion planes, tile) have landed
     __syncthreads();
     // slots outside the buffer hold the read sampler's border colour in BOTH windows for the whole chunk
