@@ -168,7 +168,7 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
 /* Process-wide tunables: A/B switches for measurements and parity tests (no counterpart in the reference; nothing a
  * host needs to call). Each starts from the environment variable TBRM_<NAME IN CAPITALS>, read once when the library is
  * loaded; no operator reads the environment. Names (default): force_slice_kernel (0), chunk_steps (0 = by fit),
- * occ_slices (0 = 128), sparse_occ (1), occ_list (1), light_cache_mb (16384), light_batching (1; 0 never, 2 always), share_grid (1),
+ * occ_slices (0 = 128), sparse_occ (1), occ_list (1), light_cache_mb (-1 = while half of the device's memory stays free; 0 = off), light_batching (1; 0 never, 2 always), share_grid (1),
  * ray_lanes (0 = by load; 4 / 8), chain_fast_loop (1), occ_overlap (2 = workgroups per CU of an occlusion launch that runs
  * beside the previous span's propagation; 0 = one after the other). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
@@ -376,8 +376,8 @@ TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
  * axis pass of the Add / Change shaders does to the light volume is a function of L, the light's propagated value per
  * voxel (AddDirLightShader.usf:117-126, ChangeDirLightShader.usf:140-154), and L depends on the volume, the transfer
  * function, the window, the clip plane and the light — not on the light volume. A pass that propagates a light which
- * stays in the scene keeps its L (nx*ny*nz floats per axis pass, least recently used first out, budget = tunable
- * light_cache_mb, default 16 GiB; 0 turns the cache off). Later operators on the same light then skip its propagation:
+ * stays in the scene keeps its L (nx*ny*nz floats per axis pass, least recently used first out; tunable light_cache_mb:
+ * a budget in MiB, 0 turns the cache off, the default -1 adds entries while half of the device's memory stays free). Later operators on the same light then skip its propagation:
  * removing it, or adding it again after ClearResourceLightVolumes, applies the kept L; ChangeDirLight propagates only the
  * NEW light and reads the old one's L. out[0] = stream-passes served from the cache, out[1] = stream-passes propagated,
  * out[2] = entries held, out[3] = their bytes. */

@@ -32,7 +32,7 @@ thread_local char g_error[512] = "";
 // ---- tunables (tbrm_internal.h): name, default; initialised from TBRM_<NAME> when the library is loaded ------------
 struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
-    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", 16384},
+    {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"occ_overlap", 2},
 };

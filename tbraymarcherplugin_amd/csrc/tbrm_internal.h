@@ -234,7 +234,7 @@ enum Tunable : int {
     TUNE_OCC_SLICES,         // slices per occlusion span (0: default)
     TUNE_SPARSE_OCC,         // 0: occlusion blocks that can only see empty bricks are computed like the others
     TUNE_OCC_LIST,           // 0: live occlusion blocks keep their grid position instead of being dealt from a work list
-    TUNE_LIGHT_CACHE_MB,     // HBM budget of the contribution cache in MiB (0: off): a light's propagated values L, kept per axis pass
+    TUNE_LIGHT_CACHE_MB,     // HBM budget of the contribution cache in MiB (0: off, < 0: while half the device stays free): a light's L, kept per axis pass
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load

@@ -798,7 +798,7 @@ def test_contribution_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_
              ("tf", lut_b), ("change", rot(1, 20), rot(1, 25)), ("add", l0),
              ("volume", vol2), ("change", rot(1, 25), rot(1, 30)), ("remove", l0), ("change", rot(1, 30), rot(1, 90))]  # last: across faces
     finals, stats = [], []
-    for cache_mb in (16384, 0):
+    for cache_mb in (-1, 0, 8):  # the default (entries while half the device stays free), off, room for three entries (evictions)
         tunables("light_cache_mb", cache_mb)
         orc = oracle_mod.OracleScene(vol, light_32bit)
         orc.set_tf_lut(lut_a)
@@ -833,13 +833,15 @@ def test_contribution_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_
                     orc = orc2
                     continue
                 assert_light_equal(res, orc)
-                if cache_mb and i == 4:
+                if cache_mb < 0 and i == 4:
                     before = res.light_cache_stats()
-                if cache_mb and i == 5:
+                if cache_mb < 0 and i == 5:
                     after = res.light_cache_stats()
                     assert after["hits"] - before["hits"] == 4 and after["propagated"] == before["propagated"], (before, after)
             finals.append(res.download_light_volume())
             stats.append(res.light_cache_stats())
             assert res.launch_counters()["slice"] == 0
-    assert stats[0]["hits"] >= 10 and stats[0]["entries"] > 0 and stats[1]["hits"] == 0 and stats[1]["entries"] == 0, stats
-    assert np.array_equal(finals[0], finals[1]) if not light_32bit else np.abs(finals[0] - finals[1]).max() == 0.0
+    assert stats[0]["hits"] >= 10 and stats[0]["entries"] > 3 and stats[1]["hits"] == 0 and stats[1]["entries"] == 0, stats
+    assert 0 < stats[2]["entries"] <= 3 and stats[2]["bytes"] <= 8 << 20, stats
+    for other in finals[1:]:
+        assert np.array_equal(finals[0], other) if not light_32bit else np.abs(finals[0] - other).max() == 0.0

@@ -6,7 +6,7 @@ set -u
 OUT=gpurun_out/${1:-round}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > "$OUT/tests.txt"
+(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" | tail -8) > "$OUT/tests.txt"
 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python bench.py --no-cpu-baseline --timed-only > "$OUT/bench_n1_under_rocprof.json" 2> /dev/null
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench_n1.csv" \;
@@ -20,6 +20,10 @@ python tools/pmc_traffic.py /tmp/pmc_fetch.csv /tmp/pmc_write.csv "$OUT/pmc_traf
 python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only.json" 2> /dev/null
 python tools/prof_light.py 2>&1 | grep -v amdgpu.ids > "$OUT/operators.txt"
 python tools/change_sweep.py "" "light_cache_mb=0" 2>&1 | grep -v amdgpu.ids >> "$OUT/operators.txt"
+(echo "== tools/change_sequence.py (one light turned 5 degrees per call)"; python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids
+ echo "== the same, occ_overlap=0"; TBRM_OCC_OVERLAP=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -6
+ echo "== the same, light_cache_mb=0"; TBRM_LIGHT_CACHE_MB=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -4
+ echo "== tools/apply_time.py"; python tools/apply_time.py 2>&1 | grep -v amdgpu.ids) >> "$OUT/operators.txt"
 for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
 TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"
 cat "$OUT/tests.txt" "$OUT/operators.txt"
