@@ -106,6 +106,12 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                     st_one[si][rd][z] = one;
                 }
             }
+            // the removed light's kept L is read at the owned pixels only: groups outside the tile take the "flagged" route
+            // (the first KB of the allocation, whatever it holds) instead of fetching 2 of 3 plane pixels for nothing
+            if constexpr (CACHED) {
+                const bool in_tile = row >= g.pady && row < g.pady + TY && col >= g.padx && col < g.padx + TX;
+                st_one[1][rd][0] = st_one[1][rd][1] = !in_tile;
+            }
         }
     }
     // A stream's occlusion planes and a page of ones live in one allocation: a copy's source is the stream's uniform base

@@ -231,6 +231,7 @@ void release_occ_stores(tbrm_resources* r)
         delete e;
     }
     r->kept.clear();
+    r->kept_auto_entries = -1;
 }
 
 // room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass
@@ -303,8 +304,13 @@ static KeptPass* kept_new(tbrm_resources* r, const KeptKey& key)
     size_t budget = (size_t) std::max(tune(TUNE_LIGHT_CACHE_MB), 0) << 20;
     bool room = (r->kept.size() + 1) * bytes <= budget;
     if (tune(TUNE_LIGHT_CACHE_MB) < 0) {
-        size_t free_b = 0, total_b = 0;
-        room = r->kept.size() < 32 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b >= bytes && free_b - bytes >= total_b / 2;
+        if (r->kept_auto_entries < 0) { // asked once per handle (hipMemGetInfo takes milliseconds); a later allocation that fails shrinks it
+            size_t free_b = 0, total_b = 0;
+            r->kept_auto_entries = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > total_b / 2)
+                r->kept_auto_entries = (int) std::min<size_t>(32, (free_b - total_b / 2) / bytes);
+        }
+        room = (int) r->kept.size() < r->kept_auto_entries;
         budget = room ? (r->kept.size() + 1) * bytes : r->kept.size() * bytes;
     }
     KeptPass* e = nullptr;
@@ -314,6 +320,7 @@ static KeptPass* kept_new(tbrm_resources* r, const KeptKey& key)
         if (hipMalloc((void**) &e->base, bytes) != hipSuccess) { // out of HBM: do without
             (void) hipGetLastError();
             delete e;
+            r->kept_auto_entries = std::min(r->kept_auto_entries, (int) r->kept.size());
             return nullptr;
         }
         r->kept.push_back(e);

@@ -108,6 +108,7 @@ struct tbrm_resources {
     hipEvent_t occ_ev_fork[2]{}, occ_ev_ready[2]{};
     std::vector<KeptPass*> kept;   // the contribution cache (every entry nx*ny*nz floats: an axis pass covers the light volume once)
     uint64_t kept_clock = 0;       // its LRU clock
+    int kept_auto_entries = -1;    // light_cache_mb < 0: entries this handle may hold (-1: not asked yet)
     uint64_t kept_hits = 0, kept_computed = 0; // stream-passes served from the cache / propagated (tbrm_light_cache_stats)
     uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
 

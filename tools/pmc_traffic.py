@@ -22,6 +22,33 @@ def per_kernel(path, counter):
     return acc
 
 
+LIGHT_KERNELS = ("k_light_chain", "k_light_occlusion", "k_occ_flags", "k_occ_compact", "k_apply_kept", "k_propagate_slice")
+
+
+def operator_runs(path, counter, scale):
+    """Bytes of every ChangeDirLight call of the profiled command (bench.py --timed-only: setup, then per step one
+    ChangeDirLight and one frame): in dispatch order, every maximal run of light-operator kernels AFTER the first frame is one
+    call (the runs before it are the setup's ResetAllLights). Returns [(bytes, kind)], kind = which chain kernels ran:
+    'cached' (MODE 4: only the new light propagated), 'both' (MODE 1), 'remove+add' (MODE 0), 'applied' (k_apply_kept alone)."""
+    rows = []
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"].split("(")[0].replace("void ", "").strip(), float(row["Counter_Value"])))
+    rows.sort()
+    runs, cur, modes, seen_frame = [], 0.0, set(), False
+    for _, name, value in rows:
+        if "k_raymarch_lit" in name:
+            if seen_frame and modes:
+                kind = "cached" if "4" in modes else ("both" if "1" in modes else ("remove+add" if "0" in modes else "applied"))
+                runs.append((cur * scale, kind))
+            seen_frame, cur, modes = True, 0.0, set()
+        elif seen_frame and any(k in name for k in LIGHT_KERNELS):
+            cur += value
+            m = re.search(r"k_light_chain<\d+, (\d+),", name)
+            modes.add(m.group(1) if m else "apply")
+    return runs
+
+
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
@@ -35,17 +62,19 @@ def main():
         wr = w * 1024 / max(nw, 1)
         out[name] = {"launches": max(nf, nw), "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                      "hbm_bytes_per_launch": rd + wr, "fetch_size_raw_kib": f / max(nf, 1), "write_size_raw_kib": w / max(nw, 1)}
-    # per operator call: every step of the profiled bench command (bench.py --timed-only) makes one ChangeDirLight and one
-    # raymarch, so the number of raymarch launches is the number of Change calls; the Change's kernels are
-    # k_light_chain<LFMT, MODE = 1, AXIS, KH, RS> and k_light_occlusion<DFMT, MODE, AXIS> with MODE = 1 (both streams) or 3
-    # (the added stream alone: the removed one came from the occlusion cache); the flag kernels move < 0.2 MB per pass
+    # per operator call (see operator_runs); reads doubled like the per-kernel figures
+    reads, writes = operator_runs(sys.argv[1], "FETCH_SIZE", 2.0 * 1024), operator_runs(sys.argv[2], "WRITE_SIZE", 1024.0)
     ray = [v for k, v in out.items() if "k_raymarch_lit" in k]
-    if ray:
-        calls = sum(v["launches"] for v in ray)
-        change = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in out.items()
-                     if re.search(r"k_light_chain<\d+, 1,", k) or re.search(r"k_light_occlusion<\d+, [13],", k))
-        out["_per_operator_call"] = {"calls": calls, "change_dir_light_hbm_bytes": change / calls,
-                                     "raymarch_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ray) / calls}
+    if ray and reads and len(reads) == len(writes):
+        calls = [(r[0] + w[0], r[1]) for r, w in zip(reads, writes)]
+        by_kind = collections.defaultdict(list)
+        for b, kind in calls:
+            by_kind[kind].append(b)
+        out["_per_operator_call"] = {
+            "change_dir_light_calls": len(calls),
+            "change_dir_light_hbm_bytes": sum(b for b, _ in calls) / len(calls),
+            "change_dir_light_hbm_bytes_by_kind": {k: {"calls": len(v), "hbm_bytes": sum(v) / len(v)} for k, v in sorted(by_kind.items())},
+            "raymarch_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ray) / sum(v["launches"] for v in ray)}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if k.startswith("_"):
