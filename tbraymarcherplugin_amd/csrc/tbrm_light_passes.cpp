@@ -315,7 +315,12 @@ static KeptPass* kept_new(tbrm_resources* r, const KeptKey& key)
     }
     KeptPass* e = nullptr;
     if (bytes > budget) return nullptr;
-    if (room) {
+    // an entry whose light a ChangeDirLight has replaced is taken first (no allocation while lights merely move: hipMalloc
+    // of a 4.3 GB entry at 1024^3 holds the host up for tens of milliseconds), oldest first
+    for (KeptPass* c : r->kept)
+        if (c->spent && !c->pinned && (!e || c->last_use < e->last_use)) e = c;
+    if (e) {
+    } else if (room) {
         e = new KeptPass{};
         if (hipMalloc((void**) &e->base, bytes) != hipSuccess) { // out of HBM: do without
             (void) hipGetLastError();
@@ -330,14 +335,16 @@ static KeptPass* kept_new(tbrm_resources* r, const KeptKey& key)
         if (!e) return nullptr;
     }
     e->valid = false;
+    e->spent = false;
     e->key = key;
     e->pinned = true;
     e->last_use = ++r->kept_clock;
     return e;
 }
 
-static void use_kept(tbrm_resources* r, KeptPass* e)
+static void use_kept(tbrm_resources* r, KeptPass* e, bool as_removed = false)
 {
+    e->spent = as_removed;
     e->pinned = true;
     e->last_use = ++r->kept_clock;
 }
@@ -372,6 +379,12 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
         have_a = kept_find(r, key_a);
         if (change) have_r = kept_find(r, kept_key(r, base, *pr, false));
     }
+    // whatever is kept of a light that this pass takes out of the scene (the removed side of a Change, a removal) is of no
+    // further use unless the light comes back: first in line when an entry is needed (kept_new)
+    auto retire = [&](const tbrm_light_pass& q) {
+        for (int guard = 0; guard < 2; ++guard)
+            if (KeptPass* e = kept_find(r, kept_key(r, base, q, guard != 0))) e->spent = true;
+    };
     if (have_a && (!change || have_r)) { // nothing to propagate: one k_apply_kept launch
         plan = PassPlan{};
         plan.mode = mode;
@@ -388,7 +401,9 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
         plan.n_chunks = 1;
         plan.chunks_of_pass = 1;
         use_kept(r, have_a);
-        if (have_r) use_kept(r, have_r);
+        if (have_r) use_kept(r, have_r, true);
+        if (change) retire(*pr);
+        else if (b_added < 0.0f) retire(pa);
         r->kept_hits += change ? 2 : 1;
         return TBRM_OK;
     }
@@ -412,11 +427,13 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     plan.mode = mode;
     if (mode == PASS_CHANGE_CACHED) {
         plan.kept_r = have_r;
-        use_kept(r, have_r);
+        use_kept(r, have_r, true);
         ++r->kept_hits;
     }
     // what is added stays in the scene: its L is worth keeping (null: no room). What is removed does not.
     if (cache_on && !have_a && !(mode == PASS_ADD && b_added < 0.0f)) plan.keep[0] = kept_new(r, key_a);
+    if (cache_on && change) retire(*pr);
+    if (cache_on && !change && b_added < 0.0f) retire(pa);
     r->kept_computed += (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2;
     ChunkParams& p = plan.p;
     p.data = base.data;

@@ -59,6 +59,7 @@ struct KeptPass {
     KeptKey key{};
     bool valid = false;             // every chunk of the pass that fills it has been enqueued
     bool pinned = false;            // in use by the operator being planned
+    bool spent = false;             // served as the removed side of a ChangeDirLight: its light has left the scene
     uint64_t last_use = 0;
 };
 
