@@ -18,12 +18,15 @@ find /tmp/prof_fetch -name "*counter_collection.csv" -exec cp {} /tmp/pmc_fetch.
 find /tmp/prof_write -name "*counter_collection.csv" -exec cp {} /tmp/pmc_write.csv \;
 python tools/pmc_traffic.py /tmp/pmc_fetch.csv /tmp/pmc_write.csv "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
 python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only.json" 2> /dev/null
-python tools/prof_light.py 2>&1 | grep -v amdgpu.ids > "$OUT/operators.txt"
+(echo "== tools/prof_light.py, light_cache_mb=0 (every call propagates)"; TBRM_LIGHT_CACHE_MB=0 python tools/prof_light.py 2>&1 | grep -v amdgpu.ids
+ echo "== tools/prof_light.py, defaults (repeated calls are served from the kept L)"; python tools/prof_light.py 2>&1 | grep -v amdgpu.ids) > "$OUT/operators.txt"
+echo "== tools/change_sweep.py" >> "$OUT/operators.txt"
 python tools/change_sweep.py "" "light_cache_mb=0" 2>&1 | grep -v amdgpu.ids >> "$OUT/operators.txt"
 (echo "== tools/change_sequence.py (one light turned 5 degrees per call)"; python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids
  echo "== the same, occ_overlap=0"; TBRM_OCC_OVERLAP=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -6
  echo "== the same, light_cache_mb=0"; TBRM_LIGHT_CACHE_MB=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -4
- echo "== tools/apply_time.py"; python tools/apply_time.py 2>&1 | grep -v amdgpu.ids) >> "$OUT/operators.txt"
+ echo "== tools/apply_time.py"; python tools/apply_time.py 2>&1 | grep -v amdgpu.ids
+ echo "== tools/host_enqueue_time.py"; python tools/host_enqueue_time.py 2>&1 | grep -v amdgpu.ids) >> "$OUT/operators.txt"
 for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
 TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"
 cat "$OUT/tests.txt" "$OUT/operators.txt"
