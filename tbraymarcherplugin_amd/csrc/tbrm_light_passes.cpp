@@ -811,7 +811,13 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         }
         const PassPlan* next = i + 1 < specs.size() && chunked[i + 1] ? &plans[i + 1] : nullptr;
         for (int c = 0; c < plans[i].n_chunks; ++c)
-            if (int e = enqueue_plan_chunk(r, plans[i], c, next)) { unpin_kept(r); return e; }
+            if (int e = enqueue_plan_chunk(r, plans[i], c, next)) {
+                // an occlusion already under way beside the chain will not be consumed: nothing may outlive the operator on
+                // the second stream (the caller may free or overwrite what it reads)
+                if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
+                unpin_kept(r);
+                return e;
+            }
     }
     unpin_kept(r);
     return TBRM_OK;
