@@ -230,7 +230,8 @@ int ensure_skipping(tbrm_resources* r)
         r->empty_valid = false;
     }
     if (!r->empty_valid) {
-        int prefix[257];
+        int prefix[258]; // [257]: the shell-transparency flag (k_shell_transparent clears it)
+        prefix[257] = 1;
         prefix[0] = 0;
         for (int i = 0; i < 256; ++i) {
             const float a = r->tf_host[i * 4 + 3];
@@ -241,6 +242,17 @@ int ensure_skipping(tbrm_resources* r)
         HIP_TRY(hipStreamSynchronize(r->stream));
         EmptyParams ep{r->d_minmax, nb, window_dev(r), r->d_alpha_prefix, r->d_empty};
         HIP_TRY(launch_brick_empty(ep, r->stream));
+        // may the contribution cache serve the Add shader from what the Change shader propagated and the other way round?
+        // (one more host round trip per new transfer function / window / volume, next to the one above)
+        r->shell_transparent = false;
+        if (r->res_data.lo == 0 && r->res_data.hi == r->bn[2]) {
+            int flag = 0;
+            HIP_TRY(launch_shell_transparent(ep, r->bn[0], r->bn[1], r->bn[2], host_data_border(r->win, r->desc.border_mode),
+                                             r->d_alpha_prefix + 257, r->stream));
+            HIP_TRY(hipMemcpyAsync(&flag, r->d_alpha_prefix + 257, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            r->shell_transparent = flag != 0;
+        }
         // distance field for empty-space leaping: three separable passes, x then y then z
         const int mode = r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP;
         for (int axis = 0; axis < 3; ++axis) {
@@ -387,7 +399,7 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     CREATE_TRY(hipMalloc((void**) &r->d_minmax, nb * sizeof(float2)));
     CREATE_TRY(hipMalloc((void**) &r->d_empty, nb_pad / 8));
     for (int k = 0; k < 2; ++k) CREATE_TRY(hipMalloc((void**) &r->d_dist[k], nb_pad));
-    CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 257 * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 258 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**) &r->d_counter, sizeof(unsigned long long)));
     for (int k = 0; k < 2; ++k)
         for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));

@@ -176,6 +176,8 @@ struct EmptyParams {
     uint32_t* bits;
 };
 
+hipError_t launch_shell_transparent(const EmptyParams& p, int bnx, int bny, int bnz, float border, int* flag, hipStream_t s);
+
 constexpr int kSkipDistCap = 32;
 struct DistParams {
     const uint32_t* bits; // pass 0: the k_brick_empty bits

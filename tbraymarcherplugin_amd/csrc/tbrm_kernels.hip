@@ -612,37 +612,38 @@ hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s)
 // A brick is empty when every value in [min,max] maps to corrected opacity 0: the TF position is monotone in
 // the value (width > 0), so it suffices that the part of [pos(min), pos(max)] that survives the cutoffs only
 // touches TF texels with alpha <= 0.
+__device__ __forceinline__ bool range_maps_to_zero_opacity(float vmin, float vmax, const WindowDev& win, const int* alpha_prefix)
+{
+    if (!(win.width > 0.0f && vmin <= vmax && vmin > -__builtin_inff() && vmax < __builtin_inff())) return false;
+    float lo = tf_position(vmin, win.center, win.width);
+    float hi = tf_position(vmax, win.center, win.width);
+    if (!(lo == lo && hi == hi)) return false;
+    bool all_cut = false;
+    if (win.low_cutoff > 0.0f) {
+        if (hi < 0.0f) all_cut = true;
+        lo = fmaxf(lo, 0.0f);
+    }
+    if (win.high_cutoff > 0.0f) {
+        if (lo > 1.0f) all_cut = true;
+        hi = fminf(hi, 1.0f);
+    }
+    if (all_cut) return true;
+    int i_lo, i_hi;
+    float f;
+    texel_split(lo, 256.0f, i_lo, f);
+    texel_split(hi, 256.0f, i_hi, f);
+    i_lo = min(max(i_lo, 0), 255);
+    i_hi = min(max(i_hi + 1, 0), 255);
+    return (alpha_prefix[i_hi + 1] - alpha_prefix[i_lo]) == 0;
+}
+
 __global__ __launch_bounds__(256) void k_brick_empty(const EmptyParams p)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     bool empty = false;
     if (b < p.n_bricks) {
         const float2 mm = p.minmax[b];
-        if (p.win.width > 0.0f && mm.x <= mm.y && mm.x > -__builtin_inff() && mm.y < __builtin_inff()) {
-            float lo = tf_position(mm.x, p.win.center, p.win.width);
-            float hi = tf_position(mm.y, p.win.center, p.win.width);
-            if (lo == lo && hi == hi) {
-                bool all_cut = false;
-                if (p.win.low_cutoff > 0.0f) {
-                    if (hi < 0.0f) all_cut = true;
-                    lo = fmaxf(lo, 0.0f);
-                }
-                if (p.win.high_cutoff > 0.0f) {
-                    if (lo > 1.0f) all_cut = true;
-                    hi = fminf(hi, 1.0f);
-                }
-                if (all_cut) empty = true;
-                else {
-                    int i_lo, i_hi;
-                    float f;
-                    texel_split(lo, 256.0f, i_lo, f);
-                    texel_split(hi, 256.0f, i_hi, f);
-                    i_lo = min(max(i_lo, 0), 255);
-                    i_hi = min(max(i_hi + 1, 0), 255);
-                    empty = (p.alpha_prefix[i_hi + 1] - p.alpha_prefix[i_lo]) == 0;
-                }
-            }
-        }
+        empty = range_maps_to_zero_opacity(mm.x, mm.y, p.win, p.alpha_prefix);
     }
     const unsigned long long m = __ballot(empty);
     const int lane = threadIdx.x & 63;
@@ -656,6 +657,29 @@ hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s)
 {
     if (p.n_bricks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_brick_empty, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// Is the volume's shell transparent to the light shaders? *flag (preset to 1) is cleared when some brick of the outer brick
+// layer can produce a non-zero opacity from a blend of its values (min/max over the brick and its apron) with the data
+// sampler's border colour. When it stays 1, every sample of a light pass whose position lies outside the unit cube — taps
+// in that layer and beyond it — has CurrentSample exactly 0 under the Change shader's rules (ChangeDirLightShader.usf
+// samples unconditionally), which is what the Add shader's uvw == saturate(uvw) guard makes it (AddDirLightShader.usf:98):
+// the two shaders then propagate the same values for a light, and the contribution cache may serve either from the other's.
+__global__ __launch_bounds__(256) void k_shell_transparent(const EmptyParams p, int bnx, int bny, int bnz, float border, int* flag)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= p.n_bricks) return;
+    const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
+    if (bx != 0 && bx != bnx - 1 && by != 0 && by != bny - 1 && bz != 0 && bz != bnz - 1) return;
+    const float2 mm = p.minmax[b];
+    if (!range_maps_to_zero_opacity(fminf(mm.x, border), fmaxf(mm.y, border), p.win, p.alpha_prefix)) *flag = 0;
+}
+
+hipError_t launch_shell_transparent(const EmptyParams& p, int bnx, int bny, int bnz, float border, int* flag, hipStream_t s)
+{
+    if (p.n_bricks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shell_transparent, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p, bnx, bny, bnz, border, flag);
     return hipGetLastError();
 }
 

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             // the removed light's kept L is read at the owned pixels only: groups outside the tile take the "flagged" route
             // (the first KB of the allocation, whatever it holds) instead of fetching 2 of 3 plane pixels for nothing
             if constexpr (CACHED) {
-                const bool in_tile = row >= g.pady && row < g.pady + TY && col >= g.padx && col < g.padx + TX;
+                const bool in_tile = row >= g.pady && row < g.pady + TY && col + 4 > g.padx && col < g.padx + TX; // (overlaps it)
                 st_one[1][rd][0] = st_one[1][rd][1] = !in_tile;
             }
         }

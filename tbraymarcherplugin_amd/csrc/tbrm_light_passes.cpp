@@ -274,7 +274,9 @@ static KeptKey kept_key(const tbrm_resources* r, const PropParams& base, const t
     k.data_border = base.data_border;
     k.clip_mode = base.clip_mode;
     k.axis = q.axis; k.dir = q.dir; k.start = q.start; k.D = q.td[2]; k.W = q.td[0]; k.H = q.td[1];
-    k.guard = guard ? 1 : 0;
+    // the Add shader's uvw == saturate(uvw) guard only matters where a sample outside the cube could be opaque
+    // (k_shell_transparent): else both shaders propagate the same L and one entry serves both
+    k.guard = (guard && !r->shell_transparent) ? 1 : 0;
     k.step100 = q.step_size * 100.0f;
     k.prev_off[0] = q.prev_pixel_offset[0]; k.prev_off[1] = q.prev_pixel_offset[1];
     k.light_alpha = q.light_alpha;
@@ -772,6 +774,8 @@ struct PassSpec {
 // kernels decline takes the one-slice-per-launch path, any other planning failure leaves the light volume untouched.
 int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs)
 {
+    if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)
+        if (int e = ensure_skipping(r)) return e;
     std::vector<PassPlan> plans;
     std::vector<char> chunked;
     for (size_t i = 0; i < specs.size(); ++i) {
@@ -866,6 +870,8 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         for (int k = 0; k < n; ++k) all.push_back(Entry{i, k, passes[k], false});
     }
     const PropParams base = base_prop_params(r, world);
+    if (cache_usable(r))
+        if (int e = ensure_skipping(r)) return e;
     const float b = added ? 1.0f : -1.0f;
     const bool pairing = tune(TUNE_LIGHT_BATCHING) != 0;
     std::vector<PassSpec> specs;

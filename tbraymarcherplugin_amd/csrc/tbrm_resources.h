@@ -119,6 +119,7 @@ struct tbrm_resources {
     uint32_t* d_empty = nullptr;
     uint8_t* d_dist[2]{};          // empty-space leaping: per-brick distance field (ping-pong of the separable passes; [0] is final)
     int* d_alpha_prefix = nullptr;
+    bool shell_transparent = false; // valid with empty_valid (ensure_skipping): the Add and the Change shader propagate the same L
     bool minmax_valid = false, empty_valid = false;
 
     // Octree render mode: 4-level UNORM16 max pyramid (allocated by the first tbrm_generate_octree)

@@ -549,6 +549,62 @@ def test_reset_all_lights_from_kept_passes_is_one_launch_and_bit_exact(gpu, orac
         assert_light_equal(res, orc)
 
 
+@pytest.mark.parametrize("opaque_shell", [False, True])
+def test_add_and_change_share_kept_passes_only_when_the_shell_is_transparent(gpu, oracle_mod, opaque_shell):
+    """The Add shader skips samples outside the unit cube (AddDirLightShader.usf:98), the Change shader takes them with the
+    border colour (ChangeDirLightShader.usf:100-130). Where such a sample can be opaque the two propagate different values
+    and the contribution cache keeps them apart; where the volume's outer brick layer blended with the border colour maps to
+    opacity 0 (air around the scan: k_shell_transparent) both propagate the same L and a Change is served from what the Add
+    kept — and the removal across cube faces from what the Change kept. Either way the oracle's light volume, bit for bit."""
+    dims = (72, 64, 56)
+    vol = small_volume(dims, np.uint16, seed=0x5EED0504)
+    vol = vol.copy()
+    if not opaque_shell:  # air around the scan
+        shell = np.ones(vol.shape, dtype=bool)
+        shell[9:-9, 9:-9, 9:-9] = False
+        vol[shell] = 0
+    else:  # dense material up to the volume's faces
+        vol[:, :, :3] = 52000
+        vol[:, :2, :] = 48000
+        vol[-2:, :, :] = 50000
+    world = S.default_world()
+    lut = abi.color_curve_to_lut(S.TF_A_KEYS)
+    win = abi.WindowingParams(0.5, 0.9, True, False)
+    orc = oracle_mod.OracleScene(vol, False)
+    orc.set_tf_lut(lut)
+    orc.set_windowing(win)
+    l0, l1 = S.light(0), S.light(1)
+    turned = abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1])
+    across = abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 60.0), S.LIGHTS[1][1])
+    pa, _ = abi.host_light_passes(turned, world, dims)
+    pb, _ = abi.host_light_passes(across, world, dims)
+    assert (pa[0].face, pa[1].face) != (pb[0].face, pb[1].face)
+    with abi.Resources(dims, abi.FMT_G16, False) as res:
+        res.upload_volume(vol)
+        res.set_tf_lut(lut)
+        res.set_windowing(win)
+        res.clear_light_volume(0.0)
+        for l in (l0, l1):
+            res.add_dir_light(l, True, world)
+            orc.add_dir_light(l, True, world)
+        assert_light_equal(res, orc)
+        before = res.light_cache_stats()
+        res.change_dir_light(l1, turned, world)  # the removed side: what the Add kept, if the shaders agree
+        orc.change_dir_light(l1, turned, world)
+        mid = res.light_cache_stats()
+        assert_light_equal(res, orc)
+        res.change_dir_light(turned, across, world)  # across faces: Add(turned, removed) + Add(across, added)
+        orc.change_dir_light(turned, across, world)
+        after = res.light_cache_stats()
+        assert_light_equal(res, orc)
+        n1 = abi.host_light_passes(l1, world, dims)[1]
+        if opaque_shell:
+            assert mid["hits"] == before["hits"] and after["hits"] == mid["hits"], (before, mid, after)
+        else:
+            assert mid["hits"] - before["hits"] == n1, (before, mid)
+            assert after["hits"] - mid["hits"] == abi.host_light_passes(turned, world, dims)[1], (mid, after)
+
+
 def test_occlusion_beside_the_chain_changes_nothing(gpu, tunables):
     """occ_overlap (tbrm.h): the occlusion of the next span — of the same pass or the first of the next pass — runs on a
     second stream beside the current span's propagation, into the other of two buffers. Several spans per pass (depth over
@@ -581,7 +637,7 @@ def test_occlusion_beside_the_chain_changes_nothing(gpu, tunables):
 
 # ---- randomized sweep of the light operators --------------------------------------------------------------------------
 
-@pytest.mark.parametrize("seed", list(range(24)) + [100, 101, 102, 103])
+@pytest.mark.parametrize("seed", list(range(24)) + [100, 101, 102, 103, 129])  # 129: a cached Change whose ragged last chunk has windows 5 pixels wider than the tile
 def test_random_light_operator_sequences_against_oracle(gpu, oracle_mod, seed):
     """Seeded random scenes — ragged dimensions, data / light formats, half-resolution light volume, border modes, transfer
     functions and windows, rotated and non-uniformly scaled volumes, clip planes — and random sequences of Add / Remove /
