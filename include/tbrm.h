@@ -382,6 +382,9 @@ TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
  * NEW light and reads the old one's L. out[0] = stream-passes served from the cache, out[1] = stream-passes propagated,
  * out[2] = entries held, out[3] = their bytes. */
 TBRM_API int tbrm_light_cache_stats(const tbrm_resources* res, uint64_t out[4]);
+/* Gives the cache's HBM back (blocks until the handle's stream is idle). The next operators propagate and keep again —
+ * a host that wants the memory for good sets the tunable light_cache_mb to 0 first. */
+TBRM_API int tbrm_light_cache_clear(tbrm_resources* res);
 TBRM_API int tbrm_flush(tbrm_resources* res);                 /* FlushRenderingCommands() */
 TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's

@@ -125,7 +125,7 @@ SYMBOLS = [
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_light_cache_stats", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
@@ -514,6 +514,9 @@ class Resources:
         out = (C.c_uint64 * 4)()
         check(self.lib.tbrm_light_cache_stats(self.handle, C.byref(out)))
         return {"hits": int(out[0]), "propagated": int(out[1]), "entries": int(out[2]), "bytes": int(out[3])}
+
+    def light_cache_clear(self):
+        check(self.lib.tbrm_light_cache_clear(self.handle))
 
     def flush(self):
         check(self.lib.tbrm_flush(self.handle))

@@ -1101,6 +1101,15 @@ int tbrm_light_cache_stats(const tbrm_resources* r, uint64_t out[4])
     return TBRM_OK;
 }
 
+int tbrm_light_cache_clear(tbrm_resources* r)
+{
+    if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (int e = bind(r)) return e;
+    HIP_TRY(hipStreamSynchronize(r->stream)); // (every occlusion launch beside the chain has been waited for by a chain)
+    release_kept(r);
+    return TBRM_OK;
+}
+
 int tbrm_flush(tbrm_resources* r)
 {
     if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");

@@ -215,6 +215,16 @@ static SpanRange span_range(const PassPlan& plan, int sp)
 
 // ---- occlusion stores and the contribution cache (tbrm_resources.h) ----------------------------------------------------
 
+void release_kept(tbrm_resources* r)
+{
+    for (KeptPass* e : r->kept) {
+        (void) hipFree(e->base);
+        delete e;
+    }
+    r->kept.clear();
+    r->kept_auto_entries = -1;
+}
+
 void release_occ_stores(tbrm_resources* r)
 {
     if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
@@ -226,12 +236,7 @@ void release_occ_stores(tbrm_resources* r)
             st = OccStore{};
         }
     for (auto& slot : r->occ_slot) slot = tbrm_resources::OccSlot{};
-    for (KeptPass* e : r->kept) {
-        (void) hipFree(e->base);
-        delete e;
-    }
-    r->kept.clear();
-    r->kept_auto_entries = -1;
+    release_kept(r);
 }
 
 // room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass

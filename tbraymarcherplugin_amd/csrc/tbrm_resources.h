@@ -207,6 +207,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next = nullptr); // next: the plan enqueued after this one
+void release_kept(tbrm_resources* r);       // frees the contribution cache (the stream must be idle)
 void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the contribution cache (the stream must be idle)
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
 int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
