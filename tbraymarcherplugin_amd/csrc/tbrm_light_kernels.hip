@@ -5,12 +5,14 @@
 //   k_light_occlusion                 : once per span of up to 128 slices — the factor 1 - CurrentSample
 //                                       (AddDirLightShader.usf:85-117) of every voxel of the span, no halo, fully
 //                                       parallel, live blocks dealt evenly over the CUs from the list.
-//   k_light_chain                     : once per chunk of 16 / 8 / 4 slices — advances EVERY 32x32 tile of the slice
-//                                       plane through the chunk, so an axis pass over a 512-deep volume is 4 + 32..64
+//   k_light_chain (tbrm_light_chain.hip): once per chunk of 16 / 8 / 4 / 2 slices — advances EVERY 32x32 tile of the
+//                                       slice plane through the chunk, so an axis pass over a 512-deep volume is 4 + 32..64
 //                                       launches instead of the reference's 512 dispatches (LightingShaders.cpp:132-158).
+//   k_apply_kept                      : the light-volume update of passes whose propagated values are kept from an
+//                                       earlier operator (the contribution cache, tbrm_resources.h): no propagation.
 //   k_propagate_slice                 : the reference's structure, one slice per launch (AddDirLightShader.usf:68-128,
 //                                       ChangeDirLightShader.usf:74-156). Fallback for passes the chunk kernels
-//                                       decline (degenerate offsets) and the A/B baseline (TBRM_FORCE_SLICE_KERNEL=1).
+//                                       decline (degenerate offsets) and the A/B baseline (tunable force_slice_kernel).
 //
 // Why chunks work: slice k only needs the previous slice's propagated light inside a small bilinear footprint,
 // offset by the constant PrevPixelOffset. A workgroup that owns a 32x32 tile at the END of a chunk therefore only

@@ -30,7 +30,8 @@ inline size_t format_bytes(int fmt) { return fmt == TBRM_FMT_G8 ? 1 : (fmt == TB
 
 // The occlusion factors 1 - CurrentSample (AddDirLightShader.usf:85-117) of ONE light stream for a span of S slices of an
 // axis pass, as the chain kernel consumes them: [page of ones | guard][S x H x W floats][guard], plus the pass's
-// empty-block flags and work lists. Overwritten span by span.
+// empty-block flags and work lists. Overwritten span by span; a handle has two per stream, so that the next span's can be
+// written while the chain reads the current one's (tbrm_resources::occ_tmp).
 struct OccStore {
     float* base = nullptr;          // the allocation
     size_t capacity = 0;            // floats of planes it holds (slices x H x W of the pass it was sized for)
