@@ -169,7 +169,7 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * host needs to call). Each starts from the environment variable TBRM_<NAME IN CAPITALS>, read once when the library is
  * loaded; no operator reads the environment. Names (default): force_slice_kernel (0), chunk_steps (0 = by fit),
  * occ_slices (0 = 128), sparse_occ (1), occ_list (1), light_cache_mb (-1 = while half of the device's memory stays free; 0 = off), light_batching (1; 0 never, 2 always), share_grid (1),
- * ray_lanes (0 = by load; 4 / 8), chain_fast_loop (1), occ_overlap (2 = workgroups per CU of an occlusion launch that runs
+ * ray_lanes (0 = by load; 4 / 8), chain_fast_loop (1), chain_rect_planes (1), occ_overlap (2 = workgroups per CU of an occlusion launch that runs
  * beside the previous span's propagation; 0 = one after the other). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);

@@ -106,6 +106,7 @@ struct ChunkParams {
     int tile_row0;          // chain: first tile row (slab-partitioned passes run only the rows of their slab; else 0)
     int roi_by0, roi_by1;   // occlusion: block rows [roi_by0, roi_by1) can be read by those tiles; the rest is never computed
     int dx_lo, dx_hi, dy_lo, dy_hi; // range of (tap index - pixel index) of the previous-slice bilinear fetch, widened to contain 0
+    int rect_planes;        // chain: hulls wider than 56 and at most 48 rows high get 72 x 48 LDS planes (chunk_geometry)
     float b_added;          // Add / two adds: +1 / -1 for stream a
     float b_added2;         // two adds: the same for stream r
     // empty-block hand-off: k_occ_flags marks, once per pass, every occlusion workgroup (16x16 pixels x 8 slices) whose
@@ -241,6 +242,7 @@ enum Tunable : int {
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
     TUNE_CHAIN_FAST_LOOP,    // 0: full, aligned chunks run the generic slice loop too (A/B of the unrolled, branch-free loop)
+    TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)
     TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
     TUNE_COUNT
 };
@@ -251,6 +253,7 @@ hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt);
+size_t occlusion_lds_bytes(const ChunkParams& p); // dynamic LDS of an occlusion workgroup (the bricks it stages)
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s); // + the work lists
 hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);

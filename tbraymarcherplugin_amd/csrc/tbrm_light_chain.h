@@ -15,14 +15,18 @@ struct ChunkGeom {
     int n;                  // steps in this chunk
     int lox, hix, loy, hiy;
     int HX, HY;             // hull = window at r = n (the input state)
-    int RS;                 // LDS plane edge / row stride in floats (0: the hull does not fit any instantiation)
+    int RS;                 // LDS plane row stride in floats (0: the hull does not fit any instantiation)
+    int RR;                 // LDS plane rows: RS, or 48 under a 72-float stride (ChunkParams::rect_planes)
     int padx, pady;         // plane coordinates of tile pixel (0,0)
     int lv_layers;          // 8-slice brick layers of the light volume the chunk touches
     int lv_layer0;          // first of them
 };
 
-// LDS planes are RS x RS floats, RS an odd multiple of 8 (bank-conflict-free 8x8 patches, see k_light_chain)
-__host__ __device__ constexpr int chain_plane_elems(int RS) { return RS * RS + 8; } // + slack for inactive slots' reads
+// LDS planes are RS x RR floats, RS an odd multiple of 8 (bank-conflict-free 8x8 patches, see k_light_chain); RR = RS except
+// for the one rectangular shape: 72 x 48, the hull of a 16-slice chunk whose taps are two texels wide along x and one along
+// y — the usual second pass of a slanted light. Eight square 72 x 72 planes (two windows, three ring slots of occlusion
+// factors and kept L) exceed the LDS, eight of 72 x 48 take 111 KB, so such a pass runs 16-slice chunks instead of 8.
+__host__ __device__ constexpr int chain_plane_elems(int RS, int RR) { return RS * RR + 8; } // + slack for inactive slots' reads
 __host__ __device__ constexpr int chain_row_stride(int hull) { return hull <= 40 ? 40 : (hull <= 56 ? 56 : (hull <= 72 ? 72 : 0)); }
 
 __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
@@ -33,6 +37,8 @@ __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
     g.HX = kChunkTile + g.n * (g.hix - g.lox);
     g.HY = kChunkTile + g.n * (g.hiy - g.loy);
     g.RS = chain_row_stride(g.HX > g.HY ? g.HX : g.HY);
+    g.RR = g.RS;
+    if (p.rect_planes && g.HX > 56 && g.HX <= 72 && g.HY <= 48) { g.RS = 72; g.RR = 48; }
     g.padx = -g.n * g.lox;
     g.pady = -g.n * g.loy;
     const int ja = p.j0, jb = p.j0 + (g.n - 1) * p.dir;

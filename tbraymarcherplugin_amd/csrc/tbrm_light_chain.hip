@@ -34,11 +34,11 @@ __device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int,
 // are staged in one round (RS <= 56), UNORM8 light volume: the slice loop is fully unrolled with every slice-dependent
 // quantity an immediate, no per-lane branches and KEEP (the contribution cache takes L) a compile-time fact — see "fast
 // slice loop" below. M == 0: any chunk.
-template <int LFMT, int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false>
+template <int LFMT, int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false, int RR = RS>
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TX = kChunkTile, TY = kChunkTile, RR = RS;
+    constexpr int TX = kChunkTile, TY = kChunkTile;
     constexpr int NT = kChunkThreads;                                    // one thread per tile pixel
     constexpr int BY = TY / 8;                                           // light-volume bricks under the tile along v (4 along u)
     constexpr bool CACHED = MODE == PASS_CHANGE_CACHED;                  // the removed light's L is read, not propagated
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     constexpr int NR = MODE == PASS_ADD ? 1 : 2;                         // planes staged per slice: occlusion factors, or (CACHED) factors + L
     constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KS = 1 + KH; // + the owned pixel
-    constexpr int PLANE = chain_plane_elems(RS);
+    constexpr int PLANE = chain_plane_elems(RS, RR);
     constexpr int GPR = RS / 4;                                         // 16-byte copy groups per plane row
     constexpr int GROUPS = RR * GPR;
     constexpr int ROUNDS = (GROUPS + NT - 1) / NT;                       // copy groups per thread
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         // word (one v_cndmask instead of an exec-mask region); every wave issues the same number of vector-memory
         // operations per slice, so the copy counter's operand is an immediate too.
         static_assert(ROUNDS == 1 && LV_LDS && (M == 8 || M == 16), "fast slice loop: one staging round, UNORM8 light volume");
-        constexpr int DUMMY = RS * RS; // the plane's slack word: nobody reads it
+        constexpr int DUMMY = RS * RR; // the plane's slack word: nobody reads it
         // staging: every lane with a group inside the plane copies (rows beyond the hull / the buffer copy a clamped row:
         // the pixels they feed are never valid); per stream the source offset of slice 0 and its advance per slice
         const bool st_in = (int) threadIdx.x < GROUPS;
@@ -530,14 +530,14 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
 }
 
 
-template <int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false>
+template <int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false, int RR = RS>
 static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 {
     constexpr int LFMT = TBRM_CHAIN_LFMT;
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP>, attr_done, 160 * 1024); e != hipSuccess) return e;
+    if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP, RR>, attr_done, 160 * 1024); e != hipSuccess) return e;
     const size_t lds = chunk_lds_bytes(p, MODE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
+    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP, RR>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
 
@@ -558,6 +558,13 @@ static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, 
         return true;
     };
     using std::integral_constant;
+    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED) { // the rectangular planes (ChunkParams::rect_planes)
+        if (g.n == 16 && g.RS == 72 && g.RR == 48 && kh <= 2) {
+            err = keep ? launch_chain4<MODE, AXIS, 2, 72, 16, true, 48>(p, s) : launch_chain4<MODE, AXIS, 2, 72, 16, false, 48>(p, s);
+            return true;
+        }
+    }
+    if (g.RR != g.RS) return false;
     if (g.n == 16 && g.RS == 56 && kh == 2) return go(integral_constant<int, 2>{}, integral_constant<int, 56>{}, integral_constant<int, 16>{});
     if (g.n == 8 && g.RS == 40 && kh <= 1) return go(integral_constant<int, 1>{}, integral_constant<int, 40>{}, integral_constant<int, 8>{});
     if (g.n == 8 && g.RS == 56 && kh <= 1) return go(integral_constant<int, 1>{}, integral_constant<int, 56>{}, integral_constant<int, 8>{});
@@ -576,6 +583,11 @@ static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
     const int kh = (halo + kChunkThreads - 1) / kChunkThreads; // <= 3 for hulls up to 64 x 64
     hipError_t err = hipSuccess;
     if (launch_chain_fast<MODE, AXIS>(p, g, kh, s, err)) return err;
+#if TBRM_CHAIN_LFMT == 0
+    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED)
+        if (g.RS == 72 && g.RR == 48) return launch_chain4<MODE, AXIS, 2, 72, 0, false, 48>(p, s); // (a full chunk off the brick grid)
+#endif
+    if (g.RR != g.RS) return hipErrorInvalidConfiguration;
     if constexpr (MODE == PASS_CHANGE_CACHED) { // one stream propagated, two planes staged: the Add's kernels up to RS 56
         if (g.RS == 40) return launch_chain4<MODE, AXIS, 1, 40>(p, s);
         if (g.RS == 56) return launch_chain4<MODE, AXIS, 3, 56>(p, s);

@@ -63,6 +63,12 @@ void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt)
 thread_local const char* g_plan_note = "";
 int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; }
 
+// 72 x 48 LDS planes (tbrm_light_chain.h): the kernels that have them
+static int rect_planes_for(const tbrm_resources* r, int mode)
+{
+    return (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) && r->lv_fmt == FMT_U8 && tune(TUNE_CHAIN_RECT_PLANES) != 0 ? 1 : 0;
+}
+
 // Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
 // 16/8/4/2 slices whose window (tile + steps * growth) and staged occlusion fit in LDS. false: the chunk kernels decline.
 bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, ChunkFit& fit, int mode)
@@ -85,6 +91,7 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
     ty.lo = std::min(ty.lo, 0); ty.hi = std::max(ty.hi, 0);
     ChunkParams p{};
     p.dx_lo = tx.lo; p.dx_hi = tx.hi; p.dy_lo = ty.lo; p.dy_hi = ty.hi;
+    p.rect_planes = rect_planes_for(r, mode);
     p.dir = pa.dir;
     p.j0 = pa.start;
     const int g = std::max(tx.hi - tx.lo, ty.hi - ty.lo);
@@ -455,6 +462,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     p.W = W; p.H = H;
     p.dir = pa.dir;
     p.dx_lo = fit.tx.lo; p.dx_hi = fit.tx.hi; p.dy_lo = fit.ty.lo; p.dy_hi = fit.ty.hi;
+    p.rect_planes = rect_planes_for(r, mode);
     p.b_added = b_added;
     p.b_added2 = b_added2;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
@@ -568,7 +576,7 @@ float* plan_plane(const tbrm_resources* r, int boundary, int si) { return r->d_p
 // enqueued on the handle's stream so far (the data volume, the transfer function's tables, the chains that read the
 // buffer's previous contents), with a grid small enough to be resident beside the chain's workgroups; the chain waits for
 // occ_ev_ready[b] (enqueue_plan_chunk).
-static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, int b, bool beside)
+static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, int b, bool beside, int beside_wgs_per_cu = 0)
 {
     hipStream_t s = r->stream;
     if (beside) {
@@ -606,7 +614,7 @@ static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, in
     p.occ_list = q.sparse && plan.work_list ? fs->list + (size_t) sp * plan.flags_per_span : nullptr;
     p.occ_count = q.sparse && plan.work_list ? counts + sp : nullptr;
     if (q.sparse && !plan.work_list) p.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
-    p.occ_grid_cap = beside ? tune(TUNE_OCC_OVERLAP) * r->n_cus : 0;
+    p.occ_grid_cap = beside ? beside_wgs_per_cu * r->n_cus : 0;
     HIP_TRY(launch_light_occlusion(p, occ_mode, s));
     if (beside) HIP_TRY(hipEventRecord(r->occ_ev_ready[b], s));
     r->occ_slot[b].plan_serial = plan.serial;
@@ -690,8 +698,20 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const Pas
         // workgroups are what fills a CU's spare slots (1024^3: 16.2 ms per Change one after the other, 17.1 beside)
         if (tune(TUNE_OCC_OVERLAP) > 0 && ns == 1 && p.tiles_x * p.tiles_y <= r->n_cus) {
             const PassPlan* np = sp + 1 < plan.n_spans ? &plan : (next && plan_has_occlusion(*next) ? next : nullptr);
-            if (np)
-                if (int e = enqueue_occlusion(r, *np, np == &plan ? sp + 1 : 0, ob ^ 1, true)) return e;
+            if (np) {
+                // only when the requested occlusion workgroups per CU all fit beside this plan's chain workgroup: every one of
+                // them has to be resident from the start (one that waits takes the slot the next chain launch needs), and
+                // fewer than two per CU do not finish a span's occlusion in the time of its chain (the 72 x 48 planes of a
+                // cached Change leave room for one: 2.07 ms beside, 1.90 one after the other)
+                ChunkParams full = plan.p;
+                full.n_steps = M;
+                full.j0 = plan.start;
+                const size_t chain_lds = chunk_lds_bytes(full, plan.mode, r->lv_fmt), occ_lds = occlusion_lds_bytes(np->p) + 2560;
+                const int room = chain_lds < 160 * 1024 ? (int) ((160 * 1024 - chain_lds) / occ_lds) : 0;
+                const int wgs = room >= tune(TUNE_OCC_OVERLAP) ? tune(TUNE_OCC_OVERLAP) : 0;
+                if (wgs > 0)
+                    if (int e = enqueue_occlusion(r, *np, np == &plan ? sp + 1 : 0, ob ^ 1, true, wgs)) return e;
+            }
         }
     }
     if (ob < 0) return fail(TBRM_ERR_INVALID_ARG, "chunk %d enqueued before the first chunk of its span", c);

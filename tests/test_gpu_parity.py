@@ -613,8 +613,9 @@ def test_occlusion_beside_the_chain_changes_nothing(gpu, tunables):
     vol = small_volume(dims, np.uint16, seed=0x5EED0503)
     world = S.default_world()
     results = []
-    for overlap in (0, 2, 1):
+    for overlap, rect in ((0, 1), (2, 1), (1, 1), (2, 0), (0, 0)):  # and with / without the 72 x 48 LDS planes (16- instead of 8-slice chunks)
         tunables("occ_overlap", overlap)
+        tunables("chain_rect_planes", rect)
         with abi.Resources(dims, abi.FMT_G16, False) as res:
             res.upload_volume(vol)
             res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
@@ -632,7 +633,8 @@ def test_occlusion_beside_the_chain_changes_nothing(gpu, tunables):
             results.append(res.download_light_volume())
             assert res.launch_counters()["slice"] == 0
     assert results[0].max() > 60
-    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+    for other in results[1:]:
+        assert np.array_equal(results[0], other)
 
 
 # ---- randomized sweep of the light operators --------------------------------------------------------------------------
