@@ -16,16 +16,17 @@ struct ChunkGeom {
     int lox, hix, loy, hiy;
     int HX, HY;             // hull = window at r = n (the input state)
     int RS;                 // LDS plane row stride in floats (0: the hull does not fit any instantiation)
-    int RR;                 // LDS plane rows: RS, or 48 under a 72-float stride (ChunkParams::rect_planes)
+    int RR;                 // LDS plane rows: RS, or (ChunkParams::rect_planes) 48 under a 72-float stride / 64 under a 56-float one
     int padx, pady;         // plane coordinates of tile pixel (0,0)
     int lv_layers;          // 8-slice brick layers of the light volume the chunk touches
     int lv_layer0;          // first of them
 };
 
 // LDS planes are RS x RR floats, RS an odd multiple of 8 (bank-conflict-free 8x8 patches, see k_light_chain); RR = RS except
-// for the one rectangular shape: 72 x 48, the hull of a 16-slice chunk whose taps are two texels wide along x and one along
-// y — the usual second pass of a slanted light. Eight square 72 x 72 planes (two windows, three ring slots of occlusion
-// factors and kept L) exceed the LDS, eight of 72 x 48 take 111 KB, so such a pass runs 16-slice chunks instead of 8.
+// for the two rectangular shapes: 72 x 48 and 56 x 64, the hulls of a 16-slice chunk whose taps are two texels wide along x
+// (y) and one along the other axis — the usual second pass of a slanted light — and of an 8-slice chunk with taps four
+// texels wide. Eight square 72 x 72 planes (two windows, three ring slots of occlusion factors and kept L) exceed the
+// LDS, eight of 72 x 48 take 111 KB, so such a pass runs chunks twice as long.
 __host__ __device__ constexpr int chain_plane_elems(int RS, int RR) { return RS * RR + 8; } // + slack for inactive slots' reads
 __host__ __device__ constexpr int chain_row_stride(int hull) { return hull <= 40 ? 40 : (hull <= 56 ? 56 : (hull <= 72 ? 72 : 0)); }
 
@@ -39,6 +40,7 @@ __host__ __device__ inline ChunkGeom chunk_geometry(const ChunkParams& p)
     g.RS = chain_row_stride(g.HX > g.HY ? g.HX : g.HY);
     g.RR = g.RS;
     if (p.rect_planes && g.HX > 56 && g.HX <= 72 && g.HY <= 48) { g.RS = 72; g.RR = 48; }
+    else if (p.rect_planes && g.HX <= 56 && g.HY > 56 && g.HY <= 64) { g.RS = 56; g.RR = 64; }
     g.padx = -g.n * g.lox;
     g.pady = -g.n * g.loy;
     const int ja = p.j0, jb = p.j0 + (g.n - 1) * p.dir;

@@ -558,10 +558,14 @@ static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, 
         return true;
     };
     using std::integral_constant;
-    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED) { // the rectangular planes (ChunkParams::rect_planes)
-        if (g.n == 16 && g.RS == 72 && g.RR == 48 && kh <= 2) {
-            err = keep ? launch_chain4<MODE, AXIS, 2, 72, 16, true, 48>(p, s) : launch_chain4<MODE, AXIS, 2, 72, 16, false, 48>(p, s);
-            return true;
+    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED) { // the rectangular planes (ChunkParams::rect_planes); L kept
+        if (keep && kh <= 2 && g.RS == 72 && g.RR == 48) {
+            if (g.n == 16) { err = launch_chain4<MODE, AXIS, 2, 72, 16, true, 48>(p, s); return true; }
+            if (g.n == 8) { err = launch_chain4<MODE, AXIS, 2, 72, 8, true, 48>(p, s); return true; }
+        }
+        if (keep && kh <= 2 && g.RS == 56 && g.RR == 64) {
+            if (g.n == 16) { err = launch_chain4<MODE, AXIS, 2, 56, 16, true, 64>(p, s); return true; }
+            if (g.n == 8) { err = launch_chain4<MODE, AXIS, 2, 56, 8, true, 64>(p, s); return true; }
         }
     }
     if (g.RR != g.RS) return false;
@@ -584,8 +588,10 @@ static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
     hipError_t err = hipSuccess;
     if (launch_chain_fast<MODE, AXIS>(p, g, kh, s, err)) return err;
 #if TBRM_CHAIN_LFMT == 0
-    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED)
-        if (g.RS == 72 && g.RR == 48) return launch_chain4<MODE, AXIS, 2, 72, 0, false, 48>(p, s); // (a full chunk off the brick grid)
+    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED) { // (a full chunk off the brick grid, or L not kept)
+        if (g.RS == 72 && g.RR == 48 && kh <= 2) return launch_chain4<MODE, AXIS, 2, 72, 0, false, 48>(p, s);
+        if (g.RS == 56 && g.RR == 64 && kh <= 2) return launch_chain4<MODE, AXIS, 2, 56, 0, false, 64>(p, s);
+    }
 #endif
     if (g.RR != g.RS) return hipErrorInvalidConfiguration;
     if constexpr (MODE == PASS_CHANGE_CACHED) { // one stream propagated, two planes staged: the Add's kernels up to RS 56

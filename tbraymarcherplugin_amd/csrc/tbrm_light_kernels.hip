@@ -234,8 +234,9 @@ size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt)
     const ChunkGeom g = chunk_geometry(p);
     const int ns = (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2; // streams propagated
     const int nr = mode == PASS_ADD ? 1 : 2;                                  // planes staged per slice
-    const bool rect = g.RR != g.RS; // 72 x 48: instantiated for an Add and a cached Change over a UNORM8 light volume
+    const bool rect = g.RR != g.RS; // 72 x 48 / 56 x 64: instantiated for an Add and a cached Change over a UNORM8 light volume
     if (rect && !((mode == PASS_ADD || mode == PASS_CHANGE_CACHED) && lv_fmt == FMT_U8)) return (size_t) 1 << 30;
+    if (rect && g.HX * g.HY - kChunkTile * kChunkTile > 2 * kChunkThreads) return (size_t) 1 << 30; // (two halo slots per thread)
     if (g.RS == 0 || (mode != PASS_ADD && !rect && g.RS > 56)) return (size_t) 1 << 30;
     size_t total = (size_t) (2 * ns + kOccRing * nr) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged ring
     if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;                // light-volume tile
