@@ -43,7 +43,9 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     constexpr int BY = TY / 8;                                           // light-volume bricks under the tile along v (4 along u)
     constexpr bool CACHED = MODE == PASS_CHANGE_CACHED;                  // the removed light's L is read, not propagated
     constexpr int NS = (MODE == PASS_ADD || CACHED) ? 1 : 2;             // streams propagated (windows)
-    constexpr int NR = MODE == PASS_ADD ? 1 : 2;                         // planes staged per slice: occlusion factors, or (CACHED) factors + L
+    constexpr int NR = MODE == PASS_ADD ? 1 : 2;                         // copies a wave issues per staged slice and round: occlusion factors per stream, or (CACHED) factors + L
+    constexpr int NRP = CACHED ? 1 : NR;                                 // of them hull-sized planes (the removed light's kept L is staged for the tile alone)
+    constexpr int LRP = kChunkTile * kChunkTile;                         // floats of a kept-L ring slot
     constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KS = 1 + KH; // + the owned pixel
     constexpr int PLANE = chain_plane_elems(RS, RR);
@@ -63,18 +65,22 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int tile_y = tile_id / p.tiles_x, tile_x = tile_id - tile_y * p.tiles_x;
     const int base_x = tile_x * TX, base_y = (p.tile_row0 + tile_y) * TY;
 
-    // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, staged plane si of ring slot q at (2*NS + q*NR + si)*PLANE;
-    // then the light-volume tile (bytes)
+    // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, staged plane si of ring slot q at (2*NS + q*NRP + si)*PLANE;
+    // CACHED: three 32 x 32 slots for the removed light's kept L — only the owned pixels read it — and 1 KB that the waves
+    // without a share of the tile copy into (every wave issues the same number of copies per slice: the slice loops' vmcnt
+    // bookkeeping); then the light-volume tile (bytes)
     float* const lds = (float*) smem;
-    uint8_t* const lv_tile = (uint8_t*) (lds + (2 * NS + kOccRing * NR) * PLANE);
+    float* const lr_base = lds + (2 * NS + kOccRing * NRP) * PLANE;
+    uint8_t* const lv_tile = (uint8_t*) (lr_base + (CACHED ? kOccRing * LRP + 256 : 0));
     auto window = [&](int w, int si) -> float* { return lds + (w * NS + si) * PLANE; };
-    auto ring = [&](int q, int si) -> float* { return lds + (2 * NS + q * NR + si) * PLANE; };
+    auto ring = [&](int q, int si) -> float* { return lds + (2 * NS + q * NRP + si) * PLANE; };
+    auto lr_ring = [&](int q) -> float* { return lr_base + q * LRP; };
 
     // ---- 16-byte staging pattern: copy group i = floats [4i, 4i+4) of an LDS plane = 4 pixels of one hull row ------
     int st_src[ROUNDS];   // pixel index of the group's first pixel inside a plane (may run off the row ends: guard bands)
     bool st_ok[ROUNDS];
     int st_dst[ROUNDS];   // this wave's 64 x 4 floats
-    bool st_one[NR][ROUNDS][2] = {}; // the group's 4 pixels lie in blocks of slice group 0 / 1 of the chunk that are empty for the stream
+    bool st_one[NRP][ROUNDS][2] = {}; // the group's 4 pixels lie in blocks of slice group 0 / 1 of the chunk that are empty for the stream
     int ndma = 0;         // copies this WAVE issues per staged slice (wave-uniform)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -84,18 +90,18 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         st_src[rd] = py * p.W + base_x - g.padx + col;
         st_ok[rd] = gi < GROUPS && row < g.HY && col < g.HX && (unsigned) py < (unsigned) p.H;
         st_dst[rd] = (wave * 64 + rd * NT) * 4;
-        if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NR;
+        if (__builtin_amdgcn_ballot_w64(st_ok[rd]) != 0) ndma += NRP;
         // empty occlusion blocks (16x16 pixels x 8 slices) are handed over as one flag: their factor 1 - 0 is staged from
         // a page of ones
         if (st_ok[rd]) {
             const int x_first = base_x - g.padx + col, x_last = x_first + 3;
             const int bx0 = max(x_first, 0) >> 4, bx1 = min(x_last, p.W - 1) >> 4, by = py >> 4;
 #pragma unroll
-            for (int si = 0; si < NR; ++si) {
+            for (int si = 0; si < NRP; ++si) {
                 const uint8_t* flags = si == 0 ? p.a.occ_flags : p.r.occ_flags;
                 if (!flags) continue;
-                if constexpr (NR == 2)
-                    if (si == 1 && flags == p.a.occ_flags) { st_one[NR - 1][rd][0] = st_one[0][rd][0]; st_one[NR - 1][rd][1] = st_one[0][rd][1]; continue; } // computed jointly
+                if constexpr (NRP == 2)
+                    if (si == 1 && flags == p.a.occ_flags) { st_one[NRP - 1][rd][0] = st_one[0][rd][0]; st_one[NRP - 1][rd][1] = st_one[0][rd][1]; continue; } // computed jointly
 #pragma unroll
                 for (int z = 0; z < 2; ++z) {
                     bool one = x_last >= 0 && x_first < p.W && z * kOccSlices < p.occ_phase + g.n;
@@ -106,14 +112,18 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                     st_one[si][rd][z] = one;
                 }
             }
-            // the removed light's kept L is read at the owned pixels only: groups outside the tile take the "flagged" route
-            // (the first KB of the allocation, whatever it holds) instead of fetching 2 of 3 plane pixels for nothing
-            if constexpr (CACHED) {
-                const bool in_tile = row >= g.pady && row < g.pady + TY && col + 4 > g.padx && col < g.padx + TX; // (overlaps it)
-                st_one[1][rd][0] = st_one[1][rd][1] = !in_tile;
-            }
         }
     }
+    // CACHED, the removed light's kept L: threads 0..255 copy the tile's 32 rows of 8 groups (rows beyond the buffer copy its
+    // last row: their pixels are never valid), the other waves the first KB of the allocation into the spare KB
+    if constexpr (CACHED) ndma += 1;
+    const bool lr_in = (int) threadIdx.x < LRP / 4;
+    const uint32_t lr_src = lr_in ? (uint32_t) (min(base_y + ((int) threadIdx.x >> 3), p.H - 1) * p.W + base_x + ((int) threadIdx.x & 7) * 4) : 0u;
+    const int lr_dst = wave < LRP / 256 ? wave * 256 : kOccRing * LRP; // (relative to lr_base: ring slot 0 / the spare KB)
+    auto stage_lr = [&](int sf, int q) { // slice sf of the chunk into slot q
+        const uint32_t off = lr_in ? p.r.occ_off + (uint32_t) (sf * plane_elems) + lr_src : (uint32_t) lane * 4u;
+        dma_16(p.r.occ_base + off, lr_base + lr_dst + (lr_in ? q * LRP : 0));
+    };
     // A stream's occlusion planes and a page of ones live in one allocation: a copy's source is the stream's uniform base
     // plus a 32-bit offset, and flagged-empty lanes only swap the offset (the same number of copy instructions per wave and
     // slice either way, which the vmcnt bookkeeping of the slice loop relies on).
@@ -125,13 +135,14 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if (!st_ok[rd]) continue;
             const uint32_t px = (uint32_t) (sf * plane_elems + st_src[rd]);
 #pragma unroll
-            for (int si = 0; si < NR; ++si) {
+            for (int si = 0; si < NRP; ++si) {
                 const ChunkStream& s = si == 0 ? p.a : p.r;
                 const bool one = group == 0 ? st_one[si][rd][0] : st_one[si][rd][1];
                 const uint32_t off = one ? (uint32_t) lane * 4u : s.occ_off + px;
                 dma_16(s.occ_base + off, ring(q, si) + st_dst[rd]);
             }
         }
+        if constexpr (CACHED) stage_lr(sf, q);
     };
 
     // ---- input state: the plane after the previous chunk ------------------------------------------------------------
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if (k == 0) {
                 if constexpr (LV_LDS) lv_old = decode_u8(lv_tile[vi]);
                 else lv_old = load_voxel<LFMT>(p.light, vi);
-                if constexpr (CACHED) l_removed = ring(q, 1)[li[0]]; // the removed light's L of this voxel, as its own pass left it
+                if constexpr (CACHED) l_removed = lr_ring(q)[sqy[0] * TX + sqx[0]]; // the removed light's L of this voxel, as its own pass left it
             }
         }
 #pragma unroll
@@ -366,13 +377,13 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         // staging: every lane with a group inside the plane copies (rows beyond the hull / the buffer copy a clamped row:
         // the pixels they feed are never valid); per stream the source offset of slice 0 and its advance per slice
         const bool st_in = (int) threadIdx.x < GROUPS;
-        uint32_t st_off[NR], st_adv[NR][2];
+        uint32_t st_off[NRP], st_adv[NRP][2];
         {
             const int gi = (int) threadIdx.x, row = gi / GPR, col = (gi - row * GPR) * 4;
             const int py = min(max(base_y - g.pady + row, 0), p.H - 1);
             const uint32_t src = (uint32_t) (py * p.W + base_x - g.padx + col);
 #pragma unroll
-            for (int si = 0; si < NR; ++si) {
+            for (int si = 0; si < NRP; ++si) {
                 const ChunkStream& st = si == 0 ? p.a : p.r;
 #pragma unroll
                 for (int z = 0; z < 2; ++z) st_adv[si][z] = (st_ok[0] && st_one[si][0][z]) ? 0u : (uint32_t) plane_elems;
@@ -384,13 +395,14 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if constexpr (SF < M) {
                 if (st_in) {
 #pragma unroll
-                    for (int si = 0; si < NR; ++si) {
+                    for (int si = 0; si < NRP; ++si) {
                         const ChunkStream& st = si == 0 ? p.a : p.r;
                         const bool one = st_adv[si][SF / kOccSlices] == 0u;
                         const uint32_t off = one ? (uint32_t) lane * 4u : st_off[si] + (uint32_t) SF * (uint32_t) plane_elems;
                         dma_16(st.occ_base + off, ring(Q, si) + st_dst[0]);
                     }
                 }
+                if constexpr (CACHED) stage_lr(SF, Q);
             }
         };
         // slot 0 never branches: a pixel outside the buffer is computed like any other and lands in the slack word
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             }
             const uint32_t code_old = lv_tile[vi];
             float l_removed = 0.0f;
-            if constexpr (CACHED) l_removed = ring(Q, 1)[li[0]];
+            if constexpr (CACHED) l_removed = lr_ring(Q)[sqy[0] * TX + sqx[0]];
             // halo pixels: a wave none of whose lanes has a pixel inside the window skips the slot
             bool act[KS];
             float h00[KS][NS], h01[KS][NS], h10[KS][NS], h11[KS][NS], hfac[KS][NS];

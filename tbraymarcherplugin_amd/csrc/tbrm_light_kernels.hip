@@ -238,7 +238,9 @@ size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt)
     if (rect && !((mode == PASS_ADD || mode == PASS_CHANGE_CACHED) && lv_fmt == FMT_U8)) return (size_t) 1 << 30;
     if (rect && g.HX * g.HY - kChunkTile * kChunkTile > 2 * kChunkThreads) return (size_t) 1 << 30; // (two halo slots per thread)
     if (g.RS == 0 || (mode != PASS_ADD && !rect && g.RS > 56)) return (size_t) 1 << 30;
-    size_t total = (size_t) (2 * ns + kOccRing * nr) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged ring
+    const int nrp = mode == PASS_CHANGE_CACHED ? 1 : nr;                                         // of them hull-sized
+    size_t total = (size_t) (2 * ns + kOccRing * nrp) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged ring
+    if (mode == PASS_CHANGE_CACHED) total += (size_t) (kOccRing * kChunkTile * kChunkTile + 256) * 4; // the removed light's kept L, tile only
     if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;                // light-volume tile
     return total;
 }
