@@ -555,7 +555,8 @@ static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 
 // The fast slice loop (k_light_chain, M > 0) is instantiated for the shapes the planner produces for full chunks of light
 // passes with taps one or two texels wide: 16 slices in 56 x 56 planes with 2 halo pixels per thread, 8 slices in 40 x 40
-// planes (1) or 56 x 56 planes (1, 2) — for a UNORM8 light volume. false: not one of them (the generic loop runs).
+// planes (1) or 56 x 56 planes (1, 2); an Add or a cached Change that keeps L also 16 and 8 slices in the rectangular
+// 72 x 48 and 56 x 64 planes (2) — for a UNORM8 light volume. false: not one of them (the generic loop runs).
 template <int MODE, int AXIS>
 static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, hipStream_t s, hipError_t& err)
 {
@@ -590,7 +591,7 @@ static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, 
 }
 
 // The instantiated shapes of the generic loop (chunk_lds_bytes tells the planner which hulls have one): two streams RS 40
-// (1 halo slot per thread) / 56 (1, 2, 3); one stream RS 40 (1) / 56 (3) / 72 (3)
+// (1 halo slot per thread) / 56 (1, 2, 3); one stream RS 40 (1) / 56 (3) / 72 (3, a plain Add) / 72 x 48 and 56 x 64 (2, UNORM8)
 template <int MODE, int AXIS>
 static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
 {

@@ -227,8 +227,8 @@ hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s)
 // a chunk of slices per launch pair
 
 // LDS bytes of a chain workgroup; 1 GiB when no instantiated kernel shape holds the chunk's hull
-// (tbrm_light_chain.hip launch_chain3 lists the shapes: everything but a plain Add runs RS 40/56 — ten or eight 72 x 72
-// planes exceed the LDS — an Add RS 40/56/72)
+// (tbrm_light_chain.hip launch_chain3 lists the shapes: square planes of RS 40 / 56 for everything, 72 for a plain Add —
+// ten 72 x 72 planes exceed the LDS — and the rectangular 72 x 48 / 56 x 64 for an Add and a cached Change, UNORM8)
 size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
