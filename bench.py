@@ -54,6 +54,9 @@ def relaunch_under_torchrun(n_gpus):
     import socket
     import subprocess
 
+    from tbraymarcherplugin_amd import build as tb
+
+    tb.build()  # once, here: the N ranks must not all find a stale library and rebuild it side by side
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]

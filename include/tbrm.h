@@ -161,6 +161,11 @@ typedef struct tbrm_resources tbrm_resources; /* opaque: FBasicRaymarchRendering
 
 /* ------------------------------------------------------------------------------------------------ */
 /* library                                                                                           */
+/* Bumped whenever an entry point changes its signature or meaning (3: round 3 — tbrm_change_dir_light has carried its
+ * trailing gpu_sync argument since 2; 3 adds tbrm_abi_version itself and the error report of tbrm_flush). A host built
+ * against another number must not call into the library. */
+#define TBRM_ABI_VERSION 3
+TBRM_API int tbrm_abi_version(void);
 TBRM_API const char* tbrm_version(void);
 TBRM_API const char* tbrm_last_error(void);       /* thread-local message of the last failing call */
 TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the HIP runtime has none */

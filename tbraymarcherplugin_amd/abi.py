@@ -114,7 +114,7 @@ class SlabPass(C.Structure):  # tbrm_slab_pass
 
 # every symbol include/tbrm.h declares (tests/test_abi.py checks the header against this list and the .so)
 SYMBOLS = [
-    "tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable",
+    "tbrm_abi_version", "tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable",
     "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",

@@ -15,6 +15,7 @@ UNITS = [
     ("tbrm_api.cpp", "tbrm_api", []), ("tbrm_light_passes.cpp", "tbrm_light_passes", []), ("tbrm_host_math.cpp", "tbrm_host_math", []),
     ("tbrm_kernels.hip", "tbrm_kernels", []), ("tbrm_light_kernels.hip", "tbrm_light_kernels", []),
     ("tbrm_light_chain.hip", "tbrm_light_chain_u8", ["-DTBRM_CHAIN_LFMT=0"]), ("tbrm_light_chain.hip", "tbrm_light_chain_f32", ["-DTBRM_CHAIN_LFMT=2"]),
+    ("tbrm_light_sweep.hip", "tbrm_light_sweep", []),
 ]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h",
@@ -43,13 +44,30 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
-    """One hipcc -c per source, in parallel (the kernel files take most of a minute each), then one link."""
+    """One hipcc -c per source, in parallel (the kernel files take most of a minute each), then one link.
+
+    Safe against concurrent callers (N ranks of a torchrun launch that all find a stale library): one builder at a time
+    holds a lock file, the others wait and then find the library fresh; objects go to a per-process directory and the
+    library is linked under a temporary name and moved into place, so a reader never maps a half-written file."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
     from concurrent.futures import ThreadPoolExecutor
 
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    lock = open(os.path.join(LIB_DIR, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not needs_build():  # another process built it while this one waited
+            return LIB_PATH
+        return _build_locked(verbose, ThreadPoolExecutor)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose, ThreadPoolExecutor):
+    obj_dir = os.path.join(LIB_DIR, "obj", str(os.getpid()))
     os.makedirs(obj_dir, exist_ok=True)
     compile_flags = [f for f in FLAGS if f != "-shared"]
 
@@ -64,10 +82,13 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
         objs = list(pool.map(compile_one, UNITS))
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", LIB_PATH]
+    tmp_lib = LIB_PATH + f".{os.getpid()}.tmp"
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", tmp_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    os.replace(tmp_lib, LIB_PATH)
+    shutil.rmtree(obj_dir, ignore_errors=True)
     return LIB_PATH
 
 

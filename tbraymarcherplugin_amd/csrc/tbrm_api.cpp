@@ -34,7 +34,7 @@ struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
-    {"chain_rect_planes", 1}, {"occ_overlap", 2},
+    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -271,7 +271,8 @@ int ensure_skipping(tbrm_resources* r)
 
 extern "C" {
 
-const char* tbrm_version(void) { return "tbrm-mi355x 0.1.0 (gfx950)"; }
+const char* tbrm_version(void) { return "tbrm-mi355x 0.3.0 (gfx950)"; }
+int tbrm_abi_version(void) { return TBRM_ABI_VERSION; }
 const char* tbrm_last_error(void) { return g_error; }
 
 int tbrm_device_count(int* out_count)
@@ -415,6 +416,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     if (!r) return TBRM_OK;
     (void) hipSetDevice(r->desc.device);
     if (r->stream) (void) hipStreamSynchronize(r->stream);
+    if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream); // (an occlusion beside a chain reads the volume and the skipping metadata)
     (void) hipFree(r->res_data.alloc);
     (void) hipFree(r->d_tf);
     (void) hipFree(r->res_light.alloc);
@@ -423,6 +425,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (float* pl : r->d_plane) (void) hipFree(pl);
     delete r->slab_op;
     release_occ_stores(r);
+    release_sweep(r);
     (void) hipFree(r->d_minmax);
     (void) hipFree(r->d_empty);
     if (r->occ_stream) {
@@ -458,6 +461,7 @@ int tbrm_upload_volume(tbrm_resources* r, const void* host_voxels, size_t n_byte
     if (!r || !host_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
     if (int e = bind(r)) return e;
+    quiesce_occ_stream(r); // (nothing on the second stream may still be reading the volume)
     void* staging = nullptr; // linear copy in HBM, re-laid out into bricks by the GPU
     HIP_TRY(hipMalloc(&staging, n_bytes));
     const int dims[3] = {r->desc.dim_x, r->desc.dim_y, r->desc.dim_z};
@@ -479,6 +483,7 @@ int tbrm_upload_volume_device(tbrm_resources* r, const void* device_voxels, size
     if (!r || !device_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (n_bytes != r->data_bytes) return fail(TBRM_ERR_INVALID_ARG, "volume is %zu bytes, expected %zu", n_bytes, r->data_bytes);
     if (int e = bind(r)) return e;
+    quiesce_occ_stream(r);
     const int dims[3] = {r->desc.dim_x, r->desc.dim_y, r->desc.dim_z};
     HIP_TRY(launch_relayout(relayout_params(device_voxels, r->d_data, dims, r->dbn, format_bytes(r->desc.data_format), true), r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -715,6 +720,7 @@ int tbrm_upload_volume_slices(tbrm_resources* r, int32_t z_begin, int32_t z_coun
         return fail(TBRM_ERR_INVALID_ARG, "slices [%d, %d): whole brick layers (multiples of 8) of a volume %d deep", z_begin, z_begin + z_count, nz);
     if (n_bytes != slice * (size_t) z_count) return fail(TBRM_ERR_INVALID_ARG, "%d slices are %zu bytes, got %zu", z_count, slice * (size_t) z_count, n_bytes);
     if (int e = bind(r)) return e;
+    quiesce_occ_stream(r);
     void* staging = nullptr;
     HIP_TRY(hipMalloc(&staging, n_bytes));
     hipError_t e1 = hipMemcpyAsync(staging, host_voxels, n_bytes, hipMemcpyHostToDevice, r->stream);
@@ -1115,7 +1121,7 @@ int tbrm_flush(tbrm_resources* r)
     if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (int e = bind(r)) return e;
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return TBRM_OK;
+    return sweep_check(r);
 }
 
 int tbrm_stream(tbrm_resources* r, void** out_hip_stream)

@@ -129,6 +129,23 @@ struct ChunkParams {
     ChunkStream a, r;
 };
 
+// k_light_sweep (tbrm_light_sweep.hip): one launch advances every 32x32 tile of the slice plane through a whole span of
+// slices. The previous-slice taps of a pass lie on ONE side of the pixel per plane axis (the constant PrevPixelOffset,
+// AddDirLightShader.usf:81-82), so a tile depends on at most three neighbours — the ones towards the light — and the tiles
+// form a pipeline: tile t runs a few slices behind its upstream neighbours and reads the hx columns / hy rows it needs of
+// their slice from a hand-off record in global memory (dwords {24-bit launch tag, UNORM8 code}, written and polled with
+// relaxed agent-scope atomics: no fences, no kernel boundary, no recomputed halo).
+struct SweepParams {
+    int sx, sy;             // side of the previous-slice taps along the plane's x / y: +1, -1, 0 (none: the tap is the pixel itself)
+    int hx, hy;             // how many columns / rows beyond the tile they reach (both streams)
+    uint32_t* rec[2];       // per stream: the hand-off records, [slice of the launch][tile][32*hx + 32*hy words]
+    uint32_t epoch;         // this launch's tag, 1 .. 2^24 - 1 (records are not cleared between launches)
+    int prefetch;           // slices ahead of their use that the neighbours' records are requested
+    int* ticket;            // [0]: next tile to start (tiles are dealt in upstream-first order: a tile only ever waits for tiles
+                            // that started before it), [1]: tiles finished (the last one re-arms both)
+    int* error;             // set when a tile gave up waiting (bit 0) or found its taps outside the halo (bit 1)
+};
+
 struct RayParams {
     VolumeDev data;
     int data_addr_mode; // ADDR_WRAP / ADDR_CLAMP
@@ -244,6 +261,9 @@ enum Tunable : int {
     TUNE_CHAIN_FAST_LOOP,    // 0: full, aligned chunks run the generic slice loop too (A/B of the unrolled, branch-free loop)
     TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)
     TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
+    TUNE_LIGHT_SWEEP,        // 0: axis passes never take the pipelined sweep kernel (k_light_sweep); 1: where it applies
+    TUNE_SWEEP_ROWS,         // rows of the tile per lane of a sweep workgroup: 1 (16 waves), 2 (8 waves), 4 (4 waves); 0: default
+    TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
     TUNE_COUNT
 };
 int tune(Tunable t);
@@ -258,6 +278,8 @@ constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plan
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s); // + the work lists
 hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
+hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, int rows, hipStream_t s);
+size_t sweep_lds_bytes(int mode);
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s);

@@ -38,6 +38,108 @@ TapRange prev_tap_range(int size, float off)
 }
 
 
+// ---- the pipelined sweep (tbrm_light_sweep.hip) ---------------------------------------------------------------------------
+// Which side of a pixel the previous-slice taps of NON-ZERO weight lie on along one buffer axis, and how far, over every
+// pixel of the axis, with the kernel's own fp32 sequence. side 0: every pixel reads itself alone. ok false: taps on both
+// sides (an offset so small that rounding decides the side pixel by pixel) or out of range — the sweep declines.
+struct TapSide { int side = 0, reach = 0; bool ok = false; };
+static TapSide prev_tap_side(int size, float off)
+{
+    TapSide t;
+    if (!std::isfinite(off) || size <= 0) return t;
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int c = 0; c < size; ++c) {
+        const float u = (((float) (uint32_t) c + 0.5f) / (float) size) + off;
+        float x = u * (float) size - 0.5f;
+        x = std::fmin(std::fmax(x, -0x1p30f), 0x1p30f);
+        const float fl = std::floor(x);
+        const float f = x - fl;
+        const int d = (int) fl - c;
+        lo = std::min(lo, d);
+        hi = std::max(hi, f != 0.0f ? d + 1 : d);
+    }
+    if (lo >= 0) { t.side = hi > 0 ? 1 : 0; t.reach = hi; t.ok = true; }
+    else if (hi <= 0) { t.side = -1; t.reach = -lo; t.ok = true; }
+    return t;
+}
+
+// Can the axis pass (one stream: pr == null) run as pipelined sweeps? The tiles' dependency has to point one way per buffer
+// axis for both streams (two lights of a fused Change whose minor components have opposite signs pull opposite ways:
+// declined), and the reach has to fit the kernel's LDS planes and one hand-off word per thread.
+bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, int rows, SweepFit& fit)
+{
+    if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident) return false;
+    if (mode != PASS_ADD && mode != PASS_CHANGE) return false;
+    fit = SweepFit{};
+    for (const tbrm_light_pass* q : {&pa, pr}) {
+        if (!q) continue;
+        const TapSide tx = prev_tap_side(q->td[0], q->prev_pixel_offset[0]), ty = prev_tap_side(q->td[1], q->prev_pixel_offset[1]);
+        if (!tx.ok || !ty.ok) return false;
+        if (tx.side * fit.sx < 0 || ty.side * fit.sy < 0) return false;
+        if (tx.side) fit.sx = tx.side;
+        if (ty.side) fit.sy = ty.side;
+        fit.hx = std::max(fit.hx, tx.reach);
+        fit.hy = std::max(fit.hy, ty.reach);
+    }
+    const int threads = 1024 / rows;
+    return fit.hx <= 14 && fit.hy <= 14 && 32 * (fit.hx + fit.hy) + fit.hx * fit.hy <= threads;
+}
+
+void release_sweep(tbrm_resources* r)
+{
+    for (auto& rec : r->sweep_rec) { (void) hipFree(rec); rec = nullptr; }
+    r->sweep_rec_words = 0;
+    (void) hipFree(r->sweep_ticket);
+    r->sweep_ticket = nullptr;
+    if (r->sweep_error) (void) hipHostFree(r->sweep_error);
+    r->sweep_error = nullptr;
+}
+
+int sweep_check(tbrm_resources* r)
+{
+    if (!r->sweep_error || *r->sweep_error == 0) return TBRM_OK;
+    const int e = *r->sweep_error;
+    *r->sweep_error = 0;
+    return fail(TBRM_ERR_NO_DEVICE, "a light-propagation sweep failed on the device (%s%s): the light volume is undefined",
+                (e & 1) ? "a tile gave up waiting for its neighbours" : "", (e & 2) ? " previous-slice taps outside the planned halo" : "");
+}
+
+// room for the hand-off records of a span of `slices` slices (both streams), the tickets and the error word
+static int ensure_sweep(tbrm_resources* r, size_t words)
+{
+    if (!r->sweep_ticket) {
+        HIP_TRY(hipMalloc((void**) &r->sweep_ticket, 2 * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(r->sweep_ticket, 0, 2 * sizeof(int), r->stream));
+        HIP_TRY(hipHostMalloc((void**) &r->sweep_error, sizeof(int), hipHostMallocMapped));
+        *r->sweep_error = 0;
+    }
+    if (words > r->sweep_rec_words) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        for (auto& rec : r->sweep_rec) {
+            (void) hipFree(rec);
+            rec = nullptr;
+        }
+        r->sweep_rec_words = 0;
+        for (auto& rec : r->sweep_rec) {
+            HIP_TRY(hipMalloc((void**) &rec, words * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(rec, 0, words * sizeof(uint32_t), r->stream)); // tag 0: no launch
+        }
+        r->sweep_rec_words = words;
+        r->sweep_epoch = 0;
+    }
+    return TBRM_OK;
+}
+
+static int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch)
+{
+    if (++r->sweep_epoch >= (1u << 24)) { // 2^24 launches later: tags start over
+        for (auto& rec : r->sweep_rec) HIP_TRY(hipMemsetAsync(rec, 0, r->sweep_rec_words * sizeof(uint32_t), r->stream));
+        r->sweep_epoch = 1;
+    }
+    epoch = r->sweep_epoch;
+    return TBRM_OK;
+}
+
 float through_light_format(int lv_fmt, float v)
 {
     if (lv_fmt != FMT_U8) return v;
@@ -423,7 +525,15 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     }
     if (change && have_r) mode = PASS_CHANGE_CACHED; // only the new light is propagated; its windows follow its taps alone
     ChunkFit fit;
-    if (!chunk_fit(r, pa, mode == PASS_CHANGE_CACHED ? nullptr : pr, fit, mode)) {
+    // The pipelined sweep takes whole, unpartitioned passes over a UNORM8 light volume whose L nobody keeps or supplies
+    SweepFit sfit;
+    int sweep_rows = tune(TUNE_SWEEP_ROWS);
+    if (sweep_rows != 1 && sweep_rows != 2 && sweep_rows != 4) sweep_rows = 2;
+    const bool sweep = !slab && !cache_on && sweep_fit(r, pa, pr, mode, sweep_rows, sfit);
+    if (sweep) {
+        int S = tune(TUNE_OCC_SLICES) > 0 ? tune(TUNE_OCC_SLICES) : 128;
+        fit.M = std::max(8, std::min(S, 504)); // a span per launch (the kernel's flag table holds 64 slice groups)
+    } else if (!chunk_fit(r, pa, mode == PASS_CHANGE_CACHED ? nullptr : pr, fit, mode)) {
         if (mode == PASS_CHANGE_CACHED) { // (an Add-sized hull that the cached shapes lack: propagate both lights)
             mode = two_stream_mode;
             have_r = nullptr;
@@ -469,6 +579,8 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     if (change && mode != PASS_CHANGE_CACHED) fill_chunk_stream(p.r, *pr, r->lv_fmt);
     const int M = fit.M;
     plan.M = M;
+    plan.sweep = sweep;
+    plan.sweep_rows = sweep_rows;
 
     // what this handle runs: the whole pass, or (slab-partitioned) its rows of every slice / its slices of a pass along z
     plan.D = D_pass;
@@ -535,6 +647,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     int S = 128; // measured on MI355X, fused Change at 512^3: S = 32 2.80 ms, 64 2.61, 128 2.53, 256 2.52
     if (tune(TUNE_OCC_SLICES) > 0) S = tune(TUNE_OCC_SLICES);
     S = std::max(M, (S / M) * M);
+    if (sweep) S = M;
 
     const size_t slice_elems = (size_t) W * H;
     while (S > M && ((size_t) S * slice_elems + 2 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) S -= M;
@@ -563,6 +676,14 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     for (int b = 0; b < 2; ++b)
         for (int si = 0; si < (plan.two_streams() ? 2 : 1); ++si)
             if (int e = ensure_store(r, &r->occ_tmp[b][si], S, slice_elems, si == 0 ? flag_bytes : 0)) return e;
+    if (sweep) {
+        SweepParams& q = plan.sq;
+        q.sx = sfit.sx; q.sy = sfit.sy; q.hx = sfit.hx; q.hy = sfit.hy;
+        const size_t words = (size_t) std::min(S, D) * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy));
+        if (int e = ensure_sweep(r, std::max<size_t>(words, 1))) return e;
+        // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
+        q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 4;
+    }
     plan.serial = ++r->plan_serial;
     return TBRM_OK;
 }
@@ -648,9 +769,30 @@ static int enqueue_apply(tbrm_resources* r, const PassPlan* const* plans, int n)
 
 static bool plan_has_occlusion(const PassPlan& plan) { return !plan.sliced && !plan.apply && plan.n_chunks > 0; }
 
+static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next);
+
+// Nothing may outlive a failed operator on the second stream: an occlusion launched beside the chain would still be reading
+// the data volume and the skipping metadata when the caller uploads or frees them, and its buffer would keep a label that
+// no chain will ever wait for.
+void quiesce_occ_stream(tbrm_resources* r)
+{
+    if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
+    for (int b = 0; b < 2; ++b) {
+        r->occ_slot_async[b] = false;
+        r->occ_slot[b] = tbrm_resources::OccSlot{};
+    }
+}
+
 // Enqueues chunk c of the plan: in front of a span's first chunk the occlusion of the span unless it is already under way,
 // and the occlusion of the span after it (of this plan, or the first of `next`) beside this span's chain; then the chain.
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next)
+{
+    const int e = enqueue_plan_chunk_impl(r, plan, c, next);
+    if (e != TBRM_OK) quiesce_occ_stream(r);
+    return e;
+}
+
+static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next)
 {
     if (plan.sliced) {
         PropParams sp = plan.slice_params;
@@ -696,7 +838,7 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const Pas
         // the span after this one — beside a chain that propagates one stream: the LDS of a two-stream chain leaves an
         // occlusion workgroup no room on its CU — and one tile per CU at most: with several rounds of tiles the chain's own
         // workgroups are what fills a CU's spare slots (1024^3: 16.2 ms per Change one after the other, 17.1 beside)
-        if (tune(TUNE_OCC_OVERLAP) > 0 && ns == 1 && p.tiles_x * p.tiles_y <= r->n_cus) {
+        if (tune(TUNE_OCC_OVERLAP) > 0 && (ns == 1 || plan.sweep) && p.tiles_x * p.tiles_y <= r->n_cus) {
             const PassPlan* np = sp + 1 < plan.n_spans ? &plan : (next && plan_has_occlusion(*next) ? next : nullptr);
             if (np) {
                 // only when the requested occlusion workgroups per CU all fit beside this plan's chain workgroup: every one of
@@ -706,7 +848,8 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const Pas
                 ChunkParams full = plan.p;
                 full.n_steps = M;
                 full.j0 = plan.start;
-                const size_t chain_lds = chunk_lds_bytes(full, plan.mode, r->lv_fmt), occ_lds = occlusion_lds_bytes(np->p) + 2560;
+                const size_t chain_lds = plan.sweep ? sweep_lds_bytes(plan.mode) : chunk_lds_bytes(full, plan.mode, r->lv_fmt);
+                const size_t occ_lds = occlusion_lds_bytes(np->p) + 2560;
                 const int room = chain_lds < 160 * 1024 ? (int) ((160 * 1024 - chain_lds) / occ_lds) : 0;
                 const int wgs = room >= tune(TUNE_OCC_OVERLAP) ? tune(TUNE_OCC_OVERLAP) : 0;
                 if (wgs > 0)
@@ -741,7 +884,17 @@ int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const Pas
     p.occ_list = nullptr;
     p.occ_count = nullptr;
     p.occ_flags = nullptr;
-    HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
+    if (plan.sweep) {
+        SweepParams q = plan.sq;
+        q.rec[0] = r->sweep_rec[0];
+        q.rec[1] = r->sweep_rec[1];
+        q.ticket = r->sweep_ticket;
+        q.error = r->sweep_error;
+        if (int e = next_sweep_epoch(r, q.epoch)) return e;
+        HIP_TRY(launch_light_sweep(p, q, plan.mode, plan.sweep_rows, r->stream));
+    } else {
+        HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
+    }
     ++r->launches[0];
     if (c == plan.n_chunks - 1) // an entry is complete once the last chunk that fills it is on the stream
         for (int si = 0; si < ns; ++si)
@@ -801,6 +954,10 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
 {
     if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)
         if (int e = ensure_skipping(r)) return e;
+    struct Unpin { // planning pins cache entries (use_kept / kept_new): released on every way out
+        tbrm_resources* r;
+        ~Unpin() { unpin_kept(r); }
+    } unpin{r};
     std::vector<PassPlan> plans;
     std::vector<char> chunked;
     for (size_t i = 0; i < specs.size(); ++i) {
@@ -834,21 +991,14 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             const PassPlan* run[kApplyMaxPasses];
             int n = 0;
             while (i + n < specs.size() && n < kApplyMaxPasses && chunked[i + n] && plans[i + n].apply) { run[n] = &plans[i + n]; ++n; }
-            if (int e = enqueue_apply(r, run, n)) { unpin_kept(r); return e; }
+            if (int e = enqueue_apply(r, run, n)) return e;
             i += (size_t) n - 1;
             continue;
         }
         const PassPlan* next = i + 1 < specs.size() && chunked[i + 1] ? &plans[i + 1] : nullptr;
         for (int c = 0; c < plans[i].n_chunks; ++c)
-            if (int e = enqueue_plan_chunk(r, plans[i], c, next)) {
-                // an occlusion already under way beside the chain will not be consumed: nothing may outlive the operator on
-                // the second stream (the caller may free or overwrite what it reads)
-                if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
-                unpin_kept(r);
-                return e;
-            }
+            if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e; // (enqueue_plan_chunk has drained the second stream)
     }
-    unpin_kept(r);
     return TBRM_OK;
 }
 

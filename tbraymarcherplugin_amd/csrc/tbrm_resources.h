@@ -108,6 +108,13 @@ struct tbrm_resources {
     uint64_t plan_serial = 0;      // PassPlan::serial of the last plan made
     hipStream_t occ_stream = nullptr; // low priority; created with the first overlapped launch
     hipEvent_t occ_ev_fork[2]{}, occ_ev_ready[2]{};
+    // the pipelined sweep (k_light_sweep, tbrm_light_sweep.hip): hand-off records of the two streams ([slice][tile][word],
+    // never cleared: words carry the tag of the launch that wrote them), the tile tickets and the error word
+    uint32_t* sweep_rec[2] = {nullptr, nullptr};
+    size_t sweep_rec_words = 0;    // capacity of each
+    int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
+    int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
+    uint32_t sweep_epoch = 0;      // tag of the last sweep launch
     std::vector<KeptPass*> kept;   // the contribution cache (every entry nx*ny*nz floats: an axis pass covers the light volume once)
     uint64_t kept_clock = 0;       // its LRU clock
     int kept_auto_entries = -1;    // light_cache_mb < 0: entries this handle may hold (-1: not asked yet)
@@ -197,6 +204,10 @@ struct PassPlan {
     // kernel structure (k_propagate_slice) on the read / write buffers, which then are the planes the host exchanges
     bool sliced = false;
     PropParams slice_params{};
+    // the pass's chunks are spans advanced by the pipelined sweep kernel (one launch per span; sweep_fit)
+    bool sweep = false;
+    SweepParams sq{};
+    int sweep_rows = 2;
     int halo_rows = 0;          // lateral: rows a slice's taps can reach beyond a slab
 };
 
@@ -205,9 +216,14 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
 int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr);
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
+struct SweepFit { int sx = 0, sy = 0, hx = 0, hy = 0; };
+bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, int rows, SweepFit& fit);
+void release_sweep(tbrm_resources* r);
+int sweep_check(tbrm_resources* r); // after the stream has drained: did a sweep kernel raise its error word?
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next = nullptr); // next: the plan enqueued after this one
+void quiesce_occ_stream(tbrm_resources* r);  // waits for the occlusion stream and forgets what its buffers hold
 void release_kept(tbrm_resources* r);       // frees the contribution cache (the stream must be idle)
 void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the contribution cache (the stream must be idle)
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);

@@ -26,6 +26,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in tbrm.h but not exported by libtbrm.so"
     assert b"gfx950" in lib.tbrm_version()
+    assert lib.tbrm_abi_version() == 3  # include/tbrm.h TBRM_ABI_VERSION
 
 
 def test_struct_layouts_match_the_header():
@@ -106,7 +107,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
     # every symbol that takes the handle first is covered here or in the test above
     covered = set(calls) | {"tbrm_resources_destroy", "tbrm_resources_is_initialized", "tbrm_add_dir_light", "tbrm_flush",
                             "tbrm_raymarch_intensity_device", "tbrm_raymarch_octree_device", "tbrm_download_octree_mip"}
-    free = {"tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable", "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_color_curve_to_lut",
+    free = {"tbrm_abi_version", "tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable", "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_color_curve_to_lut",
             "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip",
             "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local"}
     assert set(abi.SYMBOLS) == covered | free, set(abi.SYMBOLS) ^ (covered | free)
