@@ -34,7 +34,7 @@ struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
-    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0},
+    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_debug", 0},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -1103,7 +1103,7 @@ int tbrm_light_cache_stats(const tbrm_resources* r, uint64_t out[4])
     out[1] = r->kept_computed;
     out[2] = r->kept.size();
     // an axis pass covers the light volume once, whichever axis it runs along
-    out[3] = (uint64_t) r->kept.size() * ((uint64_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] + 2 * kPlaneGuard) * sizeof(float);
+    out[3] = (uint64_t) kept_bytes(r);
     return TBRM_OK;
 }
 

@@ -79,6 +79,14 @@ struct ChunkStream {
     const uint8_t* occ_flags; // chain: this stream's empty-block flags from the slice group holding the chunk's first slice on:
                             // [slice group][block y][block x]; null: none (the two streams of a jointly computed pass share one array)
     float* occ_next;        // occlusion launch: where the span's factors 1 - CurrentSample go, [span slices][H][W]
+    // Block-compact hand-over of the occlusion factors (k_light_occlusion writes, k_light_sweep reads; ChunkParams::compact):
+    // the live 16 x 16 x 8 block of rank k in the pass's ascending work list holds its factors as [slice 8][row 16][column 16]
+    // floats at fs_keep + 2048 k while k < fs_cap (a cache entry: tbrm_resources.h FactorEntry) and at
+    // fs_spill + 2048 (k - fs_cap) beyond (the handle's scratch store; fs_cap = 0: nothing is kept).
+    float* fs_keep;
+    float* fs_spill;
+    uint32_t fs_cap;
+    const int32_t* fs_slot; // sweep: rank of every block of the pass, [slice group][block y][block x]; -1: flagged empty (factor 1)
     float* l_dump;          // chain: 1024 floats nobody reads (kept L of tile pixels outside the buffer; the entry's guard band)
     float* l_out;           // chain: where the stream's unquantised L of every pixel of the chunk's slices is kept, [chunk slices][H][W]
                             // (null: not kept). PASS_CHANGE_CACHED: stream r is not propagated — r.occ_base / r.occ_off address its kept L
@@ -126,6 +134,9 @@ struct ChunkParams {
     int occ_grid_cap;             // occlusion launch: at most this many workgroups, each walking several blocks (0: one per block)
     uint32_t* occ_list_out;       // k_occ_compact: the whole pass, [chunk][per-chunk capacity]
     int* occ_count_out;           // k_occ_compact: [chunk]
+    int32_t* occ_slot_out;        // k_occ_compact: rank of every block in its chunk's list, -1 for the flagged ones (null: not wanted)
+    int compact;                  // occlusion launch / sweep: the factors are handed over block-compact (ChunkStream::fs_*)
+    const float* ones;            // sweep: 1024 floats of 1.0 (the factor of flagged-empty blocks and of pixels beyond the buffer)
     ChunkStream a, r;
 };
 
@@ -143,6 +154,7 @@ struct SweepParams {
     int prefetch;           // slices ahead of their use that the neighbours' records are requested
     int* ticket;            // [0]: next tile to start (tiles are dealt in upstream-first order: a tile only ever waits for tiles
                             // that started before it), [1]: tiles finished (the last one re-arms both)
+    int debug;              // diagnostics (sweep_debug tunable): bit 0 = tiles do not wait for each other (WRONG results: slice time alone)
     int* error;             // set when a tile gave up waiting (bit 0) or found its taps outside the halo (bit 1)
 };
 
@@ -262,8 +274,9 @@ enum Tunable : int {
     TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)
     TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
     TUNE_LIGHT_SWEEP,        // 0: axis passes never take the pipelined sweep kernel (k_light_sweep); 1: where it applies
-    TUNE_SWEEP_ROWS,         // rows of the tile per lane of a sweep workgroup: 1 (16 waves), 2 (8 waves), 4 (4 waves); 0: default
+    TUNE_SWEEP_ROWS,         // (unused: a sweep lane owns two rows)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
+    TUNE_SWEEP_DEBUG,        // timing diagnostics of the sweep kernel; non-zero values give WRONG light volumes (SweepParams::debug)
     TUNE_COUNT
 };
 int tune(Tunable t);
@@ -278,8 +291,10 @@ constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plan
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s); // + the work lists
 hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
-hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, int rows, hipStream_t s);
+hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s);
 size_t sweep_lds_bytes(int mode);
+int sweep_halo_chunks(int hx, int hy);
+int sweep_max_slices();
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s);

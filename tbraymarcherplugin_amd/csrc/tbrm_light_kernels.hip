@@ -384,10 +384,33 @@ __global__ __launch_bounds__(1024) void k_occ_compact(const ChunkParams p)
     const int n = min(p.chunk_slices, p.pass_slices - c * p.chunk_slices);
     const int live_groups = (n + kOccDepth - 1) / kOccDepth;       // slice groups past the chunk's last slice have no work
     const int live = live_groups * p.occ_blocks_y * p.occ_blocks_x;
-    const int run = (per_chunk + NT - 1) / NT;
+    // thread t owns `run` consecutive flags, a multiple of 16 so that they are fetched 16 at a time (a whole pass of a 512^3
+    // volume in one span is 64 flags per thread: byte by byte their load latencies added up to 60 us)
+    const int run = (((per_chunk + NT - 1) / NT) + 15) & ~15;
     const int i0 = min((int) threadIdx.x * run, live), i1 = min(i0 + run, live);
+    const bool wide = (((size_t) flags) & 15) == 0; // (i0 is a multiple of 16)
+    auto for_each_flag = [&](auto&& f) {
+        for (int i = i0; i < i1; i += 16) {
+            uint32_t w[4];
+            if (wide && i + 16 <= per_chunk) {
+                const uint4 v = *(const uint4*) (flags + i);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w[k] = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (i + 4 * k + b < per_chunk) w[k] |= (uint32_t) flags[i + 4 * k + b] << (8 * b);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (i + k < i1) f(i + k, ((w[k >> 2] >> (8 * (k & 3))) & 255u) != 0);
+        }
+    };
     int mine = 0;
-    for (int i = i0; i < i1; ++i) mine += flags[i] ? 0 : 1;
+    for_each_flag([&](int, bool flagged) { mine += flagged ? 0 : 1; });
     s_scan[threadIdx.x] = mine;
     __syncthreads();
     for (int d = 1; d < NT; d <<= 1) { // inclusive Hillis-Steele scan
@@ -397,8 +420,13 @@ __global__ __launch_bounds__(1024) void k_occ_compact(const ChunkParams p)
         __syncthreads();
     }
     int pos = s_scan[threadIdx.x] - mine;
-    for (int i = i0; i < i1; ++i)
-        if (!flags[i]) list[pos++] = (uint32_t) i;
+    int32_t* const slot = p.occ_slot_out ? p.occ_slot_out + (size_t) c * per_chunk : nullptr;
+    for_each_flag([&](int i, bool flagged) {
+        if (slot) slot[i] = flagged ? -1 : pos;
+        if (!flagged) list[pos++] = (uint32_t) i;
+    });
+    if (slot) // slice groups past the chunk's last slice
+        for (int i = live + (int) threadIdx.x; i < per_chunk; i += NT) slot[i] = -1;
     if (threadIdx.x == NT - 1) p.occ_count_out[c] = s_scan[NT - 1];
 }
 
@@ -585,7 +613,15 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
             const uint32_t u0 = voff(tu.i0, AU{}), u1 = voff(tu.i0 + 1, AU{}), v0 = voff(tv.i0, AV{}), v1 = voff(tv.i0 + 1, AV{});
             const uint32_t o00 = u0 + v0, o10 = u1 + v0, o01 = u0 + v1, o11 = u1 + v1;
             const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
+            // where the factors go: the span's plane stack, or (block-compact hand-over) the block's own 8 x 16 x 16 floats —
+            // `entry` is the block's rank in the pass's work list
             float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
+            int out_step = plane_elems;
+            if (p.compact) {
+                float* const blk_base = (uint32_t) entry < s.fs_cap ? s.fs_keep + (size_t) entry * 2048 : s.fs_spill + (size_t) ((uint32_t) entry - s.fs_cap) * 2048;
+                out = blk_base + (py - py0) * kOccTile + (px - px0);
+                out_step = kOccTile * kOccTile;
+            }
             // One texel plane of the footprint (4 taps at one slice-axis coordinate), reduced as far as the filter order
             // (x, then y, then z) allows before the slice-axis weight is applied. Consecutive slices of a pass usually
             // sample consecutive texel planes, so the +1 plane of one step is the base plane of the next: it is kept in
@@ -632,7 +668,7 @@ __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, in
                 if constexpr (GUARD) inside = guard_uv && (fl & 4);
                 float occ = 0.0f;
                 if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
-                out[q * plane_elems] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
+                out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }
         }
     };

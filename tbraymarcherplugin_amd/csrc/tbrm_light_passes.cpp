@@ -65,11 +65,13 @@ static TapSide prev_tap_side(int size, float off)
 
 // Can the axis pass (one stream: pr == null) run as pipelined sweeps? The tiles' dependency has to point one way per buffer
 // axis for both streams (two lights of a fused Change whose minor components have opposite signs pull opposite ways:
-// declined), and the reach has to fit the kernel's LDS planes and one hand-off word per thread.
-bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, int rows, SweepFit& fit)
+// declined), the reach has to fit the kernel's LDS planes and the hand-off wave's six words per lane, and the pass has to
+// consist of whole brick layers of the light volume.
+bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit)
 {
     if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident) return false;
     if (mode != PASS_ADD && mode != PASS_CHANGE) return false;
+    if (pa.td[2] % 8 != 0 || (pa.start & 7) != (pa.dir > 0 ? 0 : 7)) return false;
     fit = SweepFit{};
     for (const tbrm_light_pass* q : {&pa, pr}) {
         if (!q) continue;
@@ -81,8 +83,7 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         fit.hx = std::max(fit.hx, tx.reach);
         fit.hy = std::max(fit.hy, ty.reach);
     }
-    const int threads = 1024 / rows;
-    return fit.hx <= 14 && fit.hy <= 14 && 32 * (fit.hx + fit.hy) + fit.hx * fit.hy <= threads;
+    return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= 6;
 }
 
 void release_sweep(tbrm_resources* r)
@@ -168,7 +169,7 @@ int declined(const char* why) { g_plan_note = why; return TBRM_ERR_UNSUPPORTED; 
 // 72 x 48 LDS planes (tbrm_light_chain.h): the kernels that have them
 static int rect_planes_for(const tbrm_resources* r, int mode)
 {
-    return (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) && r->lv_fmt == FMT_U8 && tune(TUNE_CHAIN_RECT_PLANES) != 0 ? 1 : 0;
+    return mode == PASS_ADD && r->lv_fmt == FMT_U8 && tune(TUNE_CHAIN_RECT_PLANES) != 0 ? 1 : 0;
 }
 
 // Chunk length of a pass (one stream: pr == null, else two) and the tap ranges its windows have to cover: the longest of
@@ -322,16 +323,36 @@ static SpanRange span_range(const PassPlan& plan, int sp)
     return q;
 }
 
-// ---- occlusion stores and the contribution cache (tbrm_resources.h) ----------------------------------------------------
+// ---- occlusion stores and the factor cache (tbrm_resources.h) ------------------------------------------------------------
+
+static void drain_streams(tbrm_resources* r)
+{
+    (void) hipStreamSynchronize(r->stream);
+    if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
+}
+
+static void free_entry(FactorEntry* e)
+{
+    (void) hipFree(e->base);
+    (void) hipFree(e->slot);
+    if (e->count_host) (void) hipHostFree(e->count_host);
+    for (hipEvent_t ev : {e->ev_count, e->ev_filled, e->ev_idle})
+        if (ev) (void) hipEventDestroy(ev);
+    delete e;
+}
 
 void release_kept(tbrm_resources* r)
 {
-    for (KeptPass* e : r->kept) {
-        (void) hipFree(e->base);
-        delete e;
-    }
+    if (!r->kept.empty()) drain_streams(r);
+    for (FactorEntry* e : r->kept) free_entry(e);
     r->kept.clear();
-    r->kept_auto_entries = -1;
+}
+
+size_t kept_bytes(const tbrm_resources* r)
+{
+    size_t n = 0;
+    for (const FactorEntry* e : r->kept) n += e->bytes();
+    return n;
 }
 
 void release_occ_stores(tbrm_resources* r)
@@ -345,6 +366,18 @@ void release_occ_stores(tbrm_resources* r)
             st = OccStore{};
         }
     for (auto& slot : r->occ_slot) slot = tbrm_resources::OccSlot{};
+    for (FactorScratch& f : r->f_scratch) {
+        for (float*& st : f.store) { (void) hipFree(st); st = nullptr; }
+        (void) hipFree(f.flags);
+        (void) hipFree(f.list);
+        (void) hipFree(f.slot);
+        (void) hipFree(f.count);
+        for (hipEvent_t ev : {f.ev_ready, f.ev_idle})
+            if (ev) (void) hipEventDestroy(ev);
+        f = FactorScratch{};
+    }
+    (void) hipFree(r->d_ones);
+    r->d_ones = nullptr;
     release_kept(r);
 }
 
@@ -377,9 +410,62 @@ static int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slic
     return TBRM_OK;
 }
 
-static KeptKey kept_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard)
+static int ensure_occ_stream(tbrm_resources* r)
 {
-    KeptKey k;
+    if (r->occ_stream) return TBRM_OK;
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], hipEventDisableTiming));
+    }
+    return TBRM_OK;
+}
+
+// the scratch of a sweep pass with `blocks` occlusion blocks: stores of `streams` streams (every block could be live), the
+// pass's metadata, the page of ones
+static int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int streams)
+{
+    FactorScratch& f = r->f_scratch[b];
+    if (!r->d_ones) {
+        HIP_TRY(hipMalloc((void**) &r->d_ones, 1024 * sizeof(float)));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_ones, 0x3f800000, 1024, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream)); // (read from the occlusion stream's sweeps' predecessors: simplest to have it done)
+    }
+    if (!f.ev_ready) {
+        HIP_TRY(hipEventCreateWithFlags(&f.ev_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&f.ev_idle, hipEventDisableTiming));
+    }
+    const bool grow_store = blocks > f.store_blocks, grow_meta = blocks > f.meta_blocks;
+    bool need = grow_meta;
+    for (int si = 0; si < streams; ++si) need = need || grow_store || !f.store[si];
+    if (!need) return TBRM_OK;
+    drain_streams(r);
+    if (grow_meta) {
+        (void) hipFree(f.flags); (void) hipFree(f.list); (void) hipFree(f.slot); (void) hipFree(f.count);
+        f.flags = nullptr; f.list = nullptr; f.slot = nullptr; f.count = nullptr;
+        f.meta_blocks = 0;
+        HIP_TRY(hipMalloc((void**) &f.flags, blocks));
+        HIP_TRY(hipMalloc((void**) &f.list, blocks * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**) &f.slot, blocks * sizeof(int32_t)));
+        HIP_TRY(hipMalloc((void**) &f.count, 16 * sizeof(int)));
+        f.meta_blocks = blocks;
+    }
+    if (grow_store) {
+        for (float*& st : f.store) { (void) hipFree(st); st = nullptr; }
+        f.store_blocks = 0;
+    }
+    const size_t cap = std::max(blocks, f.store_blocks);
+    for (int si = 0; si < streams; ++si)
+        if (!f.store[si]) HIP_TRY(hipMalloc((void**) &f.store[si], cap * 2048 * sizeof(float)));
+    f.store_blocks = cap;
+    return TBRM_OK;
+}
+
+static FactorKey factor_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard)
+{
+    FactorKey k;
     memset(&k, 0, sizeof(k)); // compared bytewise
     k.data_gen = r->data_gen;
     k.tf_gen = r->tf_gen;
@@ -389,177 +475,135 @@ static KeptKey kept_key(const tbrm_resources* r, const PropParams& base, const t
     k.clip_mode = base.clip_mode;
     k.axis = q.axis; k.dir = q.dir; k.start = q.start; k.D = q.td[2]; k.W = q.td[0]; k.H = q.td[1];
     // the Add shader's uvw == saturate(uvw) guard only matters where a sample outside the cube could be opaque
-    // (k_shell_transparent): else both shaders propagate the same L and one entry serves both
+    // (k_shell_transparent): else both shaders compute the same factors and one entry serves both
     k.guard = (guard && !r->shell_transparent) ? 1 : 0;
     k.step100 = q.step_size * 100.0f;
-    k.prev_off[0] = q.prev_pixel_offset[0]; k.prev_off[1] = q.prev_pixel_offset[1];
-    k.light_alpha = q.light_alpha;
-    k.border_light = q.border_light;
     return k;
 }
 
-static size_t kept_elems(const tbrm_resources* r) { return (size_t) r->lv_dims[0] * r->lv_dims[1] * r->lv_dims[2] + 2 * kPlaneGuard; }
-
-static KeptPass* kept_find(tbrm_resources* r, const KeptKey& key)
+// what is known about the live blocks of a pass under the current volume / transfer function / window
+static void estimate_scope(tbrm_resources* r, const PropParams& base)
 {
-    for (KeptPass* e : r->kept)
-        if (e->valid && !memcmp(&e->key, &key, sizeof(key))) return e;
+    const float win[4] = {base.win.center, base.win.width, base.win.low_cutoff, base.win.high_cutoff};
+    if (r->f_est_key[0] != r->data_gen || r->f_est_key[1] != r->tf_gen || memcmp(r->f_est_win, win, sizeof(win))) {
+        r->f_est_key[0] = r->data_gen;
+        r->f_est_key[1] = r->tf_gen;
+        memcpy(r->f_est_win, win, sizeof(win));
+        r->f_est_blocks = 0;
+    }
+}
+
+// reads an entry's live-block count once it has arrived (wait: block until it has); an entry that overflowed is dropped
+static void resolve_entry(tbrm_resources* r, FactorEntry* e, bool wait)
+{
+    if (e->resolved || !e->enqueued) return;
+    if (wait) (void) hipEventSynchronize(e->ev_count);
+    else if (hipEventQuery(e->ev_count) != hipSuccess) { (void) hipGetLastError(); return; }
+    e->resolved = true;
+    const size_t count = (size_t) std::max(*e->count_host, 0);
+    e->valid = count <= e->cap_blocks;
+    if (e->key.data_gen == r->f_est_key[0] && e->key.tf_gen == r->f_est_key[1] && !memcmp(e->key.win, r->f_est_win, sizeof(e->key.win)))
+        r->f_est_blocks = std::max(r->f_est_blocks, count);
+}
+
+static FactorEntry* kept_find(tbrm_resources* r, const FactorKey& key)
+{
+    for (FactorEntry* e : r->kept) {
+        if (!e->enqueued || memcmp(&e->key, &key, sizeof(key)) || (e->resolved && !e->valid)) continue;
+        resolve_entry(r, e, true);
+        if (e->valid) return e;
+    }
     return nullptr;
 }
 
-// An entry for a pass about to be propagated: a fresh allocation while the budget (light_cache_mb) lasts, else the least
-// recently used entry that the operator being planned does not use. null: the cache is off, or full of pinned entries.
-static KeptPass* kept_new(tbrm_resources* r, const KeptKey& key)
+// the budget of the factor cache in bytes: the tunable, or (auto) an eighth of the device's memory
+static size_t kept_budget(const tbrm_resources* r)
 {
-    const size_t bytes = kept_elems(r) * sizeof(float);
-    // light_cache_mb < 0 (the default): no fixed budget — up to 32 entries (16 lights of two passes each; what a replaced
-    // direction left behind goes first), each added only while that leaves half of the device's memory free (whoever else
-    // uses the device included), so the cache grows to what the scene's lights need (4 lights at 1024^3:
-    // 34 GB of the 288) and never crowds out a volume; a budget too small for the scene would evict every entry before its
-    // light comes round again and pay for the stores without ever reading them
-    size_t budget = (size_t) std::max(tune(TUNE_LIGHT_CACHE_MB), 0) << 20;
-    bool room = (r->kept.size() + 1) * bytes <= budget;
-    if (tune(TUNE_LIGHT_CACHE_MB) < 0) {
-        if (r->kept_auto_entries < 0) { // asked once per handle (hipMemGetInfo takes milliseconds); a later allocation that fails shrinks it
-            size_t free_b = 0, total_b = 0;
-            r->kept_auto_entries = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > total_b / 2)
-                r->kept_auto_entries = (int) std::min<size_t>(32, (free_b - total_b / 2) / bytes);
+    const int mb = tune(TUNE_LIGHT_CACHE_MB);
+    if (mb >= 0) return (size_t) mb << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    return total_b / 8;
+}
+
+// An entry for a pass about to be computed, sized for `want` blocks: the buffer of an entry whose light has left the scene
+// if one is large enough (no allocation while lights merely move), else a fresh allocation while the budget lasts and the
+// device has room to spare, else the least recently used entry's. null: the cache is off, or nothing can be had.
+static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t want, size_t table_blocks)
+{
+    const size_t bytes = want * 2048 * sizeof(float);
+    FactorEntry* e = nullptr;
+    auto fits = [&](const FactorEntry* c) { return !c->pinned && c->cap_blocks >= want && c->cap_blocks <= want + want / 2 + 64 && c->table_blocks >= table_blocks; };
+    for (FactorEntry* c : r->kept) // dropped and spent entries first, oldest first
+        if (fits(c) && ((c->resolved && !c->valid) || c->spent || !c->enqueued) && (!e || c->last_use < e->last_use)) e = c;
+    if (!e) {
+        const size_t budget = kept_budget(r);
+        // make room: entries that are of no use go first, then the least recently used
+        auto victim = [&]() -> FactorEntry* {
+            FactorEntry* v = nullptr;
+            for (FactorEntry* c : r->kept)
+                if (!c->pinned && ((c->resolved && !c->valid) || c->spent || !c->enqueued) && (!v || c->last_use < v->last_use)) v = c;
+            if (v) return v;
+            for (FactorEntry* c : r->kept)
+                if (!c->pinned && (!v || c->last_use < v->last_use)) v = c;
+            return v;
+        };
+        if (bytes > budget) return nullptr;
+        while (kept_bytes(r) + bytes > budget) {
+            FactorEntry* v = victim();
+            if (!v) return nullptr;
+            drain_streams(r);
+            r->kept.erase(std::find(r->kept.begin(), r->kept.end(), v));
+            free_entry(v);
         }
-        room = (int) r->kept.size() < r->kept_auto_entries;
-        budget = room ? (r->kept.size() + 1) * bytes : r->kept.size() * bytes;
-    }
-    KeptPass* e = nullptr;
-    if (bytes > budget) return nullptr;
-    // an entry whose light a ChangeDirLight has replaced is taken first (no allocation while lights merely move: hipMalloc
-    // of a 4.3 GB entry at 1024^3 holds the host up for tens of milliseconds), oldest first
-    for (KeptPass* c : r->kept)
-        if (c->spent && !c->pinned && (!e || c->last_use < e->last_use)) e = c;
-    if (e) {
-    } else if (room) {
-        e = new KeptPass{};
-        if (hipMalloc((void**) &e->base, bytes) != hipSuccess) { // out of HBM: do without
+        // never the last of the device's memory: whoever else allocates on this device (a renderer, torch, another handle)
+        // must not find it gone (asked at every allocation: a few per scene, hipMemGetInfo takes milliseconds)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + ((size_t) 1 << 30)) { (void) hipGetLastError(); return nullptr; }
+        e = new FactorEntry{};
+        bool ok = hipMalloc((void**) &e->base, bytes) == hipSuccess && hipMalloc((void**) &e->slot, table_blocks * sizeof(int32_t)) == hipSuccess &&
+                  hipHostMalloc((void**) &e->count_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
+        for (hipEvent_t* ev : {&e->ev_count, &e->ev_filled, &e->ev_idle}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { // out of memory: do without
             (void) hipGetLastError();
-            delete e;
-            r->kept_auto_entries = std::min(r->kept_auto_entries, (int) r->kept.size());
+            free_entry(e);
             return nullptr;
         }
+        e->cap_blocks = want;
+        e->table_blocks = table_blocks;
         r->kept.push_back(e);
-    } else {
-        for (KeptPass* c : r->kept)
-            if (!c->pinned && (!e || c->last_use < e->last_use)) e = c;
-        if (!e) return nullptr;
     }
-    e->valid = false;
-    e->spent = false;
     e->key = key;
+    e->resolved = false;
+    e->valid = false;
+    e->enqueued = false;
+    e->spent = false;
     e->pinned = true;
     e->last_use = ++r->kept_clock;
+    *e->count_host = 0;
     return e;
 }
 
-static void use_kept(tbrm_resources* r, KeptPass* e, bool as_removed = false)
+static void use_kept(tbrm_resources* r, FactorEntry* e, bool leaves_the_scene)
 {
-    e->spent = as_removed;
+    e->spent = leaves_the_scene;
     e->pinned = true;
     e->last_use = ++r->kept_clock;
 }
 
 static void unpin_kept(tbrm_resources* r)
 {
-    for (KeptPass* e : r->kept) e->pinned = false;
+    for (FactorEntry* e : r->kept) e->pinned = false;
 }
 
-// whole, unpartitioned passes of this handle can keep / use L (the chain addresses a kept L with 32-bit offsets)
-static bool cache_usable(const tbrm_resources* r)
-{
-    return !force_slice_kernel() && tune(TUNE_LIGHT_CACHE_MB) != 0 && kept_elems(r) * sizeof(float) < ((size_t) 1 << 34) &&
-           kept_elems(r) < ((size_t) 1 << 32);
-}
+static bool cache_usable(const tbrm_resources* r) { return !force_slice_kernel() && tune(TUNE_LIGHT_CACHE_MB) != 0; }
 
-// pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
-// pr, both added with b_added / b_added2).
-int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
-              const tbrm_slab* slab, PassPlan& plan, int two_stream_mode, float b_added2)
+// The common part of a chunked / swept pass's parameters
+static void fill_pass_params(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+                             float b_added2, PassPlan& plan)
 {
-    g_plan_note = "";
-    const bool change = pr != nullptr;
-    int mode = change ? two_stream_mode : PASS_ADD;
-    // Contribution cache (tbrm_resources.h KeptPass): is this light's L — and, for a Change, the removed light's — at hand?
-    // Whole, unpartitioned passes only; the chain addresses the removed light's L with 32-bit offsets.
-    KeptPass *have_a = nullptr, *have_r = nullptr;
-    const bool cache_on = !slab && mode != PASS_ADD2 && cache_usable(r);
-    KeptKey key_a{};
-    if (cache_on) {
-        key_a = kept_key(r, base, pa, mode == PASS_ADD);
-        have_a = kept_find(r, key_a);
-        if (change) have_r = kept_find(r, kept_key(r, base, *pr, false));
-    }
-    // whatever is kept of a light that this pass takes out of the scene (the removed side of a Change, a removal) is of no
-    // further use unless the light comes back: first in line when an entry is needed (kept_new)
-    auto retire = [&](const tbrm_light_pass& q) {
-        for (int guard = 0; guard < 2; ++guard)
-            if (KeptPass* e = kept_find(r, kept_key(r, base, q, guard != 0))) e->spent = true;
-    };
-    if (have_a && (!change || have_r)) { // nothing to propagate: one k_apply_kept launch
-        plan = PassPlan{};
-        plan.mode = mode;
-        plan.apply = true;
-        plan.kept_a = have_a;
-        plan.kept_r = change ? have_r : nullptr;
-        plan.apply_b = b_added;
-        plan.p.axis = pa.axis;
-        plan.p.W = pa.td[0];
-        plan.p.H = pa.td[1];
-        plan.start = pa.start;
-        plan.dir = pa.dir;
-        plan.D = pa.td[2];
-        plan.n_chunks = 1;
-        plan.chunks_of_pass = 1;
-        use_kept(r, have_a);
-        if (have_r) use_kept(r, have_r, true);
-        if (change) retire(*pr);
-        else if (b_added < 0.0f) retire(pa);
-        r->kept_hits += change ? 2 : 1;
-        return TBRM_OK;
-    }
-    if (change && have_r) mode = PASS_CHANGE_CACHED; // only the new light is propagated; its windows follow its taps alone
-    ChunkFit fit;
-    // The pipelined sweep takes whole, unpartitioned passes over a UNORM8 light volume whose L nobody keeps or supplies
-    SweepFit sfit;
-    int sweep_rows = tune(TUNE_SWEEP_ROWS);
-    if (sweep_rows != 1 && sweep_rows != 2 && sweep_rows != 4) sweep_rows = 2;
-    const bool sweep = !slab && !cache_on && sweep_fit(r, pa, pr, mode, sweep_rows, sfit);
-    if (sweep) {
-        int S = tune(TUNE_OCC_SLICES) > 0 ? tune(TUNE_OCC_SLICES) : 128;
-        fit.M = std::max(8, std::min(S, 504)); // a span per launch (the kernel's flag table holds 64 slice groups)
-    } else if (!chunk_fit(r, pa, mode == PASS_CHANGE_CACHED ? nullptr : pr, fit, mode)) {
-        if (mode == PASS_CHANGE_CACHED) { // (an Add-sized hull that the cached shapes lack: propagate both lights)
-            mode = two_stream_mode;
-            have_r = nullptr;
-            if (!chunk_fit(r, pa, pr, fit, mode)) {
-                if (!slab) return TBRM_ERR_UNSUPPORTED;
-                return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
-            }
-        } else {
-            if (!slab || two_stream_mode == PASS_ADD2) return TBRM_ERR_UNSUPPORTED;
-            return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
-        }
-    }
-    const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
-    plan = PassPlan{};
-    plan.mode = mode;
-    if (mode == PASS_CHANGE_CACHED) {
-        plan.kept_r = have_r;
-        use_kept(r, have_r, true);
-        ++r->kept_hits;
-    }
-    // what is added stays in the scene: its L is worth keeping (null: no room). What is removed does not.
-    if (cache_on && !have_a && !(mode == PASS_ADD && b_added < 0.0f)) plan.keep[0] = kept_new(r, key_a);
-    if (cache_on && change) retire(*pr);
-    if (cache_on && !change && b_added < 0.0f) retire(pa);
-    r->kept_computed += (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2;
     ChunkParams& p = plan.p;
+    const int W = pa.td[0], H = pa.td[1];
     p.data = base.data;
     p.data_border = base.data_border;
     p.tf = base.tf;
@@ -571,19 +615,11 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     p.axis = pa.axis;
     p.W = W; p.H = H;
     p.dir = pa.dir;
-    p.dx_lo = fit.tx.lo; p.dx_hi = fit.tx.hi; p.dy_lo = fit.ty.lo; p.dy_hi = fit.ty.hi;
-    p.rect_planes = rect_planes_for(r, mode);
     p.b_added = b_added;
     p.b_added2 = b_added2;
     fill_chunk_stream(p.a, pa, r->lv_fmt);
-    if (change && mode != PASS_CHANGE_CACHED) fill_chunk_stream(p.r, *pr, r->lv_fmt);
-    const int M = fit.M;
-    plan.M = M;
-    plan.sweep = sweep;
-    plan.sweep_rows = sweep_rows;
-
-    // what this handle runs: the whole pass, or (slab-partitioned) its rows of every slice / its slices of a pass along z
-    plan.D = D_pass;
+    if (pr) fill_chunk_stream(p.r, *pr, r->lv_fmt);
+    plan.D = pa.td[2];
     plan.start = pa.start;
     plan.dir = pa.dir;
     p.tiles_x = ceil_div(W, kChunkTile);
@@ -593,6 +629,120 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     p.occ_blocks_y = ceil_div(H, 16);
     p.roi_by0 = 0;
     p.roi_by1 = p.occ_blocks_y;
+}
+
+// A whole, unpartitioned pass over a UNORM8 light volume as ONE pipelined sweep (tbrm_light_sweep.hip): the occlusion of the
+// whole pass is computed block-compact on the occlusion stream — or comes from the factor cache — and one launch propagates.
+// TBRM_ERR_UNSUPPORTED (nothing changed): the pass takes the chunked chain.
+static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+                           PassPlan& plan, int mode)
+{
+    SweepFit sfit;
+    if (!sweep_fit(r, pa, pr, mode, sfit)) return TBRM_ERR_UNSUPPORTED;
+    const int D = pa.td[2];
+    if (D > sweep_max_slices() || tune(TUNE_SPARSE_OCC) == 0 || tune(TUNE_OCC_LIST) == 0) return TBRM_ERR_UNSUPPORTED;
+    if (int e = ensure_skipping(r)) return e; // (the work list needs the per-brick emptiness bits)
+    if (int e = ensure_occ_stream(r)) return e;
+    const bool change = pr != nullptr;
+    plan = PassPlan{};
+    plan.mode = mode;
+    plan.sweep = true;
+    fill_pass_params(r, base, pa, pr, b_added, 0.0f, plan);
+    ChunkParams& p = plan.p;
+    plan.M = plan.S = D;
+    plan.n_chunks = plan.n_spans = plan.chunks_of_pass = 1;
+    plan.sparse = plan.work_list = true;
+    p.occ_groups = D / 8;
+    plan.flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
+    plan.flags_per_span = (size_t) p.occ_groups * plan.flags_per_group;
+    p.empty_bits = r->d_empty;
+    p.pass_start = plan.start;
+    p.pass_slices = D;
+    p.chunk_slices = D;
+    p.compact = 1;
+    const size_t blocks = plan.flags_per_span;
+
+    // the factor cache: which streams' occlusion is at hand, which is computed (and kept)
+    estimate_scope(r, base);
+    for (FactorEntry* e : r->kept) resolve_entry(r, e, false); // (counts that have arrived sharpen the estimate)
+    const bool cache_on = cache_usable(r);
+    FactorEntry *have_a = nullptr, *have_r = nullptr;
+    FactorKey key_a{};
+    if (cache_on) {
+        key_a = factor_key(r, base, pa, mode == PASS_ADD);
+        have_a = kept_find(r, key_a);
+        if (change) have_r = kept_find(r, factor_key(r, base, *pr, false));
+        if (change && have_a && !have_r) have_a = nullptr; // (the removed light alone is not computed: both are)
+    }
+    // whatever is kept of a light that this pass takes out of the scene (the removed side of a Change, a removal) is of no
+    // further use unless the light comes back: first in line when a buffer is needed (kept_new)
+    auto retire = [&](const tbrm_light_pass& q) {
+        for (int guard = 0; guard < 2; ++guard) {
+            const FactorKey k = factor_key(r, base, q, guard != 0);
+            for (FactorEntry* e : r->kept)
+                if (!memcmp(&e->key, &k, sizeof(k))) e->spent = true;
+        }
+    };
+    plan.f_buf = r->f_buf ^ 1;
+    plan.occ_mode = -1;
+    if (have_a) { plan.f_entry[0] = have_a; plan.f_hit[0] = true; use_kept(r, have_a, !change && b_added < 0.0f); ++r->kept_hits; }
+    if (have_r) { plan.f_entry[1] = have_r; plan.f_hit[1] = true; use_kept(r, have_r, true); ++r->kept_hits; }
+    if (!have_a) {
+        // the added light's occlusion: alone (Add rules, or the Change shader's when the removed light's is at hand) or both
+        plan.occ_mode = !change ? PASS_ADD : (have_r ? PASS_CHANGE_ONE : PASS_CHANGE);
+        r->kept_computed += plan.occ_mode == PASS_CHANGE ? 2 : 1;
+        if (int e = ensure_factor_scratch(r, plan.f_buf, blocks, plan.occ_mode == PASS_CHANGE ? 2 : 1)) return e;
+        // what is added stays in the scene: its factors are worth keeping (null: no room). What is removed does not.
+        if (cache_on && !(mode == PASS_ADD && b_added < 0.0f)) {
+            const size_t want = r->f_est_blocks ? std::min(blocks, r->f_est_blocks + r->f_est_blocks / 32 + 64) : std::max<size_t>(blocks / 2, 1);
+            plan.f_entry[0] = kept_new(r, key_a, want, blocks);
+        }
+    } else if (int e = ensure_factor_scratch(r, plan.f_buf, blocks, 0)) return e; // (its events order the buffers' reuse)
+    if (cache_on && change) retire(*pr);
+    if (cache_on && !change && b_added < 0.0f) retire(pa);
+    r->f_buf = plan.f_buf;
+
+    SweepParams& q = plan.sq;
+    q.sx = sfit.sx; q.sy = sfit.sy; q.hx = sfit.hx; q.hy = sfit.hy;
+    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy));
+    if (words >= ((size_t) 1 << 32)) return declined("hand-off records too large");
+    if (int e = ensure_sweep(r, std::max<size_t>(words, 1))) return e;
+    // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
+    q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 2;
+    q.debug = tune(TUNE_SWEEP_DEBUG);
+    plan.serial = ++r->plan_serial;
+    return TBRM_OK;
+}
+
+// pr == null: Add of pa (b_added = +-1). Else two streams: mode PASS_CHANGE (pa added, pr removed) or PASS_ADD2 (pa, then
+// pr, both added with b_added / b_added2).
+int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
+              const tbrm_slab* slab, PassPlan& plan, int two_stream_mode, float b_added2)
+{
+    g_plan_note = "";
+    const bool change = pr != nullptr;
+    const int mode = change ? two_stream_mode : PASS_ADD;
+    if (!slab) {
+        const int e = plan_pass_sweep(r, base, pa, pr, b_added, plan, mode);
+        if (e != TBRM_ERR_UNSUPPORTED) return e;
+    }
+    // the chunked chain: whatever the sweep declines (float light volumes, passes that are not whole brick layers, taps on
+    // both sides of the pixel, slab-partitioned passes); its occlusion is not cached
+    ChunkFit fit;
+    if (!chunk_fit(r, pa, pr, fit, mode)) {
+        if (!slab || two_stream_mode == PASS_ADD2) return TBRM_ERR_UNSUPPORTED;
+        return plan_pass_sliced(r, base, pa, pr, b_added, *slab, plan);
+    }
+    r->kept_computed += mode == PASS_ADD ? 1 : 2;
+    const int W = pa.td[0], H = pa.td[1], D_pass = pa.td[2];
+    plan = PassPlan{};
+    plan.mode = mode;
+    fill_pass_params(r, base, pa, pr, b_added, b_added2, plan);
+    ChunkParams& p = plan.p;
+    p.dx_lo = fit.tx.lo; p.dx_hi = fit.tx.hi; p.dy_lo = fit.ty.lo; p.dy_hi = fit.ty.hi;
+    p.rect_planes = rect_planes_for(r, mode);
+    const int M = fit.M;
+    plan.M = M;
     plan.chunks_of_pass = ceil_div(D_pass, M);
     if (slab) {
         const int nz = r->lv_dims[2];
@@ -647,7 +797,6 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     int S = 128; // measured on MI355X, fused Change at 512^3: S = 32 2.80 ms, 64 2.61, 128 2.53, 256 2.52
     if (tune(TUNE_OCC_SLICES) > 0) S = tune(TUNE_OCC_SLICES);
     S = std::max(M, (S / M) * M);
-    if (sweep) S = M;
 
     const size_t slice_elems = (size_t) W * H;
     while (S > M && ((size_t) S * slice_elems + 2 * kPlaneGuard) * sizeof(float) >= ((size_t) 1 << 32)) S -= M;
@@ -676,14 +825,6 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     for (int b = 0; b < 2; ++b)
         for (int si = 0; si < (plan.two_streams() ? 2 : 1); ++si)
             if (int e = ensure_store(r, &r->occ_tmp[b][si], S, slice_elems, si == 0 ? flag_bytes : 0)) return e;
-    if (sweep) {
-        SweepParams& q = plan.sq;
-        q.sx = sfit.sx; q.sy = sfit.sy; q.hx = sfit.hx; q.hy = sfit.hy;
-        const size_t words = (size_t) std::min(S, D) * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy));
-        if (int e = ensure_sweep(r, std::max<size_t>(words, 1))) return e;
-        // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
-        q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 4;
-    }
     plan.serial = ++r->plan_serial;
     return TBRM_OK;
 }
@@ -701,24 +842,15 @@ static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, in
 {
     hipStream_t s = r->stream;
     if (beside) {
-        if (!r->occ_stream) {
-            int least = 0, greatest = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least));
-            for (int k = 0; k < 2; ++k) {
-                HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], hipEventDisableTiming));
-            }
-        }
+        if (int e = ensure_occ_stream(r)) return e;
         s = r->occ_stream;
         HIP_TRY(hipEventRecord(r->occ_ev_fork[b], r->stream));
         HIP_TRY(hipStreamWaitEvent(s, r->occ_ev_fork[b], 0));
     }
     ChunkParams p = plan.p;
     const SpanRange q = span_range(plan, sp);
-    // the propagated streams' occlusion: one launch per span computes both (a block is flagged empty when it is empty for
-    // both), or the added light alone with the Change shader's rules when the removed light's L is kept
-    const int occ_mode = plan.mode == PASS_CHANGE_CACHED ? PASS_CHANGE_ONE : plan.mode;
+    // the propagated streams' occlusion: one launch per span computes both (a block is flagged empty when it is empty for both)
+    const int occ_mode = plan.mode;
     OccStore* const fs = &r->occ_tmp[plan.serial & 1][0];
     int* const counts = (int*) (fs->list + fs->flag_bytes);
     p.a.occ_next = r->occ_tmp[b][0].base + kPlaneGuard;
@@ -744,30 +876,103 @@ static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, in
     return TBRM_OK;
 }
 
-// The light-volume updates of n (<= kApplyMaxPasses) consecutive plans whose L is all kept, as one launch
-static int enqueue_apply(tbrm_resources* r, const PassPlan* const* plans, int n)
+// The occlusion of a sweep pass (plan_pass_sweep): the whole pass's empty-block flags, work list and block ranks, then one
+// launch that leaves the factors of the live blocks block-compact in the cache entry being filled and / or the scratch
+// buffer — all on the occlusion stream, beside whatever the handle's stream is running (the sweep of the pass before, a
+// frame); the sweep waits for FactorScratch::ev_ready. Nothing to do when both streams' factors come from the cache.
+int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
 {
-    ApplyParams ap{};
-    ap.light = r->d_light;
-    for (int k = 0; k < 3; ++k) ap.lv_dims[k] = r->lv_dims[k];
-    ap.lv_bnx = r->lbn[0]; ap.lv_bnxy = r->lbn[0] * r->lbn[1]; ap.lv_bnz = r->lbn[2];
-    ap.lv_fmt = r->lv_fmt;
-    ap.n_passes = n;
-    for (int i = 0; i < n; ++i) {
-        const PassPlan& plan = *plans[i];
-        ApplyPass& q = ap.pass[i];
-        q.axis = plan.p.axis; q.W = plan.p.W; q.H = plan.p.H;
-        q.start = plan.start; q.dir = plan.dir;
-        q.la = plan.kept_a->base + kPlaneGuard;
-        q.lr = plan.kept_r ? plan.kept_r->base + kPlaneGuard : nullptr;
-        q.b_added = plan.apply_b;
+    if (!plan.sweep || plan.occ_mode < 0 || plan.occ_enqueued) return TBRM_OK;
+    FactorScratch& f = r->f_scratch[plan.f_buf];
+    FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
+    hipStream_t s = r->occ_stream;
+    // the buffers about to be overwritten may still be read by an earlier sweep
+    if (f.used) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
+    if (e && e->read_yet) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
+    ChunkParams p = plan.p;
+    p.occ_flags_out = f.flags;
+    p.occ_list_out = f.list;
+    p.occ_count_out = f.count;
+    p.occ_slot_out = e ? e->slot : f.slot;
+    HIP_TRY(launch_occ_flags(p, plan.occ_mode, 1, s));
+    if (e) { // how many blocks the entry has to hold: known on the device only (resolve_entry)
+        HIP_TRY(hipMemcpyAsync(e->count_host, f.count, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(e->ev_count, s));
     }
-    HIP_TRY(launch_apply_kept(ap, r->stream));
-    ++r->launches[0];
+    p.j0 = plan.start;
+    p.n_steps = plan.D;
+    p.occ_flags = nullptr;
+    p.occ_list = f.list;
+    p.occ_count = f.count;
+    // a grid that is resident beside a sweep's workgroups: occ_overlap workgroups per CU walk the list
+    p.occ_grid_cap = tune(TUNE_OCC_OVERLAP) > 0 ? tune(TUNE_OCC_OVERLAP) * r->n_cus : 0;
+    p.a.fs_keep = e ? e->base : nullptr;
+    p.a.fs_cap = e ? (uint32_t) e->cap_blocks : 0u;
+    p.a.fs_spill = f.store[0];
+    p.r.fs_keep = nullptr;
+    p.r.fs_cap = 0;
+    p.r.fs_spill = f.store[1];
+    HIP_TRY(launch_light_occlusion(p, plan.occ_mode, s));
+    HIP_TRY(hipEventRecord(f.ev_ready, s));
+    if (e) {
+        HIP_TRY(hipEventRecord(e->ev_filled, s));
+        e->enqueued = true;
+    }
+    plan.occ_enqueued = true;
     return TBRM_OK;
 }
 
-static bool plan_has_occlusion(const PassPlan& plan) { return !plan.sliced && !plan.apply && plan.n_chunks > 0; }
+// The sweep of a sweep pass on the handle's stream, behind the occlusion it consumes
+static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
+{
+    if (int e = enqueue_sweep_occlusion(r, plan)) return e;
+    FactorScratch& f = r->f_scratch[plan.f_buf];
+    const int ns = plan.n_streams();
+    if (plan.occ_mode >= 0) HIP_TRY(hipStreamWaitEvent(r->stream, f.ev_ready, 0));
+    for (int si = 0; si < ns; ++si)
+        if (plan.f_hit[si]) HIP_TRY(hipStreamWaitEvent(r->stream, plan.f_entry[si]->ev_filled, 0)); // (it may still be being filled)
+    ChunkParams p = plan.p;
+    p.j0 = plan.start;
+    p.n_steps = plan.D;
+    p.first_chunk = 1;
+    p.occ_phase = 0;
+    p.a.plane_in = plan_plane(r, 0, 0); p.a.plane_out = plan_plane(r, 1, 0);
+    p.r.plane_in = plan_plane(r, 0, 1); p.r.plane_out = plan_plane(r, 1, 1);
+    p.ones = r->d_ones;
+    ChunkStream* const streams[2] = {&p.a, &p.r};
+    for (int si = 0; si < ns; ++si) {
+        FactorEntry* const e = plan.f_entry[si];
+        ChunkStream& st = *streams[si];
+        if (plan.f_hit[si]) { // every live block is in the entry
+            st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->slot;
+        } else { // computed by this pass: stream a into its entry (if it has one) and the scratch, stream r into the scratch,
+                 // both under the ranks of the jointly computed work list
+            FactorEntry* const filled = plan.f_entry[0];
+            st.fs_keep = (si == 0 && filled) ? filled->base : nullptr;
+            st.fs_cap = (si == 0 && filled) ? (uint32_t) filled->cap_blocks : 0u;
+            st.fs_spill = f.store[si];
+            st.fs_slot = filled ? filled->slot : f.slot;
+        }
+    }
+    SweepParams q = plan.sq;
+    q.rec[0] = r->sweep_rec[0];
+    q.rec[1] = r->sweep_rec[1];
+    q.ticket = r->sweep_ticket;
+    q.error = r->sweep_error;
+    if (int e = next_sweep_epoch(r, q.epoch)) return e;
+    HIP_TRY(launch_light_sweep(p, q, plan.mode, r->stream));
+    ++r->launches[0];
+    HIP_TRY(hipEventRecord(f.ev_idle, r->stream));
+    f.used = true;
+    for (int si = 0; si < ns; ++si)
+        if (FactorEntry* const e = plan.f_entry[si]) {
+            HIP_TRY(hipEventRecord(e->ev_idle, r->stream));
+            e->read_yet = true;
+        }
+    return TBRM_OK;
+}
+
+static bool plan_has_occlusion(const PassPlan& plan) { return !plan.sliced && !plan.sweep && plan.n_chunks > 0; }
 
 static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next);
 
@@ -812,10 +1017,7 @@ static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int 
         ++r->launches[1];
         return TBRM_OK;
     }
-    if (plan.apply) { // every L of the pass is at hand: the light-volume update alone
-        const PassPlan* one[1] = {&plan};
-        return enqueue_apply(r, one, 1);
-    }
+    if (plan.sweep) return enqueue_sweep(r, plan);
     ChunkParams p = plan.p;
     const int M = plan.M, D = plan.D, W = p.W, H = p.H;
     const int sp = (c * M) / plan.S;
@@ -838,7 +1040,7 @@ static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int 
         // the span after this one — beside a chain that propagates one stream: the LDS of a two-stream chain leaves an
         // occlusion workgroup no room on its CU — and one tile per CU at most: with several rounds of tiles the chain's own
         // workgroups are what fills a CU's spare slots (1024^3: 16.2 ms per Change one after the other, 17.1 beside)
-        if (tune(TUNE_OCC_OVERLAP) > 0 && (ns == 1 || plan.sweep) && p.tiles_x * p.tiles_y <= r->n_cus) {
+        if (tune(TUNE_OCC_OVERLAP) > 0 && ns == 1 && p.tiles_x * p.tiles_y <= r->n_cus) {
             const PassPlan* np = sp + 1 < plan.n_spans ? &plan : (next && plan_has_occlusion(*next) ? next : nullptr);
             if (np) {
                 // only when the requested occlusion workgroups per CU all fit beside this plan's chain workgroup: every one of
@@ -848,10 +1050,10 @@ static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int 
                 ChunkParams full = plan.p;
                 full.n_steps = M;
                 full.j0 = plan.start;
-                const size_t chain_lds = plan.sweep ? sweep_lds_bytes(plan.mode) : chunk_lds_bytes(full, plan.mode, r->lv_fmt);
-                const size_t occ_lds = occlusion_lds_bytes(np->p) + 2560;
+                const size_t chain_lds = chunk_lds_bytes(full, plan.mode, r->lv_fmt), occ_lds = occlusion_lds_bytes(np->p) + 2560;
                 const int room = chain_lds < 160 * 1024 ? (int) ((160 * 1024 - chain_lds) / occ_lds) : 0;
-                const int wgs = room >= tune(TUNE_OCC_OVERLAP) ? tune(TUNE_OCC_OVERLAP) : 0;
+                const int want = std::min(tune(TUNE_OCC_OVERLAP), 2); // (two per CU beside a chain: measured)
+                const int wgs = room >= want ? want : 0;
                 if (wgs > 0)
                     if (int e = enqueue_occlusion(r, *np, np == &plan ? sp + 1 : 0, ob ^ 1, true, wgs)) return e;
             }
@@ -870,35 +1072,13 @@ static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int 
         streams[si]->occ_base = r->occ_tmp[ob][si].base;
         streams[si]->occ_off = (uint32_t) (kPlaneGuard + (size_t) k0 * slice_elems);
         streams[si]->occ_flags = chunk_flags;
-        // the contribution cache keeps L in pass order: plane k of an entry is the pass's k-th slice
-        streams[si]->l_out = plan.keep[si] ? plan.keep[si]->base + kPlaneGuard + (size_t) c * M * slice_elems : nullptr;
-        streams[si]->l_dump = plan.keep[si] ? plan.keep[si]->base : nullptr;
-    }
-    if (plan.mode == PASS_CHANGE_CACHED) { // the removed light's L is staged like a second plane of occlusion factors (no flags)
-        p.r.occ_base = plan.kept_r->base;
-        p.r.occ_off = (uint32_t) (kPlaneGuard + (size_t) c * M * slice_elems);
-        p.r.occ_flags = nullptr;
-        p.r.l_out = nullptr;
     }
     p.occ_phase = k0 % kOccSlices;
     p.occ_list = nullptr;
     p.occ_count = nullptr;
     p.occ_flags = nullptr;
-    if (plan.sweep) {
-        SweepParams q = plan.sq;
-        q.rec[0] = r->sweep_rec[0];
-        q.rec[1] = r->sweep_rec[1];
-        q.ticket = r->sweep_ticket;
-        q.error = r->sweep_error;
-        if (int e = next_sweep_epoch(r, q.epoch)) return e;
-        HIP_TRY(launch_light_sweep(p, q, plan.mode, plan.sweep_rows, r->stream));
-    } else {
-        HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
-    }
+    HIP_TRY(launch_light_chain(p, plan.mode, r->lv_fmt, r->stream));
     ++r->launches[0];
-    if (c == plan.n_chunks - 1) // an entry is complete once the last chunk that fills it is on the stream
-        for (int si = 0; si < ns; ++si)
-            if (plan.keep[si]) plan.keep[si]->valid = true;
     return TBRM_OK;
 }
 
@@ -987,15 +1167,12 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             if (int e = enqueue_pass_sliced(r, p, q.a, q.two ? &q.r : nullptr)) return e;
             continue;
         }
-        if (plans[i].apply) { // a run of passes that only update the light volume: one launch
-            const PassPlan* run[kApplyMaxPasses];
-            int n = 0;
-            while (i + n < specs.size() && n < kApplyMaxPasses && chunked[i + n] && plans[i + n].apply) { run[n] = &plans[i + n]; ++n; }
-            if (int e = enqueue_apply(r, run, n)) return e;
-            i += (size_t) n - 1;
-            continue;
-        }
         const PassPlan* next = i + 1 < specs.size() && chunked[i + 1] ? &plans[i + 1] : nullptr;
+        // sweep passes: this pass's occlusion, and the next pass's behind it on the occlusion stream, so that it runs beside
+        // this pass's sweep
+        if (int e = enqueue_sweep_occlusion(r, plans[i])) { quiesce_occ_stream(r); return e; }
+        if (next)
+            if (int e = enqueue_sweep_occlusion(r, *next)) { quiesce_occ_stream(r); return e; }
         for (int c = 0; c < plans[i].n_chunks; ++c)
             if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e; // (enqueue_plan_chunk has drained the second stream)
     }
@@ -1061,8 +1238,11 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         // only pays when the union of the two tap ranges is no wider than the wider of the two — then 0.3 to 0.5 ms per
         // paired pass (lights 1 and 7: 3.61 -> 2.53 ms for both passes); with diverging directions the wider windows and
         // shorter chunks cost up to 0.2 ms more than they save.
-        // A pass whose L is kept is applied without propagation (k_apply_kept), which beats any pairing.
-        auto kept = [&](const tbrm_light_pass& q) { return cache_usable(r) && kept_find(r, kept_key(r, base, q, true)) != nullptr; };
+        // A pass that the pipelined sweep takes is not paired: a sweep of its own costs less than its half of a paired chain.
+        auto kept = [&](const tbrm_light_pass& q) {
+            SweepFit sf;
+            return sweep_fit(r, q, nullptr, PASS_ADD, sf) && q.td[2] <= sweep_max_slices() && tune(TUNE_SPARSE_OCC) != 0 && tune(TUNE_OCC_LIST) != 0;
+        };
         Entry* partner = nullptr;
         ChunkFit fa;
         if (pairing && !kept(a.p) && chunk_fit(r, a.p, nullptr, fa)) {

@@ -40,28 +40,59 @@ struct OccStore {
     size_t flag_bytes = 0;
 };
 
-// The contribution cache: what ONE light adds to every voxel of the light volume in ONE of its axis passes — L, the
-// propagated value before it is quantised into the read/write buffers — kept as [guard][pass slices x H x W floats][guard]
-// under a key that holds everything L depends on (volume / transfer-function generation, window, clip plane, the pass's
-// axis, direction, offsets, step size, initial and border light, and which shader's rules produced it). What an axis pass
-// does to the light volume is a function of L alone, so a later pass over the same light needs no propagation: a removal
-// or a re-add applies the kept L (k_apply_kept), and a ChangeDirLight propagates only the NEW light and reads the old
-// one's L (PASS_CHANGE_CACHED). This is the Sunden / Ropinski selective update taken one step further than the reference
-// takes it: the reference recomputes the removed light; here a light is propagated once.
-struct KeptKey {
+// The factor cache. The expensive half of an axis pass is its occlusion: the factors 1 - CurrentSample
+// (AddDirLightShader.usf:85-117) of every voxel, which depend on the data volume, the transfer function, the window, the clip
+// plane and the light's sampling offsets — not on the light volume and not on the light's intensity. A pass that propagates a
+// light which stays in the scene keeps its factors, in the block-compact form the sweep kernel consumes
+// (tbrm_internal.h ChunkStream::fs_*): only the 16 x 16 x 8 blocks that can be opaque at all are stored, 8 KiB each, behind
+// the table of their ranks. Later operators on that light skip its occlusion: the removed side of a ChangeDirLight, a removal,
+// a re-add after ClearResourceLightVolumes propagate from the kept factors (the propagation itself is cheap: one sweep).
+// This is the Sunden / Ropinski selective update taken one step further than the reference takes it — the reference samples
+// the volume again for the removed light; here a light's samples are taken once.
+//
+// An entry is allocated before its pass runs, for an estimated number of live blocks (the count is computed on the device);
+// blocks beyond the capacity go to the handle's scratch store, and an entry that overflowed is dropped when the host learns
+// the count (a tiny read-back, waited for only when the entry is looked up).
+struct FactorKey {
     uint64_t data_gen, tf_gen;
     float win[4];
     float cc[3], cd[3], data_border;
     int32_t clip_mode, axis, dir, start, D, W, H, guard;
-    float uvw_off[3], step100, prev_off[2], light_alpha, border_light;
+    float uvw_off[3], step100;
 };
-struct KeptPass {
-    float* base = nullptr;
-    KeptKey key{};
-    bool valid = false;             // every chunk of the pass that fills it has been enqueued
+struct FactorEntry {
+    float* base = nullptr;          // cap_blocks x 2048 floats
+    size_t cap_blocks = 0;
+    int32_t* slot = nullptr;        // rank of every block of the pass (device), table_blocks entries
+    size_t table_blocks = 0;
+    int* count_host = nullptr;      // pinned: live blocks of the pass, written by a copy behind k_occ_compact
+    hipEvent_t ev_count = nullptr;  // ... which this event follows (occlusion stream)
+    hipEvent_t ev_filled = nullptr; // the occlusion that fills the entry is done (occlusion stream)
+    hipEvent_t ev_idle = nullptr;   // the last sweep that reads the entry is done (the handle's stream)
+    bool read_yet = false;          // (ev_idle has been recorded)
+    FactorKey key{};
+    bool enqueued = false;          // the occlusion that fills it is on the occlusion stream
+    bool resolved = false;          // the count has been read: valid / dropped
+    bool valid = false;
     bool pinned = false;            // in use by the operator being planned
-    bool spent = false;             // served as the removed side of a ChangeDirLight: its light has left the scene
+    bool spent = false;             // its light has left the scene: first in line for reuse
     uint64_t last_use = 0;
+    size_t bytes() const { return cap_blocks * 2048 * sizeof(float) + table_blocks * sizeof(int32_t); }
+};
+
+// Scratch of the block-compact hand-over: per buffer (axis passes alternate between two) the factor stores of the two streams
+// and the pass's block metadata (flags, work list, ranks, count)
+struct FactorScratch {
+    float* store[2] = {nullptr, nullptr};
+    size_t store_blocks = 0;
+    uint8_t* flags = nullptr;
+    uint32_t* list = nullptr;
+    int32_t* slot = nullptr;
+    int* count = nullptr;
+    size_t meta_blocks = 0;
+    hipEvent_t ev_ready = nullptr;  // the occlusion into this buffer is done (occlusion stream)
+    hipEvent_t ev_idle = nullptr;   // the sweep that read this buffer is done (the handle's stream)
+    bool used = false;              // (ev_idle has been recorded)
 };
 
 struct tbrm_resources {
@@ -115,10 +146,15 @@ struct tbrm_resources {
     int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
     int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
     uint32_t sweep_epoch = 0;      // tag of the last sweep launch
-    std::vector<KeptPass*> kept;   // the contribution cache (every entry nx*ny*nz floats: an axis pass covers the light volume once)
+    std::vector<FactorEntry*> kept; // the factor cache
     uint64_t kept_clock = 0;       // its LRU clock
-    int kept_auto_entries = -1;    // light_cache_mb < 0: entries this handle may hold (-1: not asked yet)
-    uint64_t kept_hits = 0, kept_computed = 0; // stream-passes served from the cache / propagated (tbrm_light_cache_stats)
+    uint64_t kept_hits = 0, kept_computed = 0; // stream-passes whose occlusion came from the cache / was computed (tbrm_light_cache_stats)
+    size_t f_est_blocks = 0;       // live blocks per pass seen under f_est_key (what a new entry is sized for)
+    uint64_t f_est_key[2] = {0, 0};
+    float f_est_win[4] = {0, 0, 0, 0};
+    FactorScratch f_scratch[2];
+    int f_buf = 0;                 // buffer of the most recent sweep pass
+    float* d_ones = nullptr;       // 1024 floats of 1.0
     uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
 
     // empty-space-skipping metadata
@@ -190,13 +226,13 @@ struct PassPlan {
     bool pass_begins_here = true; // chunk 0 starts from the cleared buffers' value (else from imported planes)
     bool sparse = false, work_list = false;
     size_t flags_per_group = 0, flags_per_span = 0;
-    // contribution cache: apply = the pass is one k_apply_kept launch over kept L (no chunks); keep[si] = where the chain
-    // stores stream si's L (null: not kept); kept_r = PASS_CHANGE_CACHED: the removed light's L
-    bool apply = false;
-    KeptPass* keep[2] = {nullptr, nullptr};
-    KeptPass* kept_a = nullptr;
-    KeptPass* kept_r = nullptr;
-    float apply_b = 0.0f;
+    // sweep passes and the factor cache: per stream the entry its factors come from (a hit) or go to (being filled; null:
+    // scratch only), and which streams' occlusion this pass computes (occ_mode: -1 none, else the occlusion kernel's mode)
+    FactorEntry* f_entry[2] = {nullptr, nullptr};
+    bool f_hit[2] = {false, false};
+    int occ_mode = -1;
+    int f_buf = 0;              // scratch buffer of this pass
+    mutable bool occ_enqueued = false;
     // slab-partitioned passes
     bool lateral = false;       // the slices contain the slab axis: every rank runs every chunk on its rows
     int first_chunk_of_pass = 0, chunks_of_pass = 0;
@@ -207,7 +243,6 @@ struct PassPlan {
     // the pass's chunks are spans advanced by the pipelined sweep kernel (one launch per span; sweep_fit)
     bool sweep = false;
     SweepParams sq{};
-    int sweep_rows = 2;
     int halo_rows = 0;          // lateral: rows a slice's taps can reach beyond a slab
 };
 
@@ -217,15 +252,17 @@ int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr);
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
 struct SweepFit { int sx = 0, sy = 0, hx = 0, hy = 0; };
-bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, int rows, SweepFit& fit);
+bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit);
 void release_sweep(tbrm_resources* r);
 int sweep_check(tbrm_resources* r); // after the stream has drained: did a sweep kernel raise its error word?
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next = nullptr); // next: the plan enqueued after this one
+int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan); // a sweep pass's occlusion, ahead of its sweep (else: nothing)
 void quiesce_occ_stream(tbrm_resources* r);  // waits for the occlusion stream and forgets what its buffers hold
-void release_kept(tbrm_resources* r);       // frees the contribution cache (the stream must be idle)
-void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the contribution cache (the stream must be idle)
+void release_kept(tbrm_resources* r);       // frees the factor cache (the streams must be idle)
+void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the factor cache (the streams must be idle)
+size_t kept_bytes(const tbrm_resources* r);
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);
 int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, int n_lights, bool added, const tbrm_world_params& world,
                       int32_t* schedule, int32_t* n_entries);

@@ -141,3 +141,63 @@ def test_config5_skipping_and_tiles_at_2048(gpu):
         del plain
         parts = np.stack([res.raymarch_lit(cam, sharding.rank_tile(fb, fb, r, 8), rp, world) for r in range(8)])
         assert np.array_equal(sharding.assemble(parts, fb, 8), skipped)
+
+
+def _operators_and_frame_against_the_oracle(oracle_mod, config, tile=None, frame_tol=1e-4):
+    """The config's lights added, its first light turned by a fused Change, then the frame (or one tile of it): the light
+    volume against the oracle after every operator (UNORM8 bit for bit, float within 2e-6), RGBA within north_star's 1e-4."""
+    cfg, vol = device_volume(config)
+    n = cfg["n"]
+    world = S.default_world()
+    orc = oracle_mod.OracleScene(vol.cpu().numpy(), cfg["light_32bit"])
+    orc.set_tf_lut(abi.color_curve_to_lut(S.tf_keys(cfg["tf"])))
+    orc.set_windowing(abi.WindowingParams(*cfg["window"]))
+    first = cfg["lights"][0]
+    turned = abi.DirLightParams(S.rotate_z(S.LIGHTS[first][0], 5.0), S.LIGHTS[first][1])
+    pa, _ = abi.host_light_passes(S.light(first), world, (n, n, n))
+    pb, _ = abi.host_light_passes(turned, world, (n, n, n))
+    assert (pa[0].face, pa[1].face) == (pb[0].face, pb[1].face), "meant to be a fused Change"
+
+    def check(what, res):
+        got = res.download_light_volume()
+        if got.dtype == np.uint8:
+            assert np.array_equal(got, orc.light), f"{what}: {np.count_nonzero(got != orc.light)} of {got.size} UNORM8 light voxels differ"
+        else:
+            assert np.abs(got - orc.light).max() <= 2e-6, f"{what}: float light volume off by {np.abs(got - orc.light).max()}"
+
+    with handle_for(cfg, vol) as res:
+        res.clear_light_volume(0.0)
+        for i in cfg["lights"]:
+            res.add_dir_light(S.light(i), True, world)
+            orc.add_dir_light(S.light(i), True, world)
+        check("after the adds", res)
+        res.change_dir_light(S.light(first), turned, world)
+        orc.change_dir_light(S.light(first), turned, world)
+        check("after the fused change", res)
+        fb = cfg["fb"]
+        cam = S.default_camera(fb, fb)
+        tile = tile or abi.Tile(0, 0, fb, fb, 1)
+        rp = abi.RaymarchParams(float(cfg["steps"]), -1, True)
+        frame = res.raymarch_lit(cam, tile, rp, world)
+        ref, n_ref = orc.raymarch_lit(cam, tile, rp, world)
+        assert res.count_nominal_samples(cam, tile, rp, world) == n_ref
+        assert (ref[..., 3] > 0.5).any(), "the tile is meant to see the volume"
+        err = float(np.abs(frame - ref).max())
+        assert err <= frame_tol, err
+
+
+def test_config1_in_full_against_the_oracle(gpu, oracle_mod):
+    """BASELINE config 1 (the reference's own CPU-runnable case): 128^3 f32 data, f32 light volume, 256^2, 128 steps, 1 light."""
+    _operators_and_frame_against_the_oracle(oracle_mod, 1)
+
+
+def test_config2_in_full_against_the_oracle(gpu, oracle_mod):
+    """BASELINE config 2: 256^3 UNORM16 data, UNORM8 light volume, 512^2, 256 steps, 1 light."""
+    _operators_and_frame_against_the_oracle(oracle_mod, 2)
+
+
+def test_config5_light_volume_and_a_sixteenth_of_the_frame_against_the_oracle(gpu, oracle_mod):
+    """BASELINE config 5: 512^3, 8 lights, TF-B with both cutoffs: the 8-light volume bit for bit, and every 16th 8-row group
+    of the 2048^2 frame (128 rows x 2048 pixels, the share of rank 0 of 16) within 1e-4 of the oracle's."""
+    fb = S.CONFIGS[5]["fb"]
+    _operators_and_frame_against_the_oracle(oracle_mod, 5, tile=sharding.rank_tile(fb, fb, 0, 16))
