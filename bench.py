@@ -396,18 +396,56 @@ def main():
         res.flush()
         full_tile = abi.Tile(0, 0, fb_w, fb_h, 1)
         full = torch.empty((fb_h, fb_w, 4), dtype=torch.float32, device=device)
-        # ResetAllLights with everything allocated (clear + every light added), and the "recompute every frame" case of
-        # APerformanceTest1 (PerformanceTest1.cpp:64-74): reset + frame
-        ops_ms["reset_all_lights"] = min(gpu_ms(torch, lib_stream, reset_all_lights) for _ in range(2))
-        ops_ms["reset_all_lights_plus_frame"] = gpu_ms(torch, lib_stream, lambda: (reset_all_lights(), res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())))
+        # SURVEY.md 8d's operators, cold and warm. "Warm" = the factor cache holds the lights' occlusion (nothing samples the
+        # data volume again); "cold" = a window that differs by one ulp has just made everything cached stale — what a moved
+        # clip plane or volume transform (RaymarchVolume.cpp:351-356 -> ResetAllLights), a new window or transfer function
+        # (TransferFuncMenu.cpp:63-78) and APerformanceTest1's window sweep (PerformanceTest1.cpp:75-84) cost; "uncached" =
+        # the same with the cache off (light_cache_mb = 0: nothing is kept either).
+        win_k = [0]
+
+        def stale_window():
+            win_k[0] += 1
+            c = float(np.nextafter(np.float32(cfg["window"][0]), np.float32(2.0)) if win_k[0] % 2 else np.float32(cfg["window"][0]))
+            res.set_windowing(abi.WindowingParams(c, *cfg["window"][1:]))
+
+        def timed(fn, before=None, reps=2):
+            best = None
+            for _ in range(reps):
+                if before is not None:
+                    before()
+                    res.flush()
+                t = gpu_ms(torch, lib_stream, fn)
+                best = t if best is None else min(best, t)
+            return best
+
+        cache_default = abi.get_tunable("light_cache_mb")
+        ops_ms["reset_all_lights_warm"] = timed(reset_all_lights)
+        ops_ms["reset_all_lights_plus_frame_warm"] = timed(lambda: (reset_all_lights(), res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())), reps=1)
+        ops_ms["reset_all_lights_cold"] = timed(reset_all_lights, before=stale_window)
+        # one step of APerformanceTest1's window sweep: new window centre, every light again, the frame
+        ops_ms["window_sweep_step"] = timed(lambda: (stale_window(), reset_all_lights(), res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())))
+        abi.set_tunable("light_cache_mb", 0)
+        ops_ms["reset_all_lights_uncached"] = timed(reset_all_lights)
+        unc = []
+        for li in range(len(lights)):
+            new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li] + 5.0), lights[li].light_intensity)
+            res.change_dir_light(lights[li], new, world)
+            unc.append(res.last_gpu_time_ms(0))
+            res.change_dir_light(new, lights[li], world)
+        ops_ms["change_dir_light_uncached"] = float(np.mean(unc))
+        abi.set_tunable("light_cache_mb", cache_default)
+        res.set_windowing(win)
+        reset_all_lights()
         # ChangeDirLight whose old and new major axes differ: remove + add (LightingShaders.cpp:192-198). A quarter turn about z
-        # moves the first light's major axis from x to y; the second call turns it back.
+        # moves the first light's major axis from x to y (cold: the new direction's occlusion is computed); the second call
+        # turns it back (warm: both directions' factors are at hand).
         turned = abi.DirLightParams(S.rotate_z(light_dirs[0], angle[0] + 90.0), lights[0].light_intensity)
         fb_ms = []
         for old, new in ((lights[0], turned), (turned, lights[0])):
             res.change_dir_light(old, new, world)
             fb_ms.append(res.last_gpu_time_ms(0))
-        ops_ms["change_dir_light_fallback"] = float(np.mean(fb_ms))
+        ops_ms["change_dir_light_fallback_cold"] = fb_ms[0]
+        ops_ms["change_dir_light_fallback_warm"] = fb_ms[1]
         if n_gpus > 1:
             # the same workload on ONE GPU, in the same run (every rank does it, rank 0 reports): the whole frame + the update
             def whole_step(k):
@@ -504,7 +542,7 @@ def main():
                            **{k: round(v, 4) for k, v in ops_ms.items()},
                            first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
-            "light_cache": res.light_cache_stats(),  # contribution cache (include/tbrm.h tbrm_light_cache_stats)
+            "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)
             "scaling_detail": scaling_note,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -152,9 +152,14 @@ struct SweepParams {
     uint32_t* rec[2];       // per stream: the hand-off records, [slice of the launch][tile][32*hx + 32*hy words]
     uint32_t epoch;         // this launch's tag, 1 .. 2^24 - 1 (records are not cleared between launches)
     int prefetch;           // slices ahead of their use that the neighbours' records are requested
+    int stagger_ns;         // a tile d tiles away from the upstream corner starts d * stagger_ns late: the distance it would
+                            // otherwise fall behind by polling (a tile can never make up lag, and every poll that finds nothing
+                            // costs a memory round trip: arriving late on purpose is cheaper than arriving early)
     int* ticket;            // [0]: next tile to start (tiles are dealt in upstream-first order: a tile only ever waits for tiles
                             // that started before it), [1]: tiles finished (the last one re-arms both)
-    int debug;              // diagnostics (sweep_debug tunable): bit 0 = tiles do not wait for each other (WRONG results: slice time alone)
+    int debug;              // diagnostics (sweep_debug tunable): bit 0 = tiles do not wait for each other (WRONG results: slice time alone);
+                            // bit 1 = every tile leaves four time stamps (10 ns units) in `stamps`
+    unsigned long long* stamps; // [tile][4]: start of slice 0, end of slice 63, end of the last slice, after the write-back
     int* error;             // set when a tile gave up waiting (bit 0) or found its taps outside the halo (bit 1)
 };
 
@@ -276,6 +281,7 @@ enum Tunable : int {
     TUNE_LIGHT_SWEEP,        // 0: axis passes never take the pipelined sweep kernel (k_light_sweep); 1: where it applies
     TUNE_SWEEP_ROWS,         // (unused: a sweep lane owns two rows)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
+    TUNE_SWEEP_STAGGER_NS,   // start delay of a sweep tile per tile of distance from the upstream corner, ns (0: default; < 0: none)
     TUNE_SWEEP_DEBUG,        // timing diagnostics of the sweep kernel; non-zero values give WRONG light volumes (SweepParams::debug)
     TUNE_COUNT
 };

@@ -371,63 +371,80 @@ __global__ __launch_bounds__(256) void k_occ_flags(const ChunkParams p, int n_ch
 }
 
 // ---- k_occ_compact: per chunk, the ascending list of workgroups that are NOT flagged -----------------------------
-// One workgroup per chunk; thread t owns a contiguous run of the chunk's flags, a block-wide exclusive scan of the
-// per-thread counts gives every live workgroup its list position (deterministic, ascending).
-__global__ __launch_bounds__(1024) void k_occ_compact(const ChunkParams p)
+// A workgroup takes a segment of 4096 of the chunk's flags (16 per thread, one 16-byte load). It first counts the live
+// flags of every segment before its own — up to 64 KiB of coalesced reads out of the L2, instead of a second kernel or a
+// chain of workgroups waiting for each other — then scans its own: every live workgroup gets its list position
+// (deterministic, ascending) and, if wanted, every block its rank (-1: flagged). Flags are bytes of 0 / 1.
+constexpr int kCompactSeg = 4096;
+__global__ __launch_bounds__(256) void k_occ_compact(const ChunkParams p, int segs)
 {
-    constexpr int NT = 1024;
+    constexpr int NT = 256;
     __shared__ int s_scan[NT];
+    __shared__ int s_base;
     const int per_chunk = p.occ_groups * p.occ_blocks_y * p.occ_blocks_x;
-    const int c = blockIdx.x;
+    const int c = (int) blockIdx.x / segs, seg = (int) blockIdx.x % segs;
     const uint8_t* flags = p.occ_flags_out + (size_t) c * per_chunk;
     uint32_t* list = p.occ_list_out + (size_t) c * per_chunk;
+    int32_t* const slot = p.occ_slot_out ? p.occ_slot_out + (size_t) c * per_chunk : nullptr;
     const int n = min(p.chunk_slices, p.pass_slices - c * p.chunk_slices);
     const int live_groups = (n + kOccDepth - 1) / kOccDepth;       // slice groups past the chunk's last slice have no work
     const int live = live_groups * p.occ_blocks_y * p.occ_blocks_x;
-    // thread t owns `run` consecutive flags, a multiple of 16 so that they are fetched 16 at a time (a whole pass of a 512^3
-    // volume in one span is 64 flags per thread: byte by byte their load latencies added up to 60 us)
-    const int run = (((per_chunk + NT - 1) / NT) + 15) & ~15;
-    const int i0 = min((int) threadIdx.x * run, live), i1 = min(i0 + run, live);
-    const bool wide = (((size_t) flags) & 15) == 0; // (i0 is a multiple of 16)
-    auto for_each_flag = [&](auto&& f) {
-        for (int i = i0; i < i1; i += 16) {
-            uint32_t w[4];
-            if (wide && i + 16 <= per_chunk) {
-                const uint4 v = *(const uint4*) (flags + i);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
+    const bool wide = (((size_t) flags) & 15) == 0;
+    // 16 flags from position i on as four words (bytes past the live part read as flagged)
+    auto load16 = [&](int i, uint32_t (&w)[4]) {
+        if (wide && i + 16 <= live) {
+            const uint4 v = *(const uint4*) (flags + i);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    w[k] = 0;
+            for (int k = 0; k < 4; ++k) {
+                w[k] = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (i + 4 * k + b < per_chunk) w[k] |= (uint32_t) flags[i + 4 * k + b] << (8 * b);
-                }
+                for (int b = 0; b < 4; ++b) w[k] |= (uint32_t) ((i + 4 * k + b < live) ? (flags[i + 4 * k + b] ? 1u : 0u) : 1u) << (8 * b);
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (i + k < i1) f(i + k, ((w[k >> 2] >> (8 * (k & 3))) & 255u) != 0);
         }
     };
-    int mine = 0;
-    for_each_flag([&](int, bool flagged) { mine += flagged ? 0 : 1; });
+    auto live_of = [](const uint32_t (&w)[4]) { return 16 - (__builtin_popcount(w[0] & 0x01010101u) + __builtin_popcount(w[1] & 0x01010101u) + __builtin_popcount(w[2] & 0x01010101u) + __builtin_popcount(w[3] & 0x01010101u)); };
+    // live flags before this segment
+    int before = 0;
+    for (int i = (int) threadIdx.x * 16; i < seg * kCompactSeg; i += NT * 16) {
+        uint32_t w[4];
+        load16(i, w);
+        before += live_of(w);
+    }
+    s_scan[threadIdx.x] = before;
+    __syncthreads();
+    for (int d = NT / 2; d > 0; d >>= 1) {
+        if ((int) threadIdx.x < d) s_scan[threadIdx.x] += s_scan[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s_base = s_scan[0];
+    __syncthreads();
+    const int base = s_base;
+    __syncthreads();
+    // this segment
+    const int i0 = seg * kCompactSeg + (int) threadIdx.x * 16;
+    uint32_t w[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+    if (i0 < per_chunk) load16(i0, w);
+    const int mine = i0 < per_chunk ? live_of(w) : 0;
     s_scan[threadIdx.x] = mine;
     __syncthreads();
     for (int d = 1; d < NT; d <<= 1) { // inclusive Hillis-Steele scan
-        const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+        const int v = (int) threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
         __syncthreads();
         s_scan[threadIdx.x] += v;
         __syncthreads();
     }
-    int pos = s_scan[threadIdx.x] - mine;
-    int32_t* const slot = p.occ_slot_out ? p.occ_slot_out + (size_t) c * per_chunk : nullptr;
-    for_each_flag([&](int i, bool flagged) {
+    int pos = base + s_scan[threadIdx.x] - mine;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = i0 + k;
+        if (i >= per_chunk) break;
+        const bool flagged = ((w[k >> 2] >> (8 * (k & 3))) & 1u) != 0;
         if (slot) slot[i] = flagged ? -1 : pos;
         if (!flagged) list[pos++] = (uint32_t) i;
-    });
-    if (slot) // slice groups past the chunk's last slice
-        for (int i = live + (int) threadIdx.x; i < per_chunk; i += NT) slot[i] = -1;
-    if (threadIdx.x == NT - 1) p.occ_count_out[c] = s_scan[NT - 1];
+    }
+    if (seg == segs - 1 && threadIdx.x == NT - 1) p.occ_count_out[c] = base + s_scan[NT - 1];
 }
 
 template <int MODE>
@@ -438,7 +455,10 @@ static hipError_t launch_flags2(const ChunkParams& p, int n_chunks, hipStream_t 
     if (p.axis == 0) hipLaunchKernelGGL((k_occ_flags<MODE, 0>), grid, block, 0, s, p, n_chunks);
     else if (p.axis == 1) hipLaunchKernelGGL((k_occ_flags<MODE, 1>), grid, block, 0, s, p, n_chunks);
     else hipLaunchKernelGGL((k_occ_flags<MODE, 2>), grid, block, 0, s, p, n_chunks);
-    if (p.occ_list_out) hipLaunchKernelGGL(k_occ_compact, dim3(n_chunks), dim3(1024), 0, s, p);
+    if (p.occ_list_out) {
+        const int per_chunk = p.occ_groups * p.occ_blocks_y * p.occ_blocks_x, segs = (per_chunk + kCompactSeg - 1) / kCompactSeg;
+        hipLaunchKernelGGL(k_occ_compact, dim3(n_chunks * segs), dim3(256), 0, s, p, segs);
+    }
     return hipGetLastError();
 }
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s)

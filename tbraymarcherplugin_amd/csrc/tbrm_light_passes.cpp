@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -94,10 +95,32 @@ void release_sweep(tbrm_resources* r)
     r->sweep_ticket = nullptr;
     if (r->sweep_error) (void) hipHostFree(r->sweep_error);
     r->sweep_error = nullptr;
+    (void) hipFree(r->sweep_stamps);
+    r->sweep_stamps = nullptr;
 }
 
 int sweep_check(tbrm_resources* r)
 {
+    if ((tune(TUNE_SWEEP_DEBUG) & 2) && r->sweep_stamps && r->sweep_stamp_tiles > 0) { // diagnostics: the last launch's timeline
+        std::vector<unsigned long long> t((size_t) r->sweep_stamp_tiles * 4);
+        if (hipMemcpy(t.data(), r->sweep_stamps, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            const int tx = r->sweep_stamp_tx, ty = r->sweep_stamp_tiles / tx;
+            unsigned long long t0 = ~0ull;
+            for (int i = 0; i < r->sweep_stamp_tiles; ++i) t0 = std::min(t0, t[4 * i]);
+            fprintf(stderr, "[tbrm sweep stamps] %d x %d tiles, upstream side (%d, %d); per hop distance: tiles, mean us of start / slice 63 / last slice / end\n", tx, ty,
+                    r->sweep_stamp_sx, r->sweep_stamp_sy);
+            std::vector<double> acc((size_t) (tx + ty) * 5, 0.0);
+            for (int j = 0; j < ty; ++j)
+                for (int i = 0; i < tx; ++i) {
+                    const int d = (r->sweep_stamp_sx > 0 ? tx - 1 - i : (r->sweep_stamp_sx < 0 ? i : 0)) + (r->sweep_stamp_sy > 0 ? ty - 1 - j : (r->sweep_stamp_sy < 0 ? j : 0));
+                    acc[5 * d] += 1.0;
+                    for (int k = 0; k < 4; ++k) acc[5 * d + 1 + k] += (double) (t[4 * (j * tx + i) + k] - t0) * 0.01;
+                }
+            for (int d = 0; d < tx + ty; ++d)
+                if (acc[5 * d] > 0) fprintf(stderr, "  hop %2d: %3.0f tiles  %7.2f %7.2f %7.2f %7.2f\n", d, acc[5 * d], acc[5 * d + 1] / acc[5 * d], acc[5 * d + 2] / acc[5 * d], acc[5 * d + 3] / acc[5 * d], acc[5 * d + 4] / acc[5 * d]);
+        }
+        r->sweep_stamp_tiles = 0;
+    }
     if (!r->sweep_error || *r->sweep_error == 0) return TBRM_OK;
     const int e = *r->sweep_error;
     *r->sweep_error = 0;
@@ -708,7 +731,8 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     if (words >= ((size_t) 1 << 32)) return declined("hand-off records too large");
     if (int e = ensure_sweep(r, std::max<size_t>(words, 1))) return e;
     // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
-    q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 2;
+    q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 3;
+    q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : (change ? 3000 : 2000);
     q.debug = tune(TUNE_SWEEP_DEBUG);
     plan.serial = ++r->plan_serial;
     return TBRM_OK;
@@ -960,6 +984,21 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
     q.ticket = r->sweep_ticket;
     q.error = r->sweep_error;
     if (int e = next_sweep_epoch(r, q.epoch)) return e;
+    q.stamps = nullptr;
+    if (q.debug & 2) { // diagnostics: per-tile time stamps of this launch (printed by tbrm_flush)
+        const int tiles = p.tiles_x * p.tiles_y;
+        if (tiles > r->sweep_stamp_tiles || !r->sweep_stamps) {
+            drain_streams(r);
+            (void) hipFree(r->sweep_stamps);
+            r->sweep_stamps = nullptr;
+            HIP_TRY(hipMalloc((void**) &r->sweep_stamps, (size_t) tiles * 4 * sizeof(unsigned long long)));
+        }
+        r->sweep_stamp_tiles = tiles;
+        r->sweep_stamp_tx = p.tiles_x;
+        r->sweep_stamp_sx = q.sx;
+        r->sweep_stamp_sy = q.sy;
+        q.stamps = r->sweep_stamps;
+    }
     HIP_TRY(launch_light_sweep(p, q, plan.mode, r->stream));
     ++r->launches[0];
     HIP_TRY(hipEventRecord(f.ev_idle, r->stream));

@@ -42,6 +42,12 @@
 #include <type_traits>
 #include <utility>
 
+// Timing ablations of the slice loop (tools/sweep_ablation.sh builds one library per value; results are WRONG, only the
+// sweep_debug = 1 timings mean anything): 1 no light-volume update, 2 no factor loads, 4 idle hand-off wave, 8 no barrier.
+#ifndef TBRM_SWEEP_EXP
+#define TBRM_SWEEP_EXP 0
+#endif
+
 namespace tbrm {
 
 constexpr int kSweepTile = 32;
@@ -200,6 +206,14 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
     const int RW = T * (hx + hy);
     const uint32_t rec_slice = (uint32_t) (n_tiles * RW); // words per slice
     __syncthreads(); // planes, flags and the first brick layer are in LDS
+    // Staggered start (SweepParams::stagger_ns): the tile's lag behind its upstream neighbours, taken up front
+    if (q.stagger_ns > 0 && !(q.debug & 1)) {
+        const int hops = (q.sx != 0 ? ui : 0) + (q.sy != 0 ? uj : 0);
+        const unsigned long long until = wall_clock64() + (unsigned long long) hops * (unsigned long long) q.stagger_ns / 10ull; // (100 MHz)
+        while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+    const bool stamping = (q.debug & 2) != 0 && q.stamps != nullptr && threadIdx.x == 0;
+    if (stamping) q.stamps[4 * tile_lin + 0] = wall_clock64();
 
     if (wave == NWC) {
         // =================================================== the hand-off wave ===================================================
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                 constexpr int K8 = decltype(kc)::value, CUR = K8 & 1;
                 const int s = g * 8 + K8;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
-                if (s > 0) {
+                if ((TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
 #pragma unroll
                     for (int si = 0; si < NS; ++si) {
                         uint32_t* const rec = (uint32_t*) q.rec[si] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RW));
@@ -284,8 +298,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                             if (hal_on[h]) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8(w & 255u);
                         }
                 }
-                if constexpr (!LAST || K8 + PF <= 6) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
-                lds_barrier();
+                if constexpr ((!LAST || K8 + PF <= 6) && !(TBRM_SWEEP_EXP & 4)) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
+                if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
             }, std::make_integer_sequence<int, 8>{});
         };
         for (int g = 0; g < G - 1; ++g) group(g, std::false_type{});
@@ -384,7 +398,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
             for (int si = 0; si < NS; ++si)
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    freg[SLOT][si][k] = *f_ptr[si][k];
+                    if constexpr (TBRM_SWEEP_EXP & 2) freg[SLOT][si][k] = 1.0f;
+                    else freg[SLOT][si][k] = *f_ptr[si][k];
                     f_ptr[si][k] += in_pl[k] ? f_step[si] : 0u;
                 }
         };
@@ -442,7 +457,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     t00[si].x = pa[0]; t01[si].x = pa[1]; t10[si].x = pa[RS]; t11[si].x = pa[RS + 1];
                     t00[si].y = pb[0]; t01[si].y = pb[1]; t10[si].y = pb[RS]; t11[si].y = pb[RS + 1];
                 }
-                if (K8 > 0 || g > 0) light_volume_update(code_old);
+                if constexpr (!(TBRM_SWEEP_EXP & 1))
+                    if (K8 > 0 || g > 0) light_volume_update(code_old);
                 // this slice
                 v2f pval[NS];
 #pragma unroll
@@ -466,13 +482,17 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                         if (in_pl[1]) stream(si).plane_out[own_idx[1]] = pval[si].y;
                     }
                 }
-                lds_barrier();
+                if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
             }, std::make_integer_sequence<int, 8>{});
         };
         __builtin_amdgcn_s_setprio(2); // (ahead of any occlusion workgroup that shares the CU: this loop is one dependent chain)
-        for (int g = 0; g < G - 1; ++g) group(g, std::false_type{});
+        for (int g = 0; g < G - 1; ++g) {
+            group(g, std::false_type{});
+            if (g == 7 && stamping) q.stamps[4 * tile_lin + 1] = wall_clock64();
+        }
         group(G - 1, std::true_type{});
         __builtin_amdgcn_s_setprio(0);
+        if (stamping) q.stamps[4 * tile_lin + 2] = wall_clock64();
         { // the last slice's voxels, then the last two layers
             uint32_t code_old[R];
 #pragma unroll
@@ -483,6 +503,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
 
     __syncthreads(); // the last slice's voxels are in the layer buffers
     if (wave < NWC) write_back_layer(G - 1);
+    if (stamping) q.stamps[4 * tile_lin + 3] = wall_clock64();
 
     // ---- the last tile to finish re-arms the tickets for the next launch -----------------------------------------------------
     if (threadIdx.x == 0) {
@@ -506,6 +527,10 @@ template <int MODE, int AXIS, int PF>
 static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     const int hc = sweep_halo_chunks(q.hx, q.hy);
+#if TBRM_SWEEP_EXP
+    if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3>(p, q, s);
+    return hipErrorInvalidConfiguration;
+#endif
     if (hc <= 2) return launch_sweep5<MODE, AXIS, PF, 2>(p, q, s);
     if (hc <= 3) return launch_sweep5<MODE, AXIS, PF, 3>(p, q, s);
     if (hc <= 6) return launch_sweep5<MODE, AXIS, 3, 6>(p, q, s); // (six words per lane and stream: a ring of three slices is what fits the registers)

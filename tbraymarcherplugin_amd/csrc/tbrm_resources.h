@@ -146,6 +146,8 @@ struct tbrm_resources {
     int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
     int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
     uint32_t sweep_epoch = 0;      // tag of the last sweep launch
+    unsigned long long* sweep_stamps = nullptr; // diagnostics (sweep_debug & 2): the last launch's per-tile time stamps
+    int sweep_stamp_tiles = 0, sweep_stamp_tx = 0, sweep_stamp_sx = 0, sweep_stamp_sy = 0;
     std::vector<FactorEntry*> kept; // the factor cache
     uint64_t kept_clock = 0;       // its LRU clock
     uint64_t kept_hits = 0, kept_computed = 0; // stream-passes whose occlusion came from the cache / was computed (tbrm_light_cache_stats)

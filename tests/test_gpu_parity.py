@@ -45,10 +45,12 @@ def assert_light_equal(res, orc):
         np.testing.assert_allclose(got, orc.light, rtol=0, atol=TIGHT_TOL)
 
 
-@pytest.fixture(params=["chunk", "slice"])
+@pytest.fixture(params=["sweep", "chunk", "slice"])
 def kernel_variant(request, tunables):
-    """Runs a test with the production chunk kernel and with the one-slice-per-launch kernel."""
+    """Runs a test with the production kernels (the pipelined sweep wherever it applies: UNORM8 light volumes, passes of whole
+    brick layers; else the chunked chain), with the chunked chain alone, and with the one-slice-per-launch kernel."""
     tunables("force_slice_kernel", 1 if request.param == "slice" else 0)
+    tunables("light_sweep", 1 if request.param == "sweep" else 0)
     return request.param
 
 
@@ -80,7 +82,7 @@ def test_add_dir_light_all_faces(gpu, oracle_mod, dtype, light_32bit, kernel_var
         orc.add_dir_light(light, False, world)
         assert_light_equal(res, orc)
         counters = res.launch_counters()
-        if kernel_variant == "chunk":  # every one of these passes is within the chunk kernel's envelope
+        if kernel_variant != "slice":  # every one of these passes is within the chunk kernels' envelope
             assert counters["chunk"] > 0 and counters["slice"] == 0, counters
         else:
             assert counters["chunk"] == 0 and counters["slice"] > 0, counters
@@ -447,7 +449,7 @@ def test_steep_secondary_passes(gpu, oracle_mod, kernel_variant):
         orc.change_dir_light(old, new, world)
         assert_light_equal(res, orc)
         counters = res.launch_counters()
-        if kernel_variant == "chunk":
+        if kernel_variant != "slice":
             assert counters["chunk"] > 0, counters
 
 
@@ -470,9 +472,10 @@ def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, 
         sched = res.add_dir_lights(lights, True, world)
         n_passes = sum(2 if b >= 0 else 1 for _, _, b, _ in sched)
         assert n_passes == sum(abi.host_light_passes(l, world, res.light_dims)[1] for l in lights)
-        if kernel_variant == "chunk":
+        sweeps = kernel_variant == "sweep" and not light_32bit  # (these dimensions are whole brick layers)
+        if kernel_variant != "slice" and not sweeps:
             assert sum(b >= 0 for _, _, b, _ in sched) >= 2, f"fewer than two pairs: {sched}"
-        else:  # the slice-per-launch kernel has no two-light form
+        else:  # the slice-per-launch kernel has no two-light form, and a pass that sweeps is not worth pairing
             assert all(b < 0 for _, _, b, _ in sched)
         for la, pa, lb, pb in sched:
             assert orc.add_dir_light_pass(lights[la], True, world, pa) == 1
