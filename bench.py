@@ -36,6 +36,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+# the CPU oracle's OpenMP threads stay on their cores (cpu_baseline: the driver's run and a builder's run of the unpinned
+# oracle differed 4x); set before anything loads libgomp
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 
 def framebuffer_for(n_gpus, base):
@@ -479,14 +483,14 @@ def main():
     if ray_ms >= illum_ms:
         dom = dict(kernel="k_raymarch_lit", achieved=ray_bytes / (ray_ms * 1e-3) / 1e9, launch_ms=ray_ms, alg_bytes=ray_bytes)
     else:
-        dom = dict(kernel="k_light_occlusion+k_light_chain (one ChangeDirLight = 2 axis passes)",
+        dom = dict(kernel="k_light_occlusion+k_light_sweep (one ChangeDirLight = 2 axis passes)",
                    achieved=illum_bytes / (illum_ms * 1e-3) / 1e9, launch_ms=illum_ms, alg_bytes=illum_bytes)
     # HBM traffic from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
     # summarised by tools/pmc_traffic.py into profiles/): per launch of the raymarch kernel, or summed over the launches
     # one ChangeDirLight makes (tools/pmc_traffic.py "_per_operator_call")
     traffic = None
     traffic_source = None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if os.path.exists(pmc_path) and args.config == 3 and n_gpus == 1:
         try:
             with open(pmc_path) as f:
@@ -494,10 +498,24 @@ def main():
             per_call = pmc["_per_operator_call"]
             traffic = per_call["raymarch_hbm_bytes"] if dom["kernel"].startswith("k_raymarch") else per_call["change_dir_light_hbm_bytes"]
             traffic = int(traffic)
-            traffic_source = ("profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+            traffic_source = ("profiles/r03_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                               "(tools/measure_round.sh), NOT measured in this run")
         except Exception:
             traffic = None
+    # why the fraction is what it is: the instruction-issue view of the hot kernels (tools/issue_roofline.py over two more
+    # --pmc passes of this command; committed numbers, like the traffic)
+    issue = None
+    issue_path = os.path.join(ROOT, "profiles", "r03_issue.json")
+    if os.path.exists(issue_path) and args.config == 3 and n_gpus == 1:
+        try:
+            with open(issue_path) as f:
+                raw = json.load(f)
+            issue = {k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in raw.items()}
+            issue["source"] = ("profiles/r03_issue.json: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / "
+                               "SQ_ACTIVE_INST_LDS / GRBM_GUI_ACTIVE passes of this command (tools/measure_round.sh), NOT measured in this run; "
+                               "valu_issue_frac = SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)")
+        except Exception:
+            issue = None
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4)}
@@ -545,6 +563,7 @@ def main():
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)
             "scaling_detail": scaling_note,
             "roofline": roofline,
+            "roofline_issue": issue,
             "cpu_baseline": cpu,
             "full_size_parity": parity,
         }
@@ -746,11 +765,32 @@ def cpu_baseline(args, cfg, res, vol_dev, lut, win, world, cam, rp, fb_w, fb_h, 
         parity.update({"light_volume": f"UNORM8 light volume ({gpu_light.size} voxels) after one ChangeDirLight, GPU against oracle",
                        "light_voxels_differ": differ, "light_ok": differ == 0})
     res.change_dir_light(light_new, light_old, world)
+    # BASELINE.md 2 asks for the single-threaded figure too: the same probe rows and a ChangeDirLight of a 128^3 block of the
+    # volume on ONE thread (the operator's cost is per voxel: scaled by the voxel count)
+    lib = oracle.load()
+    lib.orc_set_num_threads(1)
+    t0 = time.perf_counter()
+    _, n_1t = orc.raymarch_lit(cam, probe, rp, world)
+    ray_1t = n_1t / max(time.perf_counter() - t0, 1e-6)
+    m = min(128, vol.shape[0])
+    o = (vol.shape[0] - m) // 4  # (a block that is part air, part object, like the volume)
+    small = oracle.OracleScene(np.ascontiguousarray(vol[o:o + m, o:o + m, o:o + m]), cfg["light_32bit"])
+    small.set_tf_lut(lut)
+    small.set_windowing(win)
+    t0 = time.perf_counter()
+    small.change_dir_light(light_old, light_new, world)
+    change_1t = (time.perf_counter() - t0) * (vol.size / float(m ** 3))
+    lib.orc_set_num_threads(int(cores))
+    single = {"cores": 1, "raymarch_msamples_per_s": round(ray_1t / 1e6, 3), "change_dir_light_s": round(change_1t, 2),
+              "value": round(n_full / (n_full / ray_1t + change_1t) / 1e6, 4),
+              "sample": f"one thread: the oracle's raymarch of 16 rows of the frame ({n_1t} nominal samples) and a ChangeDirLight of a {m}^3 "
+                        f"block of the volume, scaled to the whole volume"}
     cpu = {"value": round(n_full / (frame_s + change_s) / 1e6, 3), "unit": "Msamples/s", "cores": int(cores), "kind": "port", "build": build,
            "sample": f"one step of the oracle, OpenMP x{cores}: ChangeDirLight over the whole light volume ({change_s:.2f} s) + lit "
                      f"raymarch of every {g}-th 8-row group of the same {fb_w}x{fb_h} frame ({n_s} nominal samples in {dt:.2f} s, "
                      f"i.e. {frame_s:.2f} s per frame); light volume taken from the GPU",
-           "raymarch_only_msamples_per_s": round(ray_rate / 1e6, 3), "change_dir_light_s": round(change_s, 3)}
+           "raymarch_only_msamples_per_s": round(ray_rate / 1e6, 3), "change_dir_light_s": round(change_s, 3), "single_thread": single,
+           "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES", "OMP_NUM_THREADS")}}
     return cpu, parity
 
 

@@ -173,9 +173,13 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
 /* Process-wide tunables: A/B switches for measurements and parity tests (no counterpart in the reference; nothing a
  * host needs to call). Each starts from the environment variable TBRM_<NAME IN CAPITALS>, read once when the library is
  * loaded; no operator reads the environment. Names (default): force_slice_kernel (0), chunk_steps (0 = by fit),
- * occ_slices (0 = 128), sparse_occ (1), occ_list (1), light_cache_mb (-1 = while half of the device's memory stays free; 0 = off), light_batching (1; 0 never, 2 always), share_grid (1),
- * ray_lanes (0 = by load; 4 / 8), chain_fast_loop (1), chain_rect_planes (1), occ_overlap (2 = workgroups per CU of an occlusion launch that runs
- * beside the previous span's propagation; 0 = one after the other). Unknown name: TBRM_ERR_INVALID_ARG. */
+ * occ_slices (0 = 128; the chunked chain's occlusion spans), sparse_occ (1), occ_list (1), light_cache_mb (-1 = an eighth of
+ * the device's memory at most, 0 = off, else MiB), light_batching (1; 0 never, 2 always), share_grid (1), ray_lanes (0 = by
+ * load; 4 / 8), chain_fast_loop (1), chain_rect_planes (1), occ_overlap (2 = workgroups per CU of an occlusion launch that
+ * runs beside a chunked chain; 0 = one after the other), light_sweep (1 = axis passes take the pipelined sweep kernel where
+ * it applies; 0 = the chunked chain everywhere), sweep_prefetch (0 = 2 slices), sweep_stagger_ns (0 = default start delay per
+ * tile of distance, < 0 none), sweep_rows (unused), sweep_debug (timing diagnostics; non-zero bit 0 gives WRONG light
+ * volumes). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
 
@@ -377,20 +381,28 @@ TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, s
 /* Kernel launches since creation: out[0] = chunked propagation launches, out[1] = slice-per-launch propagation
  * launches (fallback path), out[2] = raymarch launches. Lets tests assert which kernel actually ran. */
 TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
-/* The contribution cache of the light operators (no counterpart in the reference, invisible in the results). What an
- * axis pass of the Add / Change shaders does to the light volume is a function of L, the light's propagated value per
- * voxel (AddDirLightShader.usf:117-126, ChangeDirLightShader.usf:140-154), and L depends on the volume, the transfer
- * function, the window, the clip plane and the light — not on the light volume. A pass that propagates a light which
- * stays in the scene keeps its L (nx*ny*nz floats per axis pass, least recently used first out; tunable light_cache_mb:
- * a budget in MiB, 0 turns the cache off, the default -1 adds entries while half of the device's memory stays free). Later operators on the same light then skip its propagation:
- * removing it, or adding it again after ClearResourceLightVolumes, applies the kept L; ChangeDirLight propagates only the
- * NEW light and reads the old one's L. out[0] = stream-passes served from the cache, out[1] = stream-passes propagated,
- * out[2] = entries held, out[3] = their bytes. */
+/* Of out[0] above, the launches of the pipelined sweep kernel (one per axis pass; the rest are chunks of the chained kernel). */
+TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);
+/* The factor cache of the light operators (no counterpart in the reference, invisible in the results). The expensive half
+ * of an axis pass of the Add / Change shaders is its occlusion: the factors 1 - CurrentSample
+ * (AddDirLightShader.usf:85-117, ChangeDirLightShader.usf:100-145) of every voxel, which depend on the volume, the transfer
+ * function, the window, the clip plane and the light's direction — not on the light volume and not on the light's
+ * intensity. A pass that samples the volume for a light which stays in the scene keeps its factors, block-compact: only the
+ * 16 x 16 x 8 blocks that can be opaque at all, 8 KiB each (UNORM8 light volumes whose passes are whole brick layers: the
+ * passes the pipelined sweep kernel takes; other passes cache nothing). Later operators on the same light then do not sample
+ * the volume again: the removed side of a ChangeDirLight, a removal, a re-add after ClearResourceLightVolumes propagate from
+ * the kept factors. Entries whose light has left the scene are reused first, then the least recently used; the budget is
+ * the tunable light_cache_mb (MiB; 0 = off; the default -1 = an eighth of the device's memory, and never the last free
+ * gigabytes). out[0] = stream-passes whose occlusion came from the cache, out[1] = stream-passes whose occlusion was
+ * computed, out[2] = entries held, out[3] = their bytes. */
 TBRM_API int tbrm_light_cache_stats(const tbrm_resources* res, uint64_t out[4]);
-/* Gives the cache's HBM back (blocks until the handle's stream is idle). The next operators propagate and keep again —
+/* Gives the cache's HBM back (blocks until the handle's streams are idle). The next operators sample and keep again —
  * a host that wants the memory for good sets the tunable light_cache_mb to 0 first. */
 TBRM_API int tbrm_light_cache_clear(tbrm_resources* res);
-TBRM_API int tbrm_flush(tbrm_resources* res);                 /* FlushRenderingCommands() */
+/* FlushRenderingCommands(). Also reports a light-propagation sweep that failed on the device (TBRM_ERR_NO_DEVICE with the
+ * reason in tbrm_last_error: a tile gave up waiting for its neighbours — the device was reset or starved for seconds —; the
+ * light volume is then undefined and has to be rebuilt: ClearResourceLightVolumes + the lights again). */
+TBRM_API int tbrm_flush(tbrm_resources* res);
 TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's
  * stream; blocks until that work is complete. kind: 0 = add/change/clear (illumination), 1 = raymarch.  */

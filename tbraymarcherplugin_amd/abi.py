@@ -125,7 +125,7 @@ SYMBOLS = [
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_sweep_launches", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
@@ -196,6 +196,7 @@ def load():
     lib.tbrm_upload_light_volume.argtypes = [vp, vp, C.c_size_t]
     lib.tbrm_light_volume_device_ptr.argtypes = [vp, P(vp), P(C.c_size_t)]
     lib.tbrm_launch_counters.argtypes = [vp, P(C.c_uint64 * 3)]
+    lib.tbrm_sweep_launches.argtypes = [vp, P(C.c_uint64)]
     lib.tbrm_selftest_unorm_decode.argtypes = [C.c_int, vp, vp]
     lib.tbrm_selftest_unorm8_roundtrip.argtypes = [C.c_int, vp, C.c_size_t, vp]
     lib.tbrm_flush.argtypes = [vp]
@@ -508,7 +509,9 @@ class Resources:
     def launch_counters(self):
         out = (C.c_uint64 * 3)()
         check(self.lib.tbrm_launch_counters(self.handle, C.byref(out)))
-        return {"chunk": int(out[0]), "slice": int(out[1]), "raymarch": int(out[2])}
+        sweeps = C.c_uint64(0)
+        check(self.lib.tbrm_sweep_launches(self.handle, C.byref(sweeps)))
+        return {"chunk": int(out[0]), "slice": int(out[1]), "raymarch": int(out[2]), "sweep": int(sweeps.value)}
 
     def light_cache_stats(self):
         out = (C.c_uint64 * 4)()

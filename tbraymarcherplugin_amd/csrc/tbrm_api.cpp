@@ -1096,6 +1096,13 @@ int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
     return TBRM_OK;
 }
 
+int tbrm_sweep_launches(const tbrm_resources* r, uint64_t* out)
+{
+    if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    *out = r->sweep_launches;
+    return TBRM_OK;
+}
+
 int tbrm_light_cache_stats(const tbrm_resources* r, uint64_t out[4])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");

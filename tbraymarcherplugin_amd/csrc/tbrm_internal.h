@@ -10,12 +10,11 @@ namespace tbrm {
 enum : int { FMT_U8 = 0, FMT_U16 = 1, FMT_F32 = 2 };
 enum : int { ADDR_WRAP = 0, ADDR_CLAMP = 1, ADDR_BORDER = 2 };
 
-// what a chunked propagation pass does with its light stream(s): Add (one light, stream a), Change (a added, r removed,
-// ChangeDirLightShader.usf), or two lights added in one pass (a then r: AddDirLightShader.usf twice, sharing the slice loop)
-// PASS_CHANGE_CACHED: a Change whose removed light's propagated values L are at hand, voxel by voxel (the contribution
-// cache, tbrm_light_passes.cpp): only the added light is propagated, the removed light's L is read. Its occlusion launches
-// run in mode PASS_CHANGE_ONE (ONE stream with the Change shader's rules, i.e. without the Add shader's guard).
-enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3, PASS_CHANGE_CACHED = 4 };
+// what a propagation pass does with its light stream(s): Add (one light, stream a), Change (a added, r removed,
+// ChangeDirLightShader.usf), or two lights added in one pass (a then r: AddDirLightShader.usf twice, sharing the slice loop).
+// PASS_CHANGE_ONE is an occlusion mode only: ONE stream with the Change shader's rules (no uvw == saturate(uvw) guard) — the
+// added light of a Change whose removed light's factors come from the factor cache (tbrm_resources.h).
+enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3 };
 
 constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
 constexpr int kBrickShift = 3;
@@ -87,9 +86,6 @@ struct ChunkStream {
     float* fs_spill;
     uint32_t fs_cap;
     const int32_t* fs_slot; // sweep: rank of every block of the pass, [slice group][block y][block x]; -1: flagged empty (factor 1)
-    float* l_dump;          // chain: 1024 floats nobody reads (kept L of tile pixels outside the buffer; the entry's guard band)
-    float* l_out;           // chain: where the stream's unquantised L of every pixel of the chunk's slices is kept, [chunk slices][H][W]
-                            // (null: not kept). PASS_CHANGE_CACHED: stream r is not propagated — r.occ_base / r.occ_off address its kept L
 };
 
 // Parameters of the chunked propagation kernels (tbrm_light_kernels.hip). One struct serves the per-pass
@@ -239,24 +235,6 @@ struct RelayoutParams {
     int to_bricks; // 1: linear -> bricked (padding voxels are zeroed); 0: bricked -> linear
 };
 
-// k_apply_kept: the light-volume update of one axis pass from kept L values alone (tbrm_light_passes.cpp, contribution cache)
-constexpr int kApplyMaxPasses = 8; // axis passes one k_apply_kept launch applies, in order
-struct ApplyPass {
-    int axis, W, H;         // the pass: propagation axis, plane size (TD.X, TD.Y)
-    int start, dir;         // its first slice and direction: plane k of a kept pass is slice start + k*dir
-    float b_added;          // Add / Remove: +1 / -1
-    const float* la;        // L of the added light (Add / Remove: the light), [pass slices][H][W]
-    const float* lr;        // L of the removed light; null: Add / Remove
-};
-struct ApplyParams {
-    void* light;            // bricked
-    int lv_dims[3];
-    int lv_bnx, lv_bnxy, lv_bnz;
-    int lv_fmt;
-    int n_passes;
-    ApplyPass pass[kApplyMaxPasses];
-};
-
 constexpr int kOccSlices = 8;      // slices per occlusion workgroup (kOccDepth in tbrm_light_kernels.hip)
 constexpr int kChunkTile = 32;      // core tile edge of the chunked propagation kernel (pixels)
 constexpr int kChunkThreads = 1024;
@@ -271,7 +249,7 @@ enum Tunable : int {
     TUNE_OCC_SLICES,         // slices per occlusion span (0: default)
     TUNE_SPARSE_OCC,         // 0: occlusion blocks that can only see empty bricks are computed like the others
     TUNE_OCC_LIST,           // 0: live occlusion blocks keep their grid position instead of being dealt from a work list
-    TUNE_LIGHT_CACHE_MB,     // HBM budget of the contribution cache in MiB (0: off, < 0: while half the device stays free): a light's L, kept per axis pass
+    TUNE_LIGHT_CACHE_MB,     // HBM budget of the factor cache in MiB (0: off, < 0: an eighth of the device's memory): a light's occlusion factors, kept per axis pass
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
@@ -303,7 +281,6 @@ int sweep_halo_chunks(int hx, int hy);
 int sweep_max_slices();
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
-hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);
 hipError_t launch_raymarch_intensity(const RayParams& p, hipStream_t s);
 hipError_t launch_raymarch_octree(const RayParams& p, hipStream_t s);

@@ -32,20 +32,17 @@ __device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int,
 // KH = halo pixels per thread: ceil((hull area - tile area) / threads).
 // M > 0: the chunk has exactly M slices (8 or 16), starts on a brick layer of the light volume (occ_phase 0) and its planes
 // are staged in one round (RS <= 56), UNORM8 light volume: the slice loop is fully unrolled with every slice-dependent
-// quantity an immediate, no per-lane branches and KEEP (the contribution cache takes L) a compile-time fact — see "fast
-// slice loop" below. M == 0: any chunk.
-template <int LFMT, int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false, int RR = RS>
+// quantity an immediate and no per-lane branches — see "fast slice loop" below. M == 0: any chunk.
+template <int LFMT, int MODE, int AXIS, int KH, int RS, int M = 0, int RR = RS>
 __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TX = kChunkTile, TY = kChunkTile;
     constexpr int NT = kChunkThreads;                                    // one thread per tile pixel
     constexpr int BY = TY / 8;                                           // light-volume bricks under the tile along v (4 along u)
-    constexpr bool CACHED = MODE == PASS_CHANGE_CACHED;                  // the removed light's L is read, not propagated
-    constexpr int NS = (MODE == PASS_ADD || CACHED) ? 1 : 2;             // streams propagated (windows)
-    constexpr int NR = MODE == PASS_ADD ? 1 : 2;                         // copies a wave issues per staged slice and round: occlusion factors per stream, or (CACHED) factors + L
-    constexpr int NRP = CACHED ? 1 : NR;                                 // of them hull-sized planes (the removed light's kept L is staged for the tile alone)
-    constexpr int LRP = kChunkTile * kChunkTile;                         // floats of a kept-L ring slot
+    constexpr int NS = MODE == PASS_ADD ? 1 : 2;                         // streams propagated (windows)
+    constexpr int NR = NS;                                               // copies a wave issues per staged slice and round: the occlusion factors of each stream
+    constexpr int NRP = NR;
     constexpr bool LV_LDS = LFMT == FMT_U8;
     constexpr int KS = 1 + KH; // + the owned pixel
     constexpr int PLANE = chain_plane_elems(RS, RR);
@@ -66,15 +63,11 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
     const int base_x = tile_x * TX, base_y = (p.tile_row0 + tile_y) * TY;
 
     // LDS map (floats): window w of stream si at (w*NS + si)*PLANE, staged plane si of ring slot q at (2*NS + q*NRP + si)*PLANE;
-    // CACHED: three 32 x 32 slots for the removed light's kept L — only the owned pixels read it — and 1 KB that the waves
-    // without a share of the tile copy into (every wave issues the same number of copies per slice: the slice loops' vmcnt
-    // bookkeeping); then the light-volume tile (bytes)
+    // then the light-volume tile (bytes)
     float* const lds = (float*) smem;
-    float* const lr_base = lds + (2 * NS + kOccRing * NRP) * PLANE;
-    uint8_t* const lv_tile = (uint8_t*) (lr_base + (CACHED ? kOccRing * LRP + 256 : 0));
+    uint8_t* const lv_tile = (uint8_t*) (lds + (2 * NS + kOccRing * NRP) * PLANE);
     auto window = [&](int w, int si) -> float* { return lds + (w * NS + si) * PLANE; };
     auto ring = [&](int q, int si) -> float* { return lds + (2 * NS + q * NRP + si) * PLANE; };
-    auto lr_ring = [&](int q) -> float* { return lr_base + q * LRP; };
 
     // ---- 16-byte staging pattern: copy group i = floats [4i, 4i+4) of an LDS plane = 4 pixels of one hull row ------
     int st_src[ROUNDS];   // pixel index of the group's first pixel inside a plane (may run off the row ends: guard bands)
@@ -114,16 +107,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             }
         }
     }
-    // CACHED, the removed light's kept L: threads 0..255 copy the tile's 32 rows of 8 groups (rows beyond the buffer copy its
-    // last row: their pixels are never valid), the other waves the first KB of the allocation into the spare KB
-    if constexpr (CACHED) ndma += 1;
-    const bool lr_in = (int) threadIdx.x < LRP / 4;
-    const uint32_t lr_src = lr_in ? (uint32_t) (min(base_y + ((int) threadIdx.x >> 3), p.H - 1) * p.W + base_x + ((int) threadIdx.x & 7) * 4) : 0u;
-    const int lr_dst = wave < LRP / 256 ? wave * 256 : kOccRing * LRP; // (relative to lr_base: ring slot 0 / the spare KB)
-    auto stage_lr = [&](int sf, int q) { // slice sf of the chunk into slot q
-        const uint32_t off = lr_in ? p.r.occ_off + (uint32_t) (sf * plane_elems) + lr_src : (uint32_t) lane * 4u;
-        dma_16(p.r.occ_base + off, lr_base + lr_dst + (lr_in ? q * LRP : 0));
-    };
     // A stream's occlusion planes and a page of ones live in one allocation: a copy's source is the stream's uniform base
     // plus a 32-bit offset, and flagged-empty lanes only swap the offset (the same number of copy instructions per wave and
     // slice either way, which the vmcnt bookkeeping of the slice loop relies on).
@@ -142,7 +125,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 dma_16(s.occ_base + off, ring(q, si) + st_dst[rd]);
             }
         }
-        if constexpr (CACHED) stage_lr(sf, q);
     };
 
     // ---- input state: the plane after the previous chunk ------------------------------------------------------------
@@ -301,7 +283,7 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
         // issued after a write would wait for it: issued up front, their latencies overlap instead of adding up)
         bool act[KS];
         float t00[KS][NS], t01[KS][NS], t10[KS][NS], t11[KS][NS], fac[KS][NS];
-        float lv_old = 0.0f, l_removed = 0.0f;
+        float lv_old = 0.0f;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             act[k] = r >= rmin[k];
@@ -315,7 +297,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
             if (k == 0) {
                 if constexpr (LV_LDS) lv_old = decode_u8(lv_tile[vi]);
                 else lv_old = load_voxel<LFMT>(p.light, vi);
-                if constexpr (CACHED) l_removed = lr_ring(q)[sqy[0] * TX + sqx[0]]; // the removed light's L of this voxel, as its own pass left it
             }
         }
 #pragma unroll
@@ -335,7 +316,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 bool write;
                 if constexpr (MODE == PASS_ADD) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; } // :123-126
                 else if constexpr (MODE == PASS_CHANGE) { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; } // Change :152-154
-                else if constexpr (CACHED) { nv = lv_old + lval[0] - l_removed; write = fabsf(lval[0] - l_removed) > 1e-3f; }
                 else { // two lights added in one pass: light a's read-modify-write, then light r's on its result (:123-126 twice)
                     const bool wa = fabsf(lval[0]) > 1e-3f, wb = fabsf(lval[NS - 1]) > 1e-3f;
                     nv = wa ? through_format<LFMT>(lv_old + lval[0] * p.b_added) : lv_old;
@@ -349,11 +329,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 if (r == 0) {
 #pragma unroll
                     for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[own_idx] = through_format<LFMT>(lval[si]);
-                }
-#pragma unroll
-                for (int si = 0; si < NS; ++si) { // the contribution cache keeps what this light adds to every voxel
-                    float* const keep = (si == 0 ? p.a : p.r).l_out;
-                    if (keep) keep[(size_t) s * plane_elems + own_idx] = lval[si];
                 }
             }
         }
@@ -402,21 +377,11 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                         dma_16(st.occ_base + off, ring(Q, si) + st_dst[0]);
                     }
                 }
-                if constexpr (CACHED) stage_lr(SF, Q);
             }
         };
         // slot 0 never branches: a pixel outside the buffer is computed like any other and lands in the slack word
         const bool own_in = rmin[0] < INT32_MAX / 2;
         const int liw0 = own_in ? li[0] : DUMMY;
-        // kept L: an owned pixel's value goes to its place in the pass's plane, that of a pixel outside the buffer to the entry's
-        // guard band (l_dump) — every lane stores, every slice
-        float* keep_at[NS];
-        uint32_t keep_step = own_in ? (uint32_t) plane_elems : 0u;
-#pragma unroll
-        for (int si = 0; si < NS; ++si) {
-            const ChunkStream& st = si == 0 ? p.a : p.r;
-            keep_at[si] = KEEP && st.l_out ? (own_in ? st.l_out + own_idx : st.l_dump + threadIdx.x) : nullptr;
-        }
         // the owned voxel's offset in the light-volume tile: slice S of an aligned chunk is row S & 7 of layer S >> 3 (counted
         // from the chunk's last layer when the pass runs downwards)
         constexpr uint32_t kLvStep = AXIS == 0 ? 1u : (AXIS == 1 ? 8u : 64u);
@@ -436,8 +401,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 fac0[si] = ring(Q, si)[li[0]];
             }
             const uint32_t code_old = lv_tile[vi];
-            float l_removed = 0.0f;
-            if constexpr (CACHED) l_removed = lr_ring(Q)[sqy[0] * TX + sqx[0]];
             // halo pixels: a wave none of whose lanes has a pixel inside the window skips the slot
             bool act[KS];
             float h00[KS][NS], h01[KS][NS], h10[KS][NS], h11[KS][NS], hfac[KS][NS];
@@ -465,7 +428,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                 bool write;
                 if constexpr (MODE == PASS_ADD) { nv = lv_old + lval[0] * p.b_added; write = fabsf(lval[0]) > 1e-3f; }
                 else if constexpr (MODE == PASS_CHANGE) { nv = lv_old + lval[0] - lval[NS - 1]; write = fabsf(lval[0] - lval[NS - 1]) > 1e-3f; }
-                else if constexpr (CACHED) { nv = lv_old + lval[0] - l_removed; write = fabsf(lval[0] - l_removed) > 1e-3f; }
                 else {
                     const bool wa = fabsf(lval[0]) > 1e-3f, wb = fabsf(lval[NS - 1]) > 1e-3f;
                     nv = wa ? through_format<LFMT>(lv_old + lval[0] * p.b_added) : lv_old;
@@ -480,12 +442,6 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                     for (int si = 0; si < NS; ++si) (si == 0 ? p.a : p.r).plane_out[own_idx] = through_format<LFMT>(lval[si]);
                 }
             }
-            if constexpr (KEEP) {
-#pragma unroll
-                for (int si = 0; si < NS; ++si) {
-                    if (si == 0 || (si == 0 ? p.a : p.r).l_out) keep_at[si][(size_t) S * keep_step] = lval[si];
-                }
-            }
 #pragma unroll
             for (int k = 1; k < KS; ++k) {
                 if (__builtin_amdgcn_ballot_w64(act[k]) == 0) continue;
@@ -496,9 +452,9 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
                     window(CUR ^ 1, si)[liw] = through_format<LFMT>(prev * hfac[k][si]);
                 }
             }
-            // copies of slice S+1 (issued a slice ago) have to have landed; this slice's own (slice S+2's planes, the kept L,
-            // the last slice's planes) may stay in flight
-            constexpr int in_flight = (S + 2 < M ? NR : 0) + (KEEP ? 1 : 0) + (R == 0 ? NS : 0);
+            // copies of slice S+1 (issued a slice ago) have to have landed; this slice's own (slice S+2's planes, the last
+            // slice's planes) may stay in flight
+            constexpr int in_flight = (S + 2 < M ? NR : 0) + (R == 0 ? NS : 0);
             if constexpr (in_flight == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if constexpr (in_flight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else if constexpr (in_flight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -542,43 +498,41 @@ __global__ __launch_bounds__(kChunkThreads) void k_light_chain(const ChunkParams
 }
 
 
-template <int MODE, int AXIS, int KH, int RS, int M = 0, bool KEEP = false, int RR = RS>
+template <int MODE, int AXIS, int KH, int RS, int M = 0, int RR = RS>
 static hipError_t launch_chain4(const ChunkParams& p, hipStream_t s)
 {
     constexpr int LFMT = TBRM_CHAIN_LFMT;
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP, RR>, attr_done, 160 * 1024); e != hipSuccess) return e;
+    if (const hipError_t e = allow_big_lds(k_light_chain<LFMT, MODE, AXIS, KH, RS, M, RR>, attr_done, 160 * 1024); e != hipSuccess) return e;
     const size_t lds = chunk_lds_bytes(p, MODE, LFMT);
-    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS, M, KEEP, RR>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
+    hipLaunchKernelGGL((k_light_chain<LFMT, MODE, AXIS, KH, RS, M, RR>), dim3(8 * ((p.tiles_x * p.tiles_y + 7) / 8)), dim3(kChunkThreads), lds, s, p);
     return hipGetLastError();
 }
 
 // The fast slice loop (k_light_chain, M > 0) is instantiated for the shapes the planner produces for full chunks of light
 // passes with taps one or two texels wide: 16 slices in 56 x 56 planes with 2 halo pixels per thread, 8 slices in 40 x 40
-// planes (1) or 56 x 56 planes (1, 2); an Add or a cached Change that keeps L also 16 and 8 slices in the rectangular
-// 72 x 48 and 56 x 64 planes (2) — for a UNORM8 light volume. false: not one of them (the generic loop runs).
+// planes (1) or 56 x 56 planes (1, 2); an Add also 16 and 8 slices in the rectangular 72 x 48 and 56 x 64 planes (2) — for a
+// UNORM8 light volume. false: not one of them (the generic loop runs).
 template <int MODE, int AXIS>
 static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, hipStream_t s, hipError_t& err)
 {
 #if TBRM_CHAIN_LFMT == 0
     const bool aligned = p.occ_phase == 0 && (p.j0 & 7) == (p.dir > 0 ? 0 : 7) && g.lv_layers == g.n / 8;
     if (!aligned || tune(TUNE_CHAIN_FAST_LOOP) == 0) return false;
-    const bool keep = p.a.l_out != nullptr;
     auto go = [&](auto khc, auto rsc, auto mc) {
         constexpr int KH = decltype(khc)::value, RS = decltype(rsc)::value, M = decltype(mc)::value;
-        if constexpr (MODE == PASS_ADD2) err = launch_chain4<MODE, AXIS, KH, RS, M, false>(p, s); // (pairs are not kept)
-        else err = keep ? launch_chain4<MODE, AXIS, KH, RS, M, true>(p, s) : launch_chain4<MODE, AXIS, KH, RS, M, false>(p, s);
+        err = launch_chain4<MODE, AXIS, KH, RS, M>(p, s);
         return true;
     };
     using std::integral_constant;
-    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED) { // the rectangular planes (ChunkParams::rect_planes); L kept
-        if (keep && kh <= 2 && g.RS == 72 && g.RR == 48) {
-            if (g.n == 16) { err = launch_chain4<MODE, AXIS, 2, 72, 16, true, 48>(p, s); return true; }
-            if (g.n == 8) { err = launch_chain4<MODE, AXIS, 2, 72, 8, true, 48>(p, s); return true; }
+    if constexpr (MODE == PASS_ADD) { // the rectangular planes (ChunkParams::rect_planes)
+        if (kh <= 2 && g.RS == 72 && g.RR == 48) {
+            if (g.n == 16) { err = launch_chain4<MODE, AXIS, 2, 72, 16, 48>(p, s); return true; }
+            if (g.n == 8) { err = launch_chain4<MODE, AXIS, 2, 72, 8, 48>(p, s); return true; }
         }
-        if (keep && kh <= 2 && g.RS == 56 && g.RR == 64) {
-            if (g.n == 16) { err = launch_chain4<MODE, AXIS, 2, 56, 16, true, 64>(p, s); return true; }
-            if (g.n == 8) { err = launch_chain4<MODE, AXIS, 2, 56, 8, true, 64>(p, s); return true; }
+        if (kh <= 2 && g.RS == 56 && g.RR == 64) {
+            if (g.n == 16) { err = launch_chain4<MODE, AXIS, 2, 56, 16, 64>(p, s); return true; }
+            if (g.n == 8) { err = launch_chain4<MODE, AXIS, 2, 56, 8, 64>(p, s); return true; }
         }
     }
     if (g.RR != g.RS) return false;
@@ -591,7 +545,7 @@ static bool launch_chain_fast(const ChunkParams& p, const ChunkGeom& g, int kh, 
 }
 
 // The instantiated shapes of the generic loop (chunk_lds_bytes tells the planner which hulls have one): two streams RS 40
-// (1 halo slot per thread) / 56 (1, 2, 3); one stream RS 40 (1) / 56 (3) / 72 (3, a plain Add) / 72 x 48 and 56 x 64 (2, UNORM8)
+// (1 halo slot per thread) / 56 (1, 2, 3); one stream RS 40 (1) / 56 (3) / 72 (3) / 72 x 48 and 56 x 64 (2, UNORM8)
 template <int MODE, int AXIS>
 static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
 {
@@ -601,16 +555,13 @@ static hipError_t launch_chain3(const ChunkParams& p, hipStream_t s)
     hipError_t err = hipSuccess;
     if (launch_chain_fast<MODE, AXIS>(p, g, kh, s, err)) return err;
 #if TBRM_CHAIN_LFMT == 0
-    if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE_CACHED) { // (a full chunk off the brick grid, or L not kept)
-        if (g.RS == 72 && g.RR == 48 && kh <= 2) return launch_chain4<MODE, AXIS, 2, 72, 0, false, 48>(p, s);
-        if (g.RS == 56 && g.RR == 64 && kh <= 2) return launch_chain4<MODE, AXIS, 2, 56, 0, false, 64>(p, s);
+    if constexpr (MODE == PASS_ADD) { // (a full chunk off the brick grid)
+        if (g.RS == 72 && g.RR == 48 && kh <= 2) return launch_chain4<MODE, AXIS, 2, 72, 0, 48>(p, s);
+        if (g.RS == 56 && g.RR == 64 && kh <= 2) return launch_chain4<MODE, AXIS, 2, 56, 0, 64>(p, s);
     }
 #endif
     if (g.RR != g.RS) return hipErrorInvalidConfiguration;
-    if constexpr (MODE == PASS_CHANGE_CACHED) { // one stream propagated, two planes staged: the Add's kernels up to RS 56
-        if (g.RS == 40) return launch_chain4<MODE, AXIS, 1, 40>(p, s);
-        if (g.RS == 56) return launch_chain4<MODE, AXIS, 3, 56>(p, s);
-    } else if constexpr (MODE != PASS_ADD) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
+    if constexpr (MODE != PASS_ADD) { // two streams double the per-slot state: the exact slot count keeps the kernel out of scratch
         if (g.RS == 40) return launch_chain4<MODE, AXIS, 1, 40>(p, s);
         if (g.RS == 56) {
             if (kh <= 1) return launch_chain4<MODE, AXIS, 1, 56>(p, s);
@@ -636,8 +587,7 @@ hipError_t launch_light_chain_u8(const ChunkParams& p, int mode, hipStream_t s)
 hipError_t launch_light_chain_f32(const ChunkParams& p, int mode, hipStream_t s)
 #endif
 {
-    return mode == PASS_ADD ? launch_chain2<PASS_ADD>(p, s)
-           : (mode == PASS_CHANGE ? launch_chain2<PASS_CHANGE>(p, s) : (mode == PASS_ADD2 ? launch_chain2<PASS_ADD2>(p, s) : launch_chain2<PASS_CHANGE_CACHED>(p, s)));
+    return mode == PASS_ADD ? launch_chain2<PASS_ADD>(p, s) : (mode == PASS_CHANGE ? launch_chain2<PASS_CHANGE>(p, s) : launch_chain2<PASS_ADD2>(p, s));
 }
 
 } // namespace tbrm

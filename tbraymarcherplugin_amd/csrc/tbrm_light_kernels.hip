@@ -5,11 +5,12 @@
 //   k_light_occlusion                 : once per span of up to 128 slices — the factor 1 - CurrentSample
 //                                       (AddDirLightShader.usf:85-117) of every voxel of the span, no halo, fully
 //                                       parallel, live blocks dealt evenly over the CUs from the list.
+//   k_light_sweep (tbrm_light_sweep.hip): once per axis pass — every 32x32 tile of the slice plane walks ALL slices of the
+//                                       pass, the tiles a pipeline with dword hand-offs through memory (UNORM8 light
+//                                       volumes, passes of whole brick layers: what a loaded scan produces).
 //   k_light_chain (tbrm_light_chain.hip): once per chunk of 16 / 8 / 4 / 2 slices — advances EVERY 32x32 tile of the
-//                                       slice plane through the chunk, so an axis pass over a 512-deep volume is 4 + 32..64
-//                                       launches instead of the reference's 512 dispatches (LightingShaders.cpp:132-158).
-//   k_apply_kept                      : the light-volume update of passes whose propagated values are kept from an
-//                                       earlier operator (the contribution cache, tbrm_resources.h): no propagation.
+//                                       slice plane through the chunk, recomputing a halo instead of waiting for its
+//                                       neighbours: the passes the sweep declines, and slab-partitioned passes.
 //   k_propagate_slice                 : the reference's structure, one slice per launch (AddDirLightShader.usf:68-128,
 //                                       ChangeDirLightShader.usf:74-156). Fallback for passes the chunk kernels
 //                                       decline (degenerate offsets) and the A/B baseline (tunable force_slice_kernel).
@@ -124,124 +125,22 @@ hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t 
     }
 }
 
-// ---- k_apply_kept: axis passes whose propagated values are all at hand ----------------------------------------------------
-// What an axis pass does to the light volume is a function of L, the light's propagated value per voxel, alone
-// (AddDirLightShader.usf:123-126: LV += L * bAdded where |L| > 1e-3; ChangeDirLightShader.usf:152-154: LV += La - Lr where
-// |La - Lr| > 1e-3). When the pass that computed L kept it (ChunkStream::l_out), a later pass over the same light — its
-// removal, a re-add after a reset, the removed side of a ChangeDirLight — needs no propagation, and neither do the passes
-// that follow it while their L is at hand too: one launch applies up to kApplyMaxPasses passes in their order.
-//
-// A workgroup takes a region of 32 x 32 x 8 voxels (4 x 4 x 1 bricks of the light volume) into LDS with whole-brick
-// copies, then walks it once per pass in THAT pass's plane order — 32 consecutive floats of L per row whichever axis the
-// pass ran along — applying the shader's arithmetic to the cell in LDS (the UNORM8 code is re-quantised after every pass, as
-// separate launches would), and writes the bricks back: L is read once in 128-byte runs, the light volume once.
-constexpr int kApplyX = 32, kApplyY = 32, kApplyZ = 8;
-
-template <int LFMT>
-__global__ __launch_bounds__(256) void k_apply_kept(const ApplyParams p)
-{
-    using Cell = std::conditional_t<LFMT == FMT_U8, uint8_t, float>;
-    constexpr int CELLS_PER_WORD = 4 / (int) sizeof(Cell);              // 4 (UNORM8) / 1
-    constexpr int ROW_WORDS = kApplyX / CELLS_PER_WORD;                 // 8 / 32
-    constexpr int BRICK_WORDS = 512 / CELLS_PER_WORD;
-    __shared__ uint32_t s_words[kApplyZ * kApplyY * ROW_WORDS];
-    Cell* const s_lv = (Cell*) s_words;
-    // cell (x, y, z) of the region; the words of a row are rotated by a function of y so that lanes that differ in y (a
-    // pass along x has y as its fastest plane axis) fall into different banks
-    auto cell_of = [&](int x, int y, int z) -> int {
-        const int rot = LFMT == FMT_U8 ? (y >> 3) : y;
-        const int word = ((x / CELLS_PER_WORD) + rot) & (ROW_WORDS - 1);
-        return ((z * kApplyY + y) * ROW_WORDS + word) * CELLS_PER_WORD + (x & (CELLS_PER_WORD - 1));
-    };
-    const int bny = p.lv_bnxy / p.lv_bnx;
-    const int gx = (p.lv_bnx + 3) >> 2, gy = (bny + 3) >> 2;
-    const int rx = (int) blockIdx.x % gx, ry = ((int) blockIdx.x / gx) % gy, bz = (int) blockIdx.x / (gx * gy);
-    const int x0 = rx * kApplyX, y0 = ry * kApplyY, z0 = bz * kApplyZ;
-    uint32_t* const lv_words = (uint32_t*) p.light;
-
-    auto copy = [&](auto to_lds) {
-#pragma unroll 4
-        for (int w = threadIdx.x; w < 16 * BRICK_WORDS; w += 256) {
-            const int brick = w / BRICK_WORDS, wi = w % BRICK_WORDS, e = wi * CELLS_PER_WORD;
-            const int bx = rx * 4 + (brick & 3), by = ry * 4 + (brick >> 2);
-            if (bx >= p.lv_bnx || by >= bny) continue;
-            const size_t g = ((size_t) bz * p.lv_bnxy + (size_t) by * p.lv_bnx + bx) * BRICK_WORDS + wi;
-            const int c = cell_of((brick & 3) * 8 + (e & 7), (brick >> 2) * 8 + ((e >> 3) & 7), e >> 6);
-            if constexpr (decltype(to_lds)::value) s_words[c / CELLS_PER_WORD] = lv_words[g];
-            else lv_words[g] = s_words[c / CELLS_PER_WORD];
-        }
-    };
-    copy(std::true_type{});
-    __syncthreads();
-
-    for (int n = 0; n < p.n_passes; ++n) {
-        const ApplyPass& q = p.pass[n];
-        constexpr int BATCH = 8;
-        for (int it0 = 0; it0 < kApplyX * kApplyY * kApplyZ / 256; it0 += BATCH) {
-            float la[BATCH], lr[BATCH];
-            int cell[BATCH];
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                const int id = (it0 + k) * 256 + (int) threadIdx.x;
-                int x, y, z, j, px, py; // region cell in the pass's plane order (plane x fastest), and its slice / plane pixel
-                if (q.axis == 0) { y = id & 31; z = (id >> 5) & 7; x = id >> 8; j = x0 + x; px = y0 + y; py = z0 + z; }
-                else if (q.axis == 1) { x = id & 31; z = (id >> 5) & 7; y = id >> 8; j = y0 + y; px = x0 + x; py = z0 + z; }
-                else { x = id & 31; y = (id >> 5) & 31; z = id >> 10; j = z0 + z; px = x0 + x; py = y0 + y; }
-                const bool in = x0 + x < p.lv_dims[0] && y0 + y < p.lv_dims[1] && z0 + z < p.lv_dims[2]; // not brick padding
-                cell[k] = in ? cell_of(x, y, z) : -1;
-                const size_t li = in ? ((size_t) ((j - q.start) * q.dir) * q.H + py) * (size_t) q.W + px : 0;
-                la[k] = q.la[li];
-                lr[k] = q.lr ? q.lr[li] : 0.0f;
-            }
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) {
-                if (cell[k] < 0) continue;
-                float lv;
-                if constexpr (LFMT == FMT_U8) lv = decode_u8(s_lv[cell[k]]); else lv = s_lv[cell[k]];
-                float out = lv;
-                bool write;
-                if (q.lr) { write = fabsf(la[k] - lr[k]) > 1e-3f; out = lv + la[k] - lr[k]; }
-                else { write = fabsf(la[k]) > 1e-3f; out = lv + (la[k] * q.b_added); }
-                if (write) {
-                    if constexpr (LFMT == FMT_U8) s_lv[cell[k]] = (uint8_t) encode_u8(out); else s_lv[cell[k]] = out;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    copy(std::false_type{});
-}
-
-hipError_t launch_apply_kept(const ApplyParams& p, hipStream_t s)
-{
-    const int bny = p.lv_bnx > 0 ? p.lv_bnxy / p.lv_bnx : 0;
-    const size_t n = (size_t) ((p.lv_bnx + 3) / 4) * ((bny + 3) / 4) * p.lv_bnz;
-    if (n == 0 || p.n_passes <= 0) return hipSuccess;
-    const dim3 grid((unsigned) n), block(256);
-    if (p.lv_fmt == FMT_U8) hipLaunchKernelGGL(k_apply_kept<FMT_U8>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_apply_kept<FMT_F32>, grid, block, 0, s, p);
-    return hipGetLastError();
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // a chunk of slices per launch pair
 
 // LDS bytes of a chain workgroup; 1 GiB when no instantiated kernel shape holds the chunk's hull
 // (tbrm_light_chain.hip launch_chain3 lists the shapes: square planes of RS 40 / 56 for everything, 72 for a plain Add —
-// ten 72 x 72 planes exceed the LDS — and the rectangular 72 x 48 / 56 x 64 for an Add and a cached Change, UNORM8)
+// ten 72 x 72 planes exceed the LDS — and the rectangular 72 x 48 / 56 x 64 for an Add, UNORM8)
 size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt)
 {
     const ChunkGeom g = chunk_geometry(p);
-    const int ns = (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2; // streams propagated
-    const int nr = mode == PASS_ADD ? 1 : 2;                                  // planes staged per slice
-    const bool rect = g.RR != g.RS; // 72 x 48 / 56 x 64: instantiated for an Add and a cached Change over a UNORM8 light volume
-    if (rect && !((mode == PASS_ADD || mode == PASS_CHANGE_CACHED) && lv_fmt == FMT_U8)) return (size_t) 1 << 30;
+    const int ns = mode == PASS_ADD ? 1 : 2; // streams propagated = planes staged per slice
+    const bool rect = g.RR != g.RS; // 72 x 48 / 56 x 64: instantiated for an Add over a UNORM8 light volume
+    if (rect && !(mode == PASS_ADD && lv_fmt == FMT_U8)) return (size_t) 1 << 30;
     if (rect && g.HX * g.HY - kChunkTile * kChunkTile > 2 * kChunkThreads) return (size_t) 1 << 30; // (two halo slots per thread)
     if (g.RS == 0 || (mode != PASS_ADD && !rect && g.RS > 56)) return (size_t) 1 << 30;
-    const int nrp = mode == PASS_CHANGE_CACHED ? 1 : nr;                                         // of them hull-sized
-    size_t total = (size_t) (2 * ns + kOccRing * nrp) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged ring
-    if (mode == PASS_CHANGE_CACHED) total += (size_t) (kOccRing * kChunkTile * kChunkTile + 256) * 4; // the removed light's kept L, tile only
-    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;                // light-volume tile
+    size_t total = (size_t) (2 * ns + kOccRing * ns) * chain_plane_elems(g.RS, g.RR) * 4; // windows + staged ring
+    if (lv_fmt == FMT_U8) total += (size_t) 16 * g.lv_layers * 512;                        // light-volume tile
     return total;
 }
 
@@ -471,7 +370,7 @@ template <int DFMT, int MODE, int AXIS>
 __global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NS = (MODE == PASS_ADD || MODE == PASS_CHANGE_ONE) ? 1 : 2;
+    constexpr int NS = (MODE == PASS_ADD || MODE == PASS_CHANGE_ONE) ? 1 : 2; // PASS_CHANGE_ONE: one stream with the Change shader's rules
     constexpr bool GUARD = MODE == PASS_ADD || MODE == PASS_ADD2; // all(uvw == saturate(uvw)): the Add shader only (AddDirLightShader.usf:98)
     constexpr int ESZ = DFMT == FMT_U8 ? 1 : (DFMT == FMT_U16 ? 2 : 4);
     __shared__ float s_alpha[256];

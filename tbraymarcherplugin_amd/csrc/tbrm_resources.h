@@ -182,6 +182,7 @@ struct tbrm_resources {
     hipEvent_t ev[2][2]{};
     bool ev_valid[2]{};
     uint64_t launches[3]{}; // chunk, slice, raymarch
+    uint64_t sweep_launches = 0; // (of the chunk launches: the pipelined sweep kernel's)
 };
 
 
@@ -219,7 +220,7 @@ struct PassPlan {
     ChunkParams p{};
     int mode = PASS_ADD;        // PASS_ADD / PASS_CHANGE / PASS_ADD2
     uint64_t serial = 0;        // identifies the plan (occlusion buffers are labelled with it)
-    int n_streams() const { return (mode == PASS_ADD || mode == PASS_CHANGE_CACHED) ? 1 : 2; } // streams propagated
+    int n_streams() const { return mode == PASS_ADD ? 1 : 2; } // streams propagated
     bool two_streams() const { return n_streams() == 2; }
     int M = 0, S = 0;           // slices per chain chunk / per occlusion span
     int D = 0;                  // slices this handle runs (the whole pass, or its slab's part of a pass along z)

@@ -95,6 +95,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
         "tbrm_slab_light_halo": lambda: lib.tbrm_slab_light_halo(z, 0, None, None, None),
         "tbrm_launch_counters": lambda: lib.tbrm_launch_counters(z, None),
         "tbrm_light_cache_stats": lambda: lib.tbrm_light_cache_stats(z, None),
+        "tbrm_sweep_launches": lambda: lib.tbrm_sweep_launches(z, None),
         "tbrm_light_cache_clear": lambda: lib.tbrm_light_cache_clear(z),
         "tbrm_stream": lambda: lib.tbrm_stream(z, None),
         "tbrm_last_gpu_time_ms": lambda: lib.tbrm_last_gpu_time_ms(z, 0, None),

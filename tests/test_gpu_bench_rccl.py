@@ -1,0 +1,42 @@
+"""bench.py's N > 1 code path over RCCL on the one GPU of the box (TBRM_BENCH_FORCE_DIST=1: a process group of ONE rank, backend
+nccl = RCCL): the asynchronous, double-buffered all_gather_into_tensor of the tiles on the library's own stream
+(torch.cuda.ExternalStream), and the slab-partitioned light update with its point-to-point plane exchange and the all-gather
+of the light volume. What an 8-GPU node would run, minus the other seven ranks — the only way to put these calls through RCCL
+where the driver has one GPU per box."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra):
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"TBRM_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_tile_gather_over_rccl_equals_the_single_gpu_frame(gpu):
+    r = run_bench(["--config", "5"])
+    assert r["n_gpus"] == 1 and r["gathered_frame_equals_single_gpu_render"] is True, r
+    assert r["value"] > 0 and r["config"]["framebuffer"] == [2048, 2048]
+
+
+def test_slab_partitioned_light_update_over_rccl_equals_the_unpartitioned_operator(gpu):
+    r = run_bench(["--config", "3", "--slab-illumination"])
+    assert r["slab_light_volume_equals_unpartitioned"] is True, r
+    assert r["gathered_frame_equals_single_gpu_render"] is True, r

@@ -1,0 +1,164 @@
+"""The pipelined sweep kernel (k_light_sweep, tbrm_light_sweep.hip): that it is the kernel that runs where it applies, what it
+declines, and the shapes the other suites do not reach — steep second passes (several hand-off words per lane), planes that are
+not whole tiles, lights that pull two ways, more tiles than the device keeps resident, the hand-off under load (many operators
+back to back, a frame beside them). Every result against the oracle, UNORM8 bit for bit."""
+import numpy as np
+import pytest
+
+from tbraymarcherplugin_amd import abi, synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def scene(oracle_mod, dims, dtype=np.uint16, seed=0x5EED0900, tf=S.TF_A_KEYS, window=(0.5, 0.9, True, False)):
+    vol = S.make_volume_numpy(dims, dtype, seed)
+    lut = abi.color_curve_to_lut(tf)
+    win = abi.WindowingParams(*window)
+    orc = oracle_mod.OracleScene(vol, False)
+    orc.set_tf_lut(lut)
+    orc.set_windowing(win)
+    res = abi.Resources(dims, abi.DTYPE_FMT[np.dtype(dtype)], False)
+    res.upload_volume(vol)
+    res.set_tf_lut(lut)
+    res.set_windowing(win)
+    res.clear_light_volume(0.0)
+    return res, orc
+
+
+def same(res, orc, what=""):
+    res.flush()
+    got = res.download_light_volume()
+    assert np.array_equal(got, orc.light), f"{what}: {np.count_nonzero(got != orc.light)} of {got.size} UNORM8 light voxels differ"
+
+
+def test_sweep_runs_where_it_applies_and_declines_the_rest(gpu, oracle_mod):
+    world = S.default_world()
+    # whole brick layers, UNORM8 light volume: one sweep launch per axis pass, no chunk of the chain
+    res, orc = scene(oracle_mod, (64, 48, 56))
+    with res:
+        n = 0
+        for i in (0, 1, 2):
+            res.add_dir_light(S.light(i), True, world)
+            orc.add_dir_light(S.light(i), True, world)
+            n += abi.host_light_passes(S.light(i), world, (64, 48, 56))[1]
+        c = res.launch_counters()
+        assert c["sweep"] == n and c["chunk"] == n and c["slice"] == 0, c
+        same(res, orc, "sweeps")
+    # a depth that is not whole brick layers along one axis: passes along that axis take the chain, the others sweep
+    dims = (64, 48, 52)
+    res, orc = scene(oracle_mod, dims)
+    with res:
+        for i in (0, 2, 5):
+            res.add_dir_light(S.light(i), True, world)
+            orc.add_dir_light(S.light(i), True, world)
+        c = res.launch_counters()
+        assert 0 < c["sweep"] < c["chunk"] and c["slice"] == 0, c
+        same(res, orc, "mixed sweep / chain")
+    # a float light volume: the chain alone
+    vol = S.make_volume_numpy((48, 48, 48), np.uint16, 7)
+    with abi.Resources((48, 48, 48), abi.FMT_G16, True) as res:
+        res.upload_volume(vol)
+        res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
+        res.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+        res.add_dir_light(S.light(0), True, world)
+        c = res.launch_counters()
+        assert c["sweep"] == 0 and c["chunk"] > 0, c
+
+
+@pytest.mark.parametrize("direction", [(1, .12, -.05), (-.1, 1, .07), (.15, -.08, -1), (1, .3, .29), (-1, -.24, .9), (.5, .52, -1)])
+def test_steep_second_passes_and_ragged_planes(gpu, oracle_mod, direction):
+    """Second passes whose taps lie 2 to 9 texels away (up to six hand-off words per lane of the hand-off wave), on planes
+    that are not whole 32 x 32 tiles (the overhanging pixels hold the border colour and hand nothing over)."""
+    dims = (88, 72, 104)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0901)
+    with res:
+        light = abi.DirLightParams(direction, 0.7)
+        other = abi.DirLightParams(S.rotate_z(direction, 4.0), 0.7)
+        for op in ("add", "change", "remove"):
+            if op == "add":
+                res.add_dir_light(light, True, world)
+                orc.add_dir_light(light, True, world)
+            elif op == "change":
+                res.change_dir_light(light, other, world)
+                orc.change_dir_light(light, other, world)
+            else:
+                res.add_dir_light(other, False, world)
+                orc.add_dir_light(other, False, world)
+            same(res, orc, f"{direction} {op}")
+        assert res.launch_counters()["slice"] == 0
+
+
+def test_lights_that_pull_two_ways_take_the_chain_for_that_pass(gpu, oracle_mod):
+    """A fused Change whose two lights' minor components have opposite signs: the tiles of one stream would depend on their
+    upper neighbours, those of the other on the lower ones — no pipeline order serves both; the planner sends that pass to the
+    chained kernel. Same results."""
+    dims = (64, 64, 64)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0902)
+    with res:
+        old, new = abi.DirLightParams((1, .3, .04), 0.6), abi.DirLightParams((1, .3, -.04), 0.6)
+        pa, na = abi.host_light_passes(old, world, dims)
+        pb, nb = abi.host_light_passes(new, world, dims)
+        assert (pa[0].face, pa[1].face) == (pb[0].face, pb[1].face), "meant to be a fused Change"
+        res.add_dir_light(old, True, world)
+        orc.add_dir_light(old, True, world)
+        before = res.launch_counters()
+        res.change_dir_light(old, new, world)
+        orc.change_dir_light(old, new, world)
+        after = res.launch_counters()
+        assert after["chunk"] - before["chunk"] > after["sweep"] - before["sweep"], (before, after)
+        same(res, orc, "two-way change")
+
+
+def test_more_tiles_than_the_device_keeps_resident(gpu, oracle_mod, tunables):
+    """A 1152 x 1152 plane is 1296 tiles: more workgroups than the device keeps resident at once (the tiles are dealt by
+    ticket in upstream-first order, so a tile only ever waits for tiles that have started: late tiles simply start late).
+    Against the one-slice-per-launch kernel on the same GPU (the oracle would take minutes)."""
+    dims = (1152, 1152, 16)
+    vol = S.make_volume_numpy(dims, np.uint8, 0x5EED0903)
+    world = S.default_world()
+    out = []
+    for variant in ("sweep", "slice"):
+        tunables("force_slice_kernel", 1 if variant == "slice" else 0)
+        with abi.Resources(dims, abi.FMT_G8, False) as res:
+            res.upload_volume(vol)
+            res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
+            res.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+            res.clear_light_volume(0.0)
+            res.add_dir_light(abi.DirLightParams((.3, -.2, -1), 0.8), True, world)   # first pass along z: the big plane
+            res.change_dir_light(abi.DirLightParams((.3, -.2, -1), 0.8), abi.DirLightParams((.33, -.17, -1), 0.8), world)
+            res.flush()
+            if variant == "sweep":
+                assert res.launch_counters()["sweep"] >= 2
+            out.append(res.download_light_volume())
+    tunables("force_slice_kernel", 0)
+    assert np.array_equal(out[0], out[1]), f"{np.count_nonzero(out[0] != out[1])} voxels differ"
+
+
+def test_many_operators_back_to_back_with_frames_beside_them(gpu, oracle_mod):
+    """The hand-off under load: 40 operators enqueued without a host synchronisation in between (the occlusion of each pass
+    runs on the second stream beside the sweep of the pass before), a lit raymarch after every fourth; one comparison with the
+    oracle at the end (its light volume after the same 40 operators) and the sweep's error word clean."""
+    dims = (96, 96, 96)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0904)
+    cam = S.default_camera(128, 128)
+    tile = abi.Tile(0, 0, 128, 128, 1)
+    rp = abi.RaymarchParams(96.0, -1, True)
+    with res:
+        cur = [S.light(i) for i in range(4)]
+        for l in cur:
+            res.add_dir_light(l, True, world)
+            orc.add_dir_light(l, True, world)
+        for k in range(36):
+            i = k % 4
+            new = abi.DirLightParams(S.rotate_z(S.LIGHTS[i][0], 7.0 * (k // 4 + 1)), S.LIGHTS[i][1])
+            res.change_dir_light(cur[i], new, world)
+            orc.change_dir_light(cur[i], new, world)
+            cur[i] = new
+            if k % 4 == 3:
+                res.raymarch_lit(cam, tile, rp, world)
+        same(res, orc, "40 operators")
+        st = res.light_cache_stats()
+        assert st["hits"] > 0 and st["entries"] > 0, st

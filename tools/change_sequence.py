@@ -1,6 +1,6 @@
 """GPU time of a sequence of ChangeDirLight calls that turn ONE light by 5 degrees at a time (bench size), with what the
-contribution cache did for each: "cached" = only the new light was propagated, "both" = both lights, "remove+add" = the
-major axes differed (LightingShaders.cpp:192-198). Diagnostics."""
+factor cache did for each: "cached" = only the new light's occlusion was computed, "both" = both lights', "from cache" = none,
+"remove+add" = the major axes differed (LightingShaders.cpp:192-198). Diagnostics."""
 import os
 import sys
 
@@ -31,7 +31,7 @@ for k in range(1, int(os.environ.get("STEPS", "14")) + 1):
     res.change_dir_light(cur, new, world)
     ms = res.last_gpu_time_ms(0)
     st = res.light_cache_stats()
-    kind = "remove+add" if not fused else ("cached" if st["hits"] - before["hits"] == 2 else ("applied" if st["hits"] - before["hits"] == 4 else "both"))
+    kind = "remove+add" if not fused else ("cached" if st["hits"] - before["hits"] == 2 else ("from cache" if st["hits"] - before["hits"] == 4 else "both"))
     print(f"{5 * (k - 1):3d} -> {5 * k:3d} deg: {ms:6.3f} ms  {kind}", flush=True)
     before, cur = st, new
 res.close()

@@ -17,15 +17,19 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o p -- python
 find /tmp/prof_fetch -name "*counter_collection.csv" -exec cp {} /tmp/pmc_fetch.csv \;
 find /tmp/prof_write -name "*counter_collection.csv" -exec cp {} /tmp/pmc_write.csv \;
 python tools/pmc_traffic.py /tmp/pmc_fetch.csv /tmp/pmc_write.csv "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt" 2>&1
+# instruction-issue view (tools/issue_roofline.py): two more counter passes of the same command
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d /tmp/prof_issue1 -o p -- python bench.py --no-cpu-baseline --timed-only --steps 20 --warmup 4 > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_issue2 -o p -- python bench.py --no-cpu-baseline --timed-only --steps 20 --warmup 4 > /dev/null 2>&1
+find /tmp/prof_issue1 -name "*counter_collection.csv" -exec cp {} /tmp/pmc_issue1.csv \;
+find /tmp/prof_issue2 -name "*counter_collection.csv" -exec cp {} /tmp/pmc_issue2.csv \;
+python tools/issue_roofline.py "$OUT/issue.json" /tmp/pmc_issue1.csv /tmp/pmc_issue2.csv > "$OUT/issue.txt" 2>&1
 python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only.json" 2> /dev/null
-(echo "== tools/prof_light.py, light_cache_mb=0 (every call propagates)"; TBRM_LIGHT_CACHE_MB=0 python tools/prof_light.py 2>&1 | grep -v amdgpu.ids
- echo "== tools/prof_light.py, defaults (repeated calls are served from the kept L)"; python tools/prof_light.py 2>&1 | grep -v amdgpu.ids) > "$OUT/operators.txt"
-echo "== tools/change_sweep.py" >> "$OUT/operators.txt"
-python tools/change_sweep.py "" "light_cache_mb=0" 2>&1 | grep -v amdgpu.ids >> "$OUT/operators.txt"
-(echo "== tools/change_sequence.py (one light turned 5 degrees per call)"; python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids
- echo "== the same, occ_overlap=0"; TBRM_OCC_OVERLAP=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -6
- echo "== the same, light_cache_mb=0"; TBRM_LIGHT_CACHE_MB=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -4
- echo "== tools/apply_time.py"; python tools/apply_time.py 2>&1 | grep -v amdgpu.ids
+(echo "== tools/prof_light.py, light_cache_mb=0 (every call samples the volume)"; TBRM_LIGHT_CACHE_MB=0 python tools/prof_light.py 2>&1 | grep -v amdgpu.ids
+ echo "== tools/prof_light.py, defaults (repeated calls propagate from kept factors)"; python tools/prof_light.py 2>&1 | grep -v amdgpu.ids) > "$OUT/operators.txt"
+(echo "== tools/sweep_time.py: sweep / chain, cache on / off"; VARIANTS="light_sweep=0,light_cache_mb=0;light_cache_mb=0;light_cache_mb=-1" python tools/sweep_time.py 2>&1 | grep -v amdgpu.ids
+ echo "== tools/change_sequence.py (one light turned 5 degrees per call)"; python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids
+ echo "== the same, light_cache_mb=0"; TBRM_LIGHT_CACHE_MB=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -6
+ echo "== tools/sweep_stamps.py (timeline of one sweep launch)"; python tools/sweep_stamps.py 2>&1 | grep -v amdgpu.ids
  echo "== tools/host_enqueue_time.py"; python tools/host_enqueue_time.py 2>&1 | grep -v amdgpu.ids) >> "$OUT/operators.txt"
 for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
 TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"

@@ -22,14 +22,15 @@ def per_kernel(path, counter):
     return acc
 
 
-LIGHT_KERNELS = ("k_light_chain", "k_light_occlusion", "k_occ_flags", "k_occ_compact", "k_apply_kept", "k_propagate_slice")
+LIGHT_KERNELS = ("k_light_sweep", "k_light_chain", "k_light_occlusion", "k_occ_flags", "k_occ_compact", "k_propagate_slice")
 
 
 def operator_runs(path, counter, scale):
     """Bytes of every ChangeDirLight call of the profiled command (bench.py --timed-only: setup, then per step one
     ChangeDirLight and one frame): in dispatch order, every maximal run of light-operator kernels AFTER the first frame is one
-    call (the runs before it are the setup's ResetAllLights). Returns [(bytes, kind)], kind = which chain kernels ran:
-    'cached' (MODE 4: only the new light propagated), 'both' (MODE 1), 'remove+add' (MODE 0), 'applied' (k_apply_kept alone)."""
+    call (the runs before it are the setup's ResetAllLights). Returns [(bytes, kind)], kind = which occlusion launches ran:
+    'cached' (mode 3: only the new light's occlusion computed, the removed light's factors kept), 'both' (mode 1),
+    'remove+add' (mode 0: the Add shader's rules), 'from cache' (no occlusion launch at all)."""
     rows = []
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] == counter:
@@ -39,13 +40,16 @@ def operator_runs(path, counter, scale):
     for _, name, value in rows:
         if "k_raymarch_lit" in name:
             if seen_frame and modes:
-                kind = "cached" if "4" in modes else ("both" if "1" in modes else ("remove+add" if "0" in modes else "applied"))
+                kind = "cached" if "3" in modes else ("both" if "1" in modes else ("remove+add" if "0" in modes else "from cache"))
                 runs.append((cur * scale, kind))
             seen_frame, cur, modes = True, 0.0, set()
         elif seen_frame and any(k in name for k in LIGHT_KERNELS):
             cur += value
-            m = re.search(r"k_light_chain<\d+, (\d+),", name)
-            modes.add(m.group(1) if m else "apply")
+            m = re.search(r"k_light_occlusion<\d+, (\d+),", name)
+            if m:
+                modes.add(m.group(1))
+            elif not modes:
+                modes.add("none")
     return runs
 
 
