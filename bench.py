@@ -407,10 +407,12 @@ def main():
         # the same with the cache off (light_cache_mb = 0: nothing is kept either).
         win_k = [0]
 
-        def stale_window():
+        def stale_window():  # a window centre nobody has used yet: win_k ulps above the config's
             win_k[0] += 1
-            c = float(np.nextafter(np.float32(cfg["window"][0]), np.float32(2.0)) if win_k[0] % 2 else np.float32(cfg["window"][0]))
-            res.set_windowing(abi.WindowingParams(c, *cfg["window"][1:]))
+            c = np.float32(cfg["window"][0])
+            for _ in range(win_k[0]):
+                c = np.nextafter(c, np.float32(2.0))
+            res.set_windowing(abi.WindowingParams(float(c), *cfg["window"][1:]))
 
         def timed(fn, before=None, reps=2):
             best = None

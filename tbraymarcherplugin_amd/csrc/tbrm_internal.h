@@ -140,13 +140,13 @@ struct ChunkParams {
 // slices. The previous-slice taps of a pass lie on ONE side of the pixel per plane axis (the constant PrevPixelOffset,
 // AddDirLightShader.usf:81-82), so a tile depends on at most three neighbours — the ones towards the light — and the tiles
 // form a pipeline: tile t runs a few slices behind its upstream neighbours and reads the hx columns / hy rows it needs of
-// their slice from a hand-off record in global memory (dwords {24-bit launch tag, UNORM8 code}, written and polled with
-// relaxed agent-scope atomics: no fences, no kernel boundary, no recomputed halo).
+// their slice from a hand-off record in global memory (dwords {16-bit launch tag, UNORM8 code of stream r, of stream a},
+// written and polled with relaxed agent-scope atomics: no fences, no kernel boundary, no recomputed halo).
 struct SweepParams {
     int sx, sy;             // side of the previous-slice taps along the plane's x / y: +1, -1, 0 (none: the tap is the pixel itself)
     int hx, hy;             // how many columns / rows beyond the tile they reach (both streams)
-    uint32_t* rec[2];       // per stream: the hand-off records, [slice of the launch][tile][32*hx + 32*hy words]
-    uint32_t epoch;         // this launch's tag, 1 .. 2^24 - 1 (records are not cleared between launches)
+    uint32_t* rec[2];       // [0]: the hand-off records, [slice of the launch][tile][32*hx + 32*hy words] ([1]: unused)
+    uint32_t epoch;         // this launch's tag, 1 .. 2^16 - 1 (records are not cleared between launches)
     int prefetch;           // slices ahead of their use that the neighbours' records are requested
     int stagger_ns;         // a tile d tiles away from the upstream corner starts d * stagger_ns late: the distance it would
                             // otherwise fall behind by polling (a tile can never make up lag, and every poll that finds nothing

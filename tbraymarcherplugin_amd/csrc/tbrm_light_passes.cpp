@@ -139,15 +139,11 @@ static int ensure_sweep(tbrm_resources* r, size_t words)
     }
     if (words > r->sweep_rec_words) {
         HIP_TRY(hipStreamSynchronize(r->stream));
-        for (auto& rec : r->sweep_rec) {
-            (void) hipFree(rec);
-            rec = nullptr;
-        }
+        (void) hipFree(r->sweep_rec[0]);
+        r->sweep_rec[0] = nullptr;
         r->sweep_rec_words = 0;
-        for (auto& rec : r->sweep_rec) {
-            HIP_TRY(hipMalloc((void**) &rec, words * sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(rec, 0, words * sizeof(uint32_t), r->stream)); // tag 0: no launch
-        }
+        HIP_TRY(hipMalloc((void**) &r->sweep_rec[0], words * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(r->sweep_rec[0], 0, words * sizeof(uint32_t), r->stream)); // tag 0: no launch
         r->sweep_rec_words = words;
         r->sweep_epoch = 0;
     }
@@ -156,8 +152,8 @@ static int ensure_sweep(tbrm_resources* r, size_t words)
 
 static int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch)
 {
-    if (++r->sweep_epoch >= (1u << 24)) { // 2^24 launches later: tags start over
-        for (auto& rec : r->sweep_rec) HIP_TRY(hipMemsetAsync(rec, 0, r->sweep_rec_words * sizeof(uint32_t), r->stream));
+    if (++r->sweep_epoch >= (1u << 16)) { // 2^16 launches later: tags start over
+        HIP_TRY(hipMemsetAsync(r->sweep_rec[0], 0, r->sweep_rec_words * sizeof(uint32_t), r->stream));
         r->sweep_epoch = 1;
     }
     epoch = r->sweep_epoch;
@@ -513,6 +509,9 @@ static void estimate_scope(tbrm_resources* r, const PropParams& base)
         r->f_est_key[1] = r->tf_gen;
         memcpy(r->f_est_win, win, sizeof(win));
         r->f_est_blocks = 0;
+        // what was kept under another volume / transfer function / window is out of reach unless the host comes back to exactly
+        // that state: first in line when a buffer is needed
+        for (FactorEntry* e : r->kept) e->spent = true;
     }
 }
 

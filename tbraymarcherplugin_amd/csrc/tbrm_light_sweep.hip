@@ -12,7 +12,8 @@
 // slices behind its upstream neighbours, whose values it has requested PF slices ahead.
 //
 // Hand-off. A plane value is a UNORM8 code (the read / write buffers are re-quantised every slice), so a record word is ONE
-// dword, {24-bit tag of this launch, code}, written with one relaxed agent-scope store and polled with relaxed agent-scope
+// dword, {16-bit tag of this launch, the removed light's code, the added light's code} — both streams of a Change travel in
+// the same word —, written with one relaxed agent-scope store and polled with relaxed agent-scope
 // loads (global_store / global_load ... sc1, MI355X_MICROARCH.md "handoff-1to1"): data and flag travel together, so there is
 // no fence, no write-back of the L2, no second round trip and nothing that could tear. Records are addressed by
 // [slice][tile][word] and never reused within a launch, so a producer never waits for a consumer; the tag makes clearing
@@ -86,7 +87,7 @@ __device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch,
     uint32_t w = 0;
     for (int tries = 0; tries < (1 << 20); ++tries) {
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
-        if ((w >> 8) == epoch) return w;
+        if ((w >> 16) == epoch) return w;
         __builtin_amdgcn_s_sleep(2);
     }
     atomicOr(error, 1);
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
         lv_next = load_layer(1);
     }
 
-    const uint32_t epoch = q.epoch & 0xffffffu, tag = epoch << 8;
+    const uint32_t epoch = q.epoch & 0xffffu, tag = epoch << 16;
     const int RW = T * (hx + hy);
     const uint32_t rec_slice = (uint32_t) (n_tiles * RW); // words per slice
     __syncthreads(); // planes, flags and the first brick layer are in LDS
@@ -254,21 +255,20 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
             hal_dst[h] = (oy + cyh) * RS + ox + cxh;
             hal_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * RW + word) : 0u;
         }
-        uint32_t hreg[RING][NS][HC];
+        uint32_t hreg[RING][HC];
         // (every lane loads: the ones without a halo word read word 0 of the slice — a branch around a load whose result is
         // consumed slices later would make the compiler drain every request in flight at the join)
         auto request_halo = [&](int s, auto slot_c) { // the neighbours' slice s
             constexpr int SLOT = decltype(slot_c)::value;
 #pragma unroll
-            for (int si = 0; si < NS; ++si)
-#pragma unroll
-                for (int h = 0; h < HC; ++h) hreg[SLOT][si][h] = sweep_load_word((const uint32_t*) q.rec[si] + ((uint32_t) s * rec_slice + hal_src[h]));
+            for (int h = 0; h < HC; ++h) hreg[SLOT][h] = sweep_load_word((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]));
         };
         sweep_each_const([&](auto sl) {
             constexpr int SL = decltype(sl)::value;
             if constexpr (SL < PF) request_halo(SL, sl); // (n >= 8 > PF)
         }, std::make_integer_sequence<int, RING>{});
 
+        __builtin_amdgcn_s_setprio(3); // (its few instructions go first: what it publishes is what the neighbours wait for)
         auto group = [&](int g, auto last_c) {
             constexpr bool LAST = decltype(last_c)::value;
             sweep_each_const([&](auto kc) {
@@ -276,27 +276,27 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                 const int s = g * 8 + K8;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
                 if ((TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
+                    uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RW));
 #pragma unroll
-                    for (int si = 0; si < NS; ++si) {
-                        uint32_t* const rec = (uint32_t*) q.rec[si] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RW));
+                    for (int h = 0; h < HC; ++h)
+                        if (pub_cell[h] >= 0) {
+                            uint32_t w = tag;
 #pragma unroll
-                        for (int h = 0; h < HC; ++h)
-                            if (pub_cell[h] >= 0) {
-                                const float v = plane(CUR, si)[pub_cell[h]];
-                                sweep_store_word(rec + (h * 64 + lane), tag | ((uint32_t) (v * 255.0f + 0.5f) & 255u)); // (v = code / 255: back to the code)
-                            }
-                    }
+                            for (int si = 0; si < NS; ++si) w |= ((uint32_t) (plane(CUR, si)[pub_cell[h]] * 255.0f + 0.5f) & 255u) << (8 * si); // (v = code / 255: back to the code)
+                            sweep_store_word(rec + (h * 64 + lane), w);
+                        }
                 }
                 // the upstream neighbours' cells of THIS slice into the halo of the plane the compute waves are building
                 if constexpr (!(LAST && K8 == 7)) {
 #pragma unroll
-                    for (int si = 0; si < NS; ++si)
+                    for (int h = 0; h < HC; ++h) {
+                        uint32_t w = hreg[K8][h];
+                        if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error);
+                        if (hal_on[h]) {
 #pragma unroll
-                        for (int h = 0; h < HC; ++h) {
-                            uint32_t w = hreg[K8][si][h];
-                            if (hal_on[h] && (w >> 8) != epoch) w = sweep_poll((const uint32_t*) q.rec[si] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error);
-                            if (hal_on[h]) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8(w & 255u);
+                            for (int si = 0; si < NS; ++si) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8((w >> (8 * si)) & 255u);
                         }
+                    }
                 }
                 if constexpr ((!LAST || K8 + PF <= 6) && !(TBRM_SWEEP_EXP & 4)) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
                 if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
