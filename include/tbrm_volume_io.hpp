@@ -79,6 +79,17 @@ struct FVolumeInfo {
     }
 };
 
+// How NormalizeArray seeds its running maximum. The reference starts it at std::numeric_limits<T>::min()
+// (TextureUtilities.h:110) — for the integer formats the lowest value, for MET_FLOAT the smallest POSITIVE one, so a float
+// volume without a positive voxel reports a maximum of 1.18e-38 instead of its own. true (the default): exactly that, results
+// identical to the reference's on every input; false: lowest() for every type, which is what was meant. Process-wide, like the
+// reference's behaviour.
+inline bool& NormalizeSeedsMaximumLikeTheReference()
+{
+    static bool value = true;
+    return value;
+}
+
 namespace detail {
 
 // [min, max] of the array onto the full range of Out, with the reference's float arithmetic (TextureUtilities.h:103-149)
@@ -86,9 +97,8 @@ template <typename In, typename Out>
 inline void NormalizeArray(const uint8_t* bytes, long long byte_size, std::vector<uint8_t>& out, float& out_min, float& out_max)
 {
     const long long n = byte_size / (long long) sizeof(In);
-    // (the reference seeds the maximum with numeric_limits<T>::min(), TextureUtilities.h:110 — for float that is the smallest
-    // POSITIVE value, so an all-negative MET_FLOAT volume got a maximum of ~0; lowest() is what was meant: deliberate deviation)
-    In lo = std::numeric_limits<In>::max(), hi = std::numeric_limits<In>::lowest();
+    In lo = std::numeric_limits<In>::max();
+    In hi = NormalizeSeedsMaximumLikeTheReference() ? std::numeric_limits<In>::min() : std::numeric_limits<In>::lowest(); // (TextureUtilities.h:110)
     for (long long i = 0; i < n; ++i) {
         In v;
         std::memcpy(&v, bytes + i * sizeof(In), sizeof(In));

@@ -1,5 +1,5 @@
 // Driver for tests/test_volume_io.py: loads one .mhd with include/tbrm_volume_io.hpp and dumps what it read.
-//   volume_io_test <file.mhd> <normalize 0|1> <to_float 0|1> <out.bin>
+//   volume_io_test <file.mhd> <normalize 0|1> <to_float 0|1> <out.bin> [<maximum seeded like the reference 0|1, default 1>]
 // stdout: key=value lines; out.bin: the converted voxel array.
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +13,7 @@ int main(int argc, char** argv)
     if (argc < 5) return 2;
     FVolumeInfo info;
     std::vector<uint8_t> voxels;
+    if (argc > 5) NormalizeSeedsMaximumLikeTheReference() = std::atoi(argv[5]) != 0;
     const bool ok = UMHDLoader::LoadVolume(argv[1], std::atoi(argv[2]) != 0, std::atoi(argv[3]) != 0, info, voxels);
     std::printf("ok=%d\n", ok ? 1 : 0);
     std::printf("parsed=%d\n", info.bParseWasSuccessful ? 1 : 0);

@@ -42,8 +42,9 @@ def write_mhd(folder, name, arr, spacing=(0.5, 0.75, 2.0), compressed=False, spa
     return path
 
 
-def run(driver, path, normalize, to_float, out_bin):
-    out = subprocess.run([driver, path, "1" if normalize else "0", "1" if to_float else "0", out_bin], check=True, capture_output=True, text=True).stdout
+def run(driver, path, normalize, to_float, out_bin, reference_seed=True):
+    out = subprocess.run([driver, path, "1" if normalize else "0", "1" if to_float else "0", out_bin, "1" if reference_seed else "0"],
+                         check=True, capture_output=True, text=True).stdout
     kv = {}
     for line in out.strip().splitlines():
         key, _, rest = line.partition("=")
@@ -51,12 +52,14 @@ def run(driver, path, normalize, to_float, out_bin):
     return kv
 
 
-def normalized_reference(arr):
-    """ConvertArrayToNormalizedArray<In, Out> in numpy float32. One deliberate deviation from the reference: the running
-    maximum starts at the LOWEST value of the type (the reference starts it at numeric_limits<T>::min(), which for float
-    is the smallest positive value, TextureUtilities.h:110 — an all-negative float volume then reports a maximum of ~0)."""
+def normalized_reference(arr, reference_seed=True):
+    """ConvertArrayToNormalizedArray<In, Out> in numpy float32. The running maximum starts at numeric_limits<T>::min() like the
+    reference's (TextureUtilities.h:110: for float the smallest POSITIVE value — a float volume without a positive voxel
+    reports a maximum of 1.18e-38); reference_seed = False: at the lowest value of the type (the loader's switch)."""
     flat = arr.reshape(-1)
     lo, hi = flat.min(), flat.max()
+    if reference_seed and arr.dtype == np.float32:
+        hi = max(hi, np.finfo(np.float32).tiny)
     out_t = np.uint8 if arr.dtype.itemsize == 1 else np.uint16
     out_max = np.float32(np.iinfo(out_t).max)
     span = np.float32(hi) - np.float32(lo)
@@ -134,10 +137,16 @@ def test_mhd_header_rules_and_failures(driver, tmp_path):
     const = np.full((2, 2, 2), 7, dtype=np.int16)
     kv = run(driver, write_mhd(str(tmp_path), "f", const), True, False, out_bin)
     assert kv["ok"] == "1" and not np.fromfile(out_bin, dtype=np.uint16).any()
-    # all-negative float file: the true maximum (-1), not the reference's FLT_MIN start value (TextureUtilities.h:110)
+    # all-negative float file. By default exactly the reference: its maximum starts at FLT_MIN (TextureUtilities.h:110), so the
+    # file's largest voxel (-1) does not reach the top code; with the switch off: the true maximum (-1) and the full range
     neg = -np.arange(1, 9, dtype=np.float32).reshape(2, 2, 2)
     kv = run(driver, write_mhd(str(tmp_path), "g", neg), True, False, out_bin)
     want, lo, hi = normalized_reference(neg)
+    got = np.fromfile(out_bin, dtype=np.uint16).reshape(2, 2, 2)
+    assert np.array_equal(got, want) and lo == -8.0 and 0.0 < hi < 1e-37 and got.max() < 65535 and got.min() == 0
+    assert float(kv["min"].split()[0].split("=")[-1]) == -8.0 and 0.0 < float(kv["min"].split("max=")[1]) < 1e-37
+    kv = run(driver, write_mhd(str(tmp_path), "g", neg), True, False, out_bin, reference_seed=False)
+    want, lo, hi = normalized_reference(neg, reference_seed=False)
     got = np.fromfile(out_bin, dtype=np.uint16).reshape(2, 2, 2)
     assert np.array_equal(got, want) and hi == -1.0 and lo == -8.0 and got.max() == 65535 and got.min() == 0
 
