@@ -85,6 +85,7 @@ def load():
     lib.orc_probe_encode_unorm8.restype = C.c_uint8; lib.orc_probe_encode_unorm8.argtypes = [f]
     lib.orc_probe_srgb8_round_trip.restype = f; lib.orc_probe_srgb8_round_trip.argtypes = [f]
     lib.orc_set_num_threads.argtypes = [C.c_int]
+    lib.orc_debug_set_opacity_scale.argtypes = [C.c_float]
     _lib = lib
     return lib
 

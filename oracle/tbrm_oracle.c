@@ -289,6 +289,11 @@ static inline float get_transfer_func_position(float value, float center, float 
     return (value - center + (width / 2.0f)) / width; /* WindowedSampling.usf:16 */
 }
 
+/* Diagnostics only (tools/exit_flip_rate.py): the corrected opacity of every sample times this factor. 1 (the default) leaves
+ * the arithmetic untouched; 1 + 2^-23 is the smallest perturbation an approximate opacity path could introduce. */
+static float g_debug_opacity_scale = 1.0f;
+void orc_debug_set_opacity_scale(float s) { g_debug_opacity_scale = s; }
+
 static void sample_windowed_transfer_function(float value, float step_size, const float* tf,
                                               const tbrm_windowing_params* wp, float out[4])
 {
@@ -301,6 +306,7 @@ static void sample_windowed_transfer_function(float value, float step_size, cons
     sample_tf(tf, tfpos, out);
     out[3] = saturatef(out[3]);
     out[3] = 1.0f - orc_powf(1.0f - out[3], step_size); /* :35 */
+    if (g_debug_opacity_scale != 1.0f) out[3] = out[3] * g_debug_opacity_scale;
 }
 
 /* ================================================================================================ */

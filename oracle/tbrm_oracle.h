@@ -75,6 +75,7 @@ uint8_t orc_probe_encode_unorm8(float x);
 float orc_probe_srgb8_round_trip(float x);
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
+void orc_debug_set_opacity_scale(float s); /* diagnostics: see tbrm_oracle.c */
 
 #ifdef __cplusplus
 }

@@ -2,15 +2,18 @@
 why the HBM roofline fraction of a kernel is what it is.
 
     python tools/issue_roofline.py <out.json> <counter_collection.csv> [...]
+    python tools/issue_roofline.py <out.json> --from-json <earlier out.json>     (recompute the ratios from its per-launch sums)
 
-Per kernel family (k_light_sweep, k_light_occlusion, k_raymarch_lit; averaged per launch, summed over the chip):
-  valu_issue_frac   SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE): share of the chip's VALU issue slots used, at the
-                    4 cycles per wave64 instruction the round-2 review prescribes (the SIMDs of this part are 32 lanes wide: a
-                    plain fp32 instruction occupies its SIMD for 2, so the pipes' busy share is half of this)
+Per kernel family (k_light_sweep, k_light_occlusion, k_raymarch_lit; averaged per launch, summed over the chip). GRBM_GUI_ACTIVE
+is summed over the 8 XCDs (a 0.58 ms frame reads 11.0 M = 8 x 0.58 ms x 2.37 GHz), so a launch lasts GRBM_GUI_ACTIVE / 8 cycles;
+SQ_WAVE_CYCLES and SQ_WAIT_INST_ANY count in units of 4 cycles.
+  valu_issue_frac   SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x launch cycles): share of the chip's VALU issue slots used, at the
+                    4 cycles per wave64 instruction the round-2 review prescribes (the round-2 figure for the frame, 0.86, is
+                    this ratio)
   salu_per_valu     scalar per vector instruction (a wave issues one instruction at a time: scalars cost issue slots too)
-  lds_busy_frac     SQ_ACTIVE_INST_LDS / (256 CUs x GRBM_GUI_ACTIVE)
+  lds_busy_frac     SQ_ACTIVE_INST_LDS x 4 / (256 CUs x launch cycles) (approximate: the counter's unit is not documented)
   wait_share        SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: share of their resident time the waves spend waiting (memory, LDS, barrier)
-  waves_per_simd    SQ_WAVE_CYCLES / (1024 x GRBM_GUI_ACTIVE): average resident waves
+  waves_per_simd    SQ_WAVE_CYCLES x 4 / (1024 x launch cycles): average resident waves
 """
 import collections
 import csv
@@ -22,6 +25,11 @@ FAMILIES = ("k_light_sweep", "k_light_occlusion", "k_raymarch_lit", "k_light_cha
 
 def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    if len(sys.argv) > 3 and sys.argv[2] == "--from-json":
+        for fam, e in json.load(open(sys.argv[3])).items():
+            for k, v in e["per_launch"].items():
+                acc[fam][k] = [e["launches"], v * e["launches"]]
+        sys.argv[2:] = []
     for path in sys.argv[2:]:
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"]
@@ -35,6 +43,7 @@ def main():
     for fam, counters in acc.items():
         c = {k: v[1] / max(v[0], 1) for k, v in counters.items()}
         gui = c.get("GRBM_GUI_ACTIVE")
+        gui = gui / 8.0 if gui else gui  # cycles of one launch
         entry = {"launches": max(v[0] for v in counters.values()), "per_launch": {k: round(v, 1) for k, v in sorted(c.items())}}
         if gui:
             if "SQ_INSTS_VALU" in c:
@@ -42,9 +51,10 @@ def main():
             if "SQ_INSTS_SALU" in c and c.get("SQ_INSTS_VALU"):
                 entry["salu_per_valu"] = round(c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"], 3)
             if "SQ_ACTIVE_INST_LDS" in c:
-                entry["lds_busy_frac"] = round(c["SQ_ACTIVE_INST_LDS"] / (256.0 * 4.0 * gui), 4)
+                entry["lds_busy_frac"] = round(c["SQ_ACTIVE_INST_LDS"] * 4.0 / (256.0 * gui), 4)
             if "SQ_WAVE_CYCLES" in c:
-                entry["waves_per_simd"] = round(c["SQ_WAVE_CYCLES"] / (1024.0 * gui), 3)
+                entry["waves_per_simd"] = round(c["SQ_WAVE_CYCLES"] * 4.0 / (1024.0 * gui), 3)
+            entry["launch_us_at_2_4_ghz"] = round(gui / 2400.0, 1)
         if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c:
             entry["wait_share"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
         out[fam] = entry
