@@ -14,7 +14,9 @@ enum : int { ADDR_WRAP = 0, ADDR_CLAMP = 1, ADDR_BORDER = 2 };
 // ChangeDirLightShader.usf), or two lights added in one pass (a then r: AddDirLightShader.usf twice, sharing the slice loop).
 // PASS_CHANGE_ONE is an occlusion mode only: ONE stream with the Change shader's rules (no uvw == saturate(uvw) guard) — the
 // added light of a Change whose removed light's factors come from the factor cache (tbrm_resources.h).
-enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3 };
+// PASS_PLANES is a sweep mode only: one stream propagated, the light volume untouched — what the launch leaves behind is its
+// hand-off records (SweepParams::r_from_records of the launch after it).
+enum : int { PASS_ADD = 0, PASS_CHANGE = 1, PASS_ADD2 = 2, PASS_CHANGE_ONE = 3, PASS_PLANES = 5 };
 
 constexpr int kBrick = 8;      // empty-space-skipping brick edge in voxels
 constexpr int kBrickShift = 3;
@@ -145,7 +147,13 @@ struct ChunkParams {
 struct SweepParams {
     int sx, sy;             // side of the previous-slice taps along the plane's x / y: +1, -1, 0 (none: the tap is the pixel itself)
     int hx, hy;             // how many columns / rows beyond the tile they reach (both streams)
-    uint32_t* rec[2];       // [0]: the hand-off records, [slice of the launch][tile][32*hx + 32*hy words] ([1]: unused)
+    // A fused Change whose lights pull opposite ways along a plane axis has no tile order that serves both streams. Its
+    // removed light is then propagated FIRST, alone, in its own order (a PASS_PLANES launch into rec[1]); the fused launch
+    // runs in the added light's order and takes the removed light's halo from those finished records.
+    int r_from_records;     // PASS_CHANGE: stream r's halo comes from rec[1] (tag r_epoch), geometry r_sx .. r_hy
+    int r_sx, r_sy, r_hx, r_hy;
+    uint32_t r_epoch;
+    uint32_t* rec[2];       // [0]: the hand-off records, [slice of the launch][tile][32*hx + 32*hy words]; [1]: r_from_records
     uint32_t epoch;         // this launch's tag, 1 .. 2^16 - 1 (records are not cleared between launches)
     int prefetch;           // slices ahead of their use that the neighbours' records are requested
     int stagger_ns;         // a tile d tiles away from the upstream corner starts d * stagger_ns late: the distance it would

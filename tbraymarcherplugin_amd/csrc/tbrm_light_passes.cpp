@@ -65,32 +65,50 @@ static TapSide prev_tap_side(int size, float off)
 }
 
 // Can the axis pass (one stream: pr == null) run as pipelined sweeps? The tiles' dependency has to point one way per buffer
-// axis for both streams (two lights of a fused Change whose minor components have opposite signs pull opposite ways:
-// declined), the reach has to fit the kernel's LDS planes and the hand-off wave's six words per lane, and the pass has to
-// consist of whole brick layers of the light volume.
+// axis, the reach has to fit the kernel's LDS planes and the hand-off wave's six words per lane, and the pass has to consist
+// of whole brick layers of the light volume. The two lights of a fused Change whose minor components have opposite signs
+// pull opposite ways: no tile order serves both, and the pass runs as TWO sweeps (SweepFit::two_way) if each light's reach
+// fits the hand-off wave and both fit the planes side by side.
 bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit)
 {
     if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident) return false;
     if (mode != PASS_ADD && mode != PASS_CHANGE) return false;
     if (pa.td[2] % 8 != 0 || (pa.start & 7) != (pa.dir > 0 ? 0 : 7)) return false;
     fit = SweepFit{};
+    TapSide side[2][2];
+    bool opposite = false;
+    int n = 0;
     for (const tbrm_light_pass* q : {&pa, pr}) {
         if (!q) continue;
         const TapSide tx = prev_tap_side(q->td[0], q->prev_pixel_offset[0]), ty = prev_tap_side(q->td[1], q->prev_pixel_offset[1]);
         if (!tx.ok || !ty.ok) return false;
-        if (tx.side * fit.sx < 0 || ty.side * fit.sy < 0) return false;
+        side[n][0] = tx; side[n][1] = ty;
+        ++n;
+        opposite = opposite || tx.side * fit.sx < 0 || ty.side * fit.sy < 0;
         if (tx.side) fit.sx = tx.side;
         if (ty.side) fit.sy = ty.side;
         fit.hx = std::max(fit.hx, tx.reach);
         fit.hy = std::max(fit.hy, ty.reach);
     }
-    return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= 6;
+    if (!opposite) return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= 6;
+    if (tune(TUNE_LIGHT_SWEEP) == 2) return false; // (diagnostics: such passes take the chain, as before round 3's last week)
+    fit.two_way = true;
+    fit.sx = side[0][0].side; fit.hx = side[0][0].reach; fit.sy = side[0][1].side; fit.hy = side[0][1].reach;
+    fit.r_sx = side[1][0].side; fit.r_hx = side[1][0].reach; fit.r_sy = side[1][1].side; fit.r_hy = side[1][1].reach;
+    // the planes hold the tile, a guard ring and both lights' halos: the low sides' larger reach plus the high sides'
+    int room[2];
+    for (int ax = 0; ax < 2; ++ax) {
+        int lo = 0, hi = 0;
+        for (int si = 0; si < 2; ++si) (side[si][ax].side < 0 ? lo : hi) = std::max(side[si][ax].side < 0 ? lo : hi, side[si][ax].reach);
+        room[ax] = lo + hi;
+    }
+    return room[0] <= 14 && room[1] <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= 6 && sweep_halo_chunks(fit.r_hx, fit.r_hy) <= 6;
 }
 
 void release_sweep(tbrm_resources* r)
 {
     for (auto& rec : r->sweep_rec) { (void) hipFree(rec); rec = nullptr; }
-    r->sweep_rec_words = 0;
+    r->sweep_rec_words = r->sweep_rec1_words = 0;
     (void) hipFree(r->sweep_ticket);
     r->sweep_ticket = nullptr;
     if (r->sweep_error) (void) hipHostFree(r->sweep_error);
@@ -124,12 +142,14 @@ int sweep_check(tbrm_resources* r)
     if (!r->sweep_error || *r->sweep_error == 0) return TBRM_OK;
     const int e = *r->sweep_error;
     *r->sweep_error = 0;
-    return fail(TBRM_ERR_NO_DEVICE, "a light-propagation sweep failed on the device (%s%s): the light volume is undefined",
-                (e & 1) ? "a tile gave up waiting for its neighbours" : "", (e & 2) ? " previous-slice taps outside the planned halo" : "");
+    return fail(TBRM_ERR_NO_DEVICE, "a light-propagation sweep failed on the device (%s%s%s): the light volume is undefined",
+                (e & 1) ? "a tile gave up waiting for its neighbours" : "", (e & 2) ? " previous-slice taps outside the planned halo" : "",
+                (e & 4) ? " a removed light's plane records were not there" : "");
 }
 
-// room for the hand-off records of a span of `slices` slices (both streams), the tickets and the error word
-static int ensure_sweep(tbrm_resources* r, size_t words)
+// room for the hand-off records of a pass (words1: of the removed light's own sweep, two-way Changes), the tickets and the
+// error word
+static int ensure_sweep(tbrm_resources* r, size_t words, size_t words1 = 0)
 {
     if (!r->sweep_ticket) {
         HIP_TRY(hipMalloc((void**) &r->sweep_ticket, 2 * sizeof(int)));
@@ -145,15 +165,25 @@ static int ensure_sweep(tbrm_resources* r, size_t words)
         HIP_TRY(hipMalloc((void**) &r->sweep_rec[0], words * sizeof(uint32_t)));
         HIP_TRY(hipMemsetAsync(r->sweep_rec[0], 0, words * sizeof(uint32_t), r->stream)); // tag 0: no launch
         r->sweep_rec_words = words;
-        r->sweep_epoch = 0;
+    }
+    if (words1 > r->sweep_rec1_words) {
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->sweep_rec[1]);
+        r->sweep_rec[1] = nullptr;
+        r->sweep_rec1_words = 0;
+        HIP_TRY(hipMalloc((void**) &r->sweep_rec[1], words1 * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(r->sweep_rec[1], 0, words1 * sizeof(uint32_t), r->stream));
+        r->sweep_rec1_words = words1;
     }
     return TBRM_OK;
 }
 
-static int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch)
+// (launches: how many consecutive launches must not have the tags start over between them)
+static int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch, uint32_t launches = 1)
 {
-    if (++r->sweep_epoch >= (1u << 16)) { // 2^16 launches later: tags start over
+    if (++r->sweep_epoch + (launches - 1) >= (1u << 16)) { // 2^16 launches later: tags start over
         HIP_TRY(hipMemsetAsync(r->sweep_rec[0], 0, r->sweep_rec_words * sizeof(uint32_t), r->stream));
+        if (r->sweep_rec[1]) HIP_TRY(hipMemsetAsync(r->sweep_rec[1], 0, r->sweep_rec1_words * sizeof(uint32_t), r->stream));
         r->sweep_epoch = 1;
     }
     epoch = r->sweep_epoch;
@@ -730,9 +760,12 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
 
     SweepParams& q = plan.sq;
     q.sx = sfit.sx; q.sy = sfit.sy; q.hx = sfit.hx; q.hy = sfit.hy;
+    q.r_from_records = sfit.two_way ? 1 : 0;
+    q.r_sx = sfit.r_sx; q.r_sy = sfit.r_sy; q.r_hx = sfit.r_hx; q.r_hy = sfit.r_hy;
     const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy));
-    if (words >= ((size_t) 1 << 32)) return declined("hand-off records too large");
-    if (int e = ensure_sweep(r, std::max<size_t>(words, 1))) return e;
+    const size_t words1 = sfit.two_way ? (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.r_hx + sfit.r_hy)) : 0;
+    if (words >= ((size_t) 1 << 32) || words1 >= ((size_t) 1 << 32)) return declined("hand-off records too large");
+    if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words1)) return e;
     // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
     q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 3;
     q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : (change ? 3000 : 2000);
@@ -988,6 +1021,24 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
     q.rec[1] = r->sweep_rec[1];
     q.ticket = r->sweep_ticket;
     q.error = r->sweep_error;
+    if (q.r_from_records) {
+        // the removed light's planes first: one stream in its own tile order, the light volume untouched, its hand-off
+        // records (which the fused launch reads instead of waiting for them) in the second buffer
+        ChunkParams pr1 = p;
+        pr1.a = p.r;
+        SweepParams q1 = q;
+        q1.sx = q.r_sx; q1.sy = q.r_sy; q1.hx = q.r_hx; q1.hy = q.r_hy;
+        q1.r_from_records = 0;
+        q1.rec[0] = r->sweep_rec[1];
+        q1.rec[1] = nullptr;
+        q1.stamps = nullptr;
+        q1.debug &= ~2;
+        if (int e = next_sweep_epoch(r, q1.epoch, 2)) return e;
+        HIP_TRY(launch_light_sweep(pr1, q1, PASS_PLANES, r->stream));
+        ++r->launches[0];
+        ++r->sweep_launches;
+        q.r_epoch = q1.epoch;
+    }
     if (int e = next_sweep_epoch(r, q.epoch)) return e;
     q.stamps = nullptr;
     if (q.debug & 2) { // diagnostics: per-tile time stamps of this launch (printed by tbrm_flush)

@@ -64,7 +64,7 @@ constexpr int kSweepFlagGroups = 128;                  // slice groups of a span
 
 size_t sweep_lds_bytes(int mode)
 {
-    const int ns = mode == PASS_ADD ? 1 : 2;
+    const int ns = mode == PASS_CHANGE ? 2 : 1;
     return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * kSweepFlagGroups * 4; // planes, three brick layers, block ranks
 }
 
@@ -112,15 +112,18 @@ __device__ __forceinline__ v2f quantize2(v2f x)                                 
 
 // MODE: PASS_ADD (stream a) or PASS_CHANGE (a added, r removed). PF: slices ahead of their use that the neighbours'
 // hand-off words are requested (a tile settles PF + 1 slices and one memory round trip behind its upstream neighbours).
-// HC: 64-word chunks of hand-off words per slice and stream.
-template <int MODE, int AXIS, int PF, int HC>
+// HC: 64-word chunks of hand-off words per slice. RREC (PASS_CHANGE): stream r's halo comes from the records of an earlier
+// PASS_PLANES launch (SweepParams::r_from_records). MODE PASS_PLANES: one stream, the light volume untouched.
+template <int MODE, int AXIS, int PF, int HC, bool RREC = false>
 __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams p, const SweepParams q)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
     constexpr int T = kSweepTile, RS = kSweepRS, PLANE = kSweepPlane, LVB = kSweepLvBrick;
     constexpr int R = 2, NWC = kSweepComputeWaves, NTC = NWC * 64, NT = kSweepThreads;
-    constexpr int NS = MODE == PASS_ADD ? 1 : 2;
+    constexpr int NS = MODE == PASS_CHANGE ? 2 : 1;
+    constexpr bool LV = MODE != PASS_PLANES; // the light volume is updated
+    static_assert(!RREC || MODE == PASS_CHANGE, "only a fused Change takes a stream from records");
     constexpr int RING = kSweepRing, FA = kSweepFactorAhead;
     static_assert(PF >= 1 && PF < RING && FA < RING, "the request rings hold 8 slices");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
     const int base_x = tile_x * T, base_y = tile_y * T;
     const int n = p.n_steps, G = n >> 3; // whole brick layers (the launcher's check)
     const int hx = q.hx, hy = q.hy;
-    const int ox = 1 + (q.sx < 0 ? hx : 0), oy = 1 + (q.sy < 0 ? hy : 0); // LDS plane coordinates of tile pixel (0, 0)
+    // LDS plane coordinates of tile pixel (0, 0): behind the guard ring and whatever halo lies on the low side
+    const int ox = 1 + max(q.sx < 0 ? hx : 0, (RREC && q.r_sx < 0) ? q.r_hx : 0), oy = 1 + max(q.sy < 0 ? hy : 0, (RREC && q.r_sy < 0) ? q.r_hy : 0);
     const bool down = p.dir < 0;
     const int layer0 = p.j0 >> 3;
 
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
         if (piece_exists) *(uint4*) ((uint8_t*) p.light + (piece_off + (uint32_t) layer_of(g) * layer_stride)) = *(const uint4*) ((const uint8_t*) piece_lds + (g % 3) * kLvBuf);
     };
     uint4 lv_next = make_uint4(0, 0, 0, 0);
-    if (wave < NWC) {
+    if (LV && wave < NWC) {
         *piece_lds = load_layer(0);
         lv_next = load_layer(1);
     }
@@ -255,13 +259,49 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
             hal_dst[h] = (oy + cyh) * RS + ox + cxh;
             hal_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * RW + word) : 0u;
         }
-        uint32_t hreg[RING][HC];
+        // RREC: stream r's halo cells, the same construction with stream r's geometry; their words were written by the launch
+        // before this one (tag r_epoch), tile by tile in the same [slice][tile][word] layout
+        bool rh_on[HC];
+        int rh_dst[HC];
+        uint32_t rh_src[HC];
+        const int r_RW = T * (q.r_hx + q.r_hy);
+        const uint32_t r_rec_slice = (uint32_t) (n_tiles * r_RW);
+        if constexpr (RREC) {
+            const int rhx = q.r_hx, rhy = q.r_hy;
+            const int re0y = q.r_sy > 0 ? 0 : T - rhy;
+#pragma unroll
+            for (int h = 0; h < HC; ++h) {
+                const int w = h * 64 + lane;
+                const int nx = T * rhx, ny = T * rhy, nc = rhx * rhy;
+                int ntx = tile_x, nty = tile_y, word = 0, cxh = 0, cyh = 0;
+                bool on = false;
+                if (w < nx) { const int row = w / max(rhx, 1), kx = w - row * rhx; ntx += q.r_sx; word = row * rhx + kx; cxh = (q.r_sx > 0 ? T : -rhx) + kx; cyh = row; on = true; }
+                else if (w < nx + ny) { const int m = w - nx, ky = m / T, col = m - ky * T; nty += q.r_sy; word = nx + ky * T + col; cxh = col; cyh = (q.r_sy > 0 ? T : -rhy) + ky; on = true; }
+                else if (w < nx + ny + nc) {
+                    const int m = w - nx - ny, ky = m / max(rhx, 1), kx = m - ky * rhx;
+                    ntx += q.r_sx; nty += q.r_sy;
+                    word = (re0y + ky) * rhx + kx;
+                    cxh = (q.r_sx > 0 ? T : -rhx) + kx; cyh = (q.r_sy > 0 ? T : -rhy) + ky;
+                    on = true;
+                }
+                on = on && (unsigned) ntx < (unsigned) p.tiles_x && (unsigned) nty < (unsigned) p.tiles_y &&
+                     (unsigned) (base_x + cxh) < (unsigned) p.W && (unsigned) (base_y + cyh) < (unsigned) p.H;
+                rh_on[h] = on;
+                rh_dst[h] = (oy + cyh) * RS + ox + cxh;
+                rh_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * r_RW + word) : 0u;
+            }
+        }
+        uint32_t hreg[RING][HC], rreg[RING][RREC ? HC : 1];
         // (every lane loads: the ones without a halo word read word 0 of the slice — a branch around a load whose result is
         // consumed slices later would make the compiler drain every request in flight at the join)
         auto request_halo = [&](int s, auto slot_c) { // the neighbours' slice s
             constexpr int SLOT = decltype(slot_c)::value;
 #pragma unroll
             for (int h = 0; h < HC; ++h) hreg[SLOT][h] = sweep_load_word((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]));
+            if constexpr (RREC) {
+#pragma unroll
+                for (int h = 0; h < HC; ++h) rreg[SLOT][h] = sweep_load_word((const uint32_t*) q.rec[1] + ((uint32_t) s * r_rec_slice + rh_src[h]));
+            }
         };
         sweep_each_const([&](auto sl) {
             constexpr int SL = decltype(sl)::value;
@@ -294,7 +334,17 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                         if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error);
                         if (hal_on[h]) {
 #pragma unroll
-                            for (int si = 0; si < NS; ++si) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8((w >> (8 * si)) & 255u);
+                            for (int si = 0; si < (RREC ? 1 : NS); ++si) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8((w >> (8 * si)) & 255u);
+                        }
+                    }
+                    if constexpr (RREC) { // the removed light's cells: published long ago (a word that is not there is an error)
+#pragma unroll
+                        for (int h = 0; h < HC; ++h) {
+                            const uint32_t w = rreg[K8][h];
+                            if (rh_on[h]) {
+                                if ((w >> 16) != (q.r_epoch & 0xffffu)) atomicOr(q.error, 4);
+                                plane(CUR ^ 1, 1)[rh_dst[h]] = decode_u8(w & 255u);
+                            }
                         }
                     }
                 }
@@ -341,7 +391,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                 ix -= px;
                 // the host promised: taps of non-zero weight within hx columns on side sx (SweepParams)
                 const int lo = ix, hi = fx != 0.0f ? ix + 1 : ix;
-                bad = bad || (q.sx >= 0 ? (lo < 0 || hi > hx) : (lo < -hx || hi > 0));
+                const int gsx = (RREC && si == 1) ? q.r_sx : q.sx, ghx = (RREC && si == 1) ? q.r_hx : hx;
+                bad = bad || (gsx >= 0 ? (lo < 0 || hi > ghx) : (lo < -ghx || hi > 0));
             }
             wfx[si] = fx;
             float fy2[R];
@@ -355,7 +406,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     texel_split(pv + s.off_v, (float) p.H, iy, fy);
                     iy -= py;
                     const int lo = iy, hi = fy != 0.0f ? iy + 1 : iy;
-                    bad = bad || (q.sy >= 0 ? (lo < 0 || hi > hy) : (lo < -hy || hi > 0));
+                    const int gsy = (RREC && si == 1) ? q.r_sy : q.sy, ghy = (RREC && si == 1) ? q.r_hy : hy;
+                    bad = bad || (gsy >= 0 ? (lo < 0 || hi > ghy) : (lo < -ghy || hi > 0));
                 }
                 fy2[k] = fy;
                 tap[si][k] = own[k] + (in_pl[k] ? iy * RS + ix : 0);
@@ -421,7 +473,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
             lv_old.x = (float) code_old[0]; lv_old.y = (float) code_old[1];
             lv_old = decode2(lv_old);
             v2f nv, d;
-            if constexpr (MODE == PASS_ADD) { nv = fma2(lv_l[0], (v2f) p.b_added, lv_old); d = lv_l[0]; } // (l * +-1 is exact: the fused form rounds once, like lv + l * b)
+            if constexpr (MODE != PASS_CHANGE) { nv = fma2(lv_l[0], (v2f) p.b_added, lv_old); d = lv_l[0]; } // (l * +-1 is exact: the fused form rounds once, like lv + l * b)
             else { d = lv_l[0] - lv_l[NS - 1]; nv = (lv_old + lv_l[0]) - lv_l[NS - 1]; }
             const v2f qn = quantize2(nv);
             const bool w0 = fabsf(d.x) > thresh && in_pl[0], w1 = fabsf(d.y) > thresh && in_pl[1];
@@ -433,10 +485,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
             uint8_t* const lv_layer = lvt + (g % 3) * kLvBuf;
             sweep_each_const([&](auto kc) {
                 constexpr int K8 = decltype(kc)::value, CUR = K8 & 1;
-                if constexpr (K8 == 1) { // (the last voxels of the layer before were updated in slice 0 of this group)
+                if constexpr (LV && K8 == 1) { // (the last voxels of the layer before were updated in slice 0 of this group)
                     if (g > 0) write_back_layer(g - 1);
                 }
-                if constexpr (K8 == 3 && !LAST) { // the next layer: loaded eight slices ago, first used four barriers from now
+                if constexpr (LV && K8 == 3 && !LAST) { // the next layer: loaded eight slices ago, first used four barriers from now
                     *(uint4*) ((uint8_t*) piece_lds + ((g + 1) % 3) * kLvBuf) = lv_next;
                     lv_next = load_layer(g + 2);
                 }
@@ -447,9 +499,11 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     request_factors(std::integral_constant<int, (K8 + FA) & 7>{});
                 }
                 // LDS reads: the voxels of the slice before, this slice's taps
-                uint32_t code_old[R];
+                uint32_t code_old[R] = {0, 0};
+                if constexpr (LV) {
 #pragma unroll
-                for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
+                    for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
+                }
                 v2f t00[NS], t01[NS], t10[NS], t11[NS];
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
@@ -457,7 +511,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     t00[si].x = pa[0]; t01[si].x = pa[1]; t10[si].x = pa[RS]; t11[si].x = pa[RS + 1];
                     t00[si].y = pb[0]; t01[si].y = pb[1]; t10[si].y = pb[RS]; t11[si].y = pb[RS + 1];
                 }
-                if constexpr (!(TBRM_SWEEP_EXP & 1))
+                if constexpr (LV && !(TBRM_SWEEP_EXP & 1))
                     if (K8 > 0 || g > 0) light_volume_update(code_old);
                 // this slice
                 v2f pval[NS];
@@ -475,7 +529,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     plane(CUR ^ 1, si)[own[1]] = in_pl[1] ? pval[si].y : st.border_light;
                 }
                 lv_prev = lv_layer + (uint32_t) (down ? 7 - K8 : K8) * kLvStep;
-                if constexpr (LAST && K8 == 7) { // the state the next span starts from
+                if constexpr (LV && LAST && K8 == 7) { // the state the next span starts from
 #pragma unroll
                     for (int si = 0; si < NS; ++si) {
                         if (in_pl[0]) stream(si).plane_out[own_idx[0]] = pval[si].x;
@@ -493,7 +547,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
         group(G - 1, std::true_type{});
         __builtin_amdgcn_s_setprio(0);
         if (stamping) q.stamps[4 * tile_lin + 2] = wall_clock64();
-        { // the last slice's voxels, then the last two layers
+        if constexpr (LV) { // the last slice's voxels, then the last layer
             uint32_t code_old[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
@@ -502,7 +556,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
     }
 
     __syncthreads(); // the last slice's voxels are in the layer buffers
-    if (wave < NWC) write_back_layer(G - 1);
+    if (LV && wave < NWC) write_back_layer(G - 1);
     if (stamping) q.stamps[4 * tile_lin + 3] = wall_clock64();
 
     // ---- the last tile to finish re-arms the tickets for the next launch -----------------------------------------------------
@@ -515,12 +569,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
     }
 }
 
-template <int MODE, int AXIS, int PF, int HC>
+template <int MODE, int AXIS, int PF, int HC, bool RREC = false>
 static hipError_t launch_sweep5(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC>, attr_done, 96 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC>), dim3(p.tiles_x * p.tiles_y), dim3(kSweepThreads), sweep_lds_bytes(MODE), s, p, q);
+    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC>, attr_done, 96 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC>), dim3(p.tiles_x * p.tiles_y), dim3(kSweepThreads), sweep_lds_bytes(MODE), s, p, q);
     return hipGetLastError();
 }
 template <int MODE, int AXIS, int PF>
@@ -531,6 +585,14 @@ static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipS
     if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3>(p, q, s);
     return hipErrorInvalidConfiguration;
 #endif
+    if constexpr (MODE == PASS_CHANGE) {
+        if (q.r_from_records) { // (sweep_fit: both streams' words fit three per lane)
+            const int hc2 = std::max(hc, sweep_halo_chunks(q.r_hx, q.r_hy));
+            if (hc2 <= 3) return launch_sweep5<MODE, AXIS, 3, 3, true>(p, q, s);
+            if (hc2 <= 6) return launch_sweep5<MODE, AXIS, 3, 6, true>(p, q, s);
+            return hipErrorInvalidConfiguration;
+        }
+    }
     if (hc <= 2) return launch_sweep5<MODE, AXIS, PF, 2>(p, q, s);
     if (hc <= 3) return launch_sweep5<MODE, AXIS, PF, 3>(p, q, s);
     if (hc <= 6) return launch_sweep5<MODE, AXIS, 3, 6>(p, q, s); // (six words per lane and stream: a ring of three slices is what fits the registers)
@@ -556,8 +618,10 @@ hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mo
     if (p.n_steps <= 0 || p.tiles_x <= 0 || p.tiles_y <= 0) return hipSuccess;
     const bool aligned = (p.n_steps & 7) == 0 && (p.j0 & 7) == (p.dir > 0 ? 0 : 7) && p.occ_phase == 0 && p.n_steps <= 8 * kSweepFlagGroups;
     if (!aligned || !p.compact || !p.ones || !p.a.fs_slot || (mode == PASS_CHANGE && !p.r.fs_slot)) return hipErrorInvalidConfiguration;
+    if (q.r_from_records && (mode != PASS_CHANGE || !q.rec[1])) return hipErrorInvalidConfiguration;
     if (mode == PASS_ADD) return launch_sweep2<PASS_ADD>(p, q, s);
     if (mode == PASS_CHANGE) return launch_sweep2<PASS_CHANGE>(p, q, s);
+    if (mode == PASS_PLANES) return launch_sweep2<PASS_PLANES>(p, q, s);
     return hipErrorInvalidConfiguration;
 }
 

@@ -142,7 +142,8 @@ struct tbrm_resources {
     // the pipelined sweep (k_light_sweep, tbrm_light_sweep.hip): hand-off records of the two streams ([slice][tile][word],
     // never cleared: words carry the tag of the launch that wrote them), the tile tickets and the error word
     uint32_t* sweep_rec[2] = {nullptr, nullptr};
-    size_t sweep_rec_words = 0;    // capacity of each
+    size_t sweep_rec_words = 0;    // capacity of [0]
+    size_t sweep_rec1_words = 0;   // capacity of [1] (two-way Changes only)
     int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
     int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
     uint32_t sweep_epoch = 0;      // tag of the last sweep launch
@@ -254,7 +255,9 @@ bool chunk_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
 int slice_tap_reach(const tbrm_light_pass& pa, const tbrm_light_pass* pr);
 int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
               const tbrm_slab* slab, PassPlan& plan, int two_stream_mode = PASS_CHANGE, float b_added2 = 0.0f);
-struct SweepFit { int sx = 0, sy = 0, hx = 0, hy = 0; };
+// two_way (fused Change only): the removed light's taps lie on the other side along some axis — its planes are swept first,
+// on their own (r_*), and the fused sweep runs in the added light's order (SweepParams::r_from_records)
+struct SweepFit { int sx = 0, sy = 0, hx = 0, hy = 0; bool two_way = false; int r_sx = 0, r_sy = 0, r_hx = 0, r_hy = 0; };
 bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit);
 void release_sweep(tbrm_resources* r);
 int sweep_check(tbrm_resources* r); // after the stream has drained: did a sweep kernel raise its error word?

@@ -89,18 +89,57 @@ def test_steep_second_passes_and_ragged_planes(gpu, oracle_mod, direction):
         assert res.launch_counters()["slice"] == 0
 
 
-def test_lights_that_pull_two_ways_take_the_chain_for_that_pass(gpu, oracle_mod):
-    """A fused Change whose two lights' minor components have opposite signs: the tiles of one stream would depend on their
-    upper neighbours, those of the other on the lower ones — no pipeline order serves both; the planner sends that pass to the
-    chained kernel. Same results."""
+TWO_WAY = [  # (pairs whose passes start from the same faces: the third-largest component changes sign)
+    ((1, .3, .04), (1, .3, -.04)),
+    ((1, .3, .2), (1, .32, -.2)),
+    ((.3, 1, -.2), (.3, 1, .2)),         # y pass first
+    ((.15, -.2, -1), (-.1, -.3, -1)),    # z pass first, downwards
+    ((1, .2, .3), (1, -.2, .3)),
+    ((.1, .45, 1), (-.1, .45, 1)),
+]
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (96, 72, 40)])
+@pytest.mark.parametrize("cache", [0, -1])
+def test_lights_that_pull_two_ways_are_swept_one_after_the_other(gpu, oracle_mod, tunables, dims, cache):
+    """A fused Change whose two lights' minor components have opposite signs: the tiles of one stream depend on their upper
+    neighbours, those of the other on the lower ones — no pipeline order serves both. The removed light's planes are swept
+    first on their own (no light-volume update), and the fused sweep reads their hand-off records (SweepParams::
+    r_from_records). Same results as the reference's slice loop; no pass falls back to the chain."""
+    tunables("light_cache_mb", cache)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0902)
+    with res:
+        for k, (d_old, d_new) in enumerate(TWO_WAY):
+            old, new = abi.DirLightParams(d_old, 0.6), abi.DirLightParams(d_new, 0.5 + 0.1 * (k % 3))
+            pa, _ = abi.host_light_passes(old, world, dims)
+            pb, _ = abi.host_light_passes(new, world, dims)
+            assert (pa[0].face, pa[1].face) == (pb[0].face, pb[1].face), "meant to be a fused Change"
+            res.add_dir_light(old, True, world)
+            orc.add_dir_light(old, True, world)
+            before = res.launch_counters()
+            res.change_dir_light(old, new, world)
+            orc.change_dir_light(old, new, world)
+            after = res.launch_counters()
+            # ("chunk" counts every propagation launch that covers more than a slice: all of them were sweeps)
+            assert after["chunk"] - before["chunk"] == after["sweep"] - before["sweep"] and after["slice"] == before["slice"], (d_old, d_new, before, after)
+            assert after["sweep"] - before["sweep"] >= 3, (d_old, d_new, before, after)  # at least one pass took two launches
+            same(res, orc, f"two-way change {d_old} -> {d_new}")
+        # and back again from what the cache kept (cache on), the other way round
+        for d_old, d_new in TWO_WAY[:2]:
+            res.change_dir_light(abi.DirLightParams(d_new, 0.5), abi.DirLightParams(d_old, 0.5), world)
+            orc.change_dir_light(abi.DirLightParams(d_new, 0.5), abi.DirLightParams(d_old, 0.5), world)
+        same(res, orc, "two-way changes back")
+
+
+def test_two_way_changes_can_be_sent_to_the_chain(gpu, oracle_mod, tunables):
+    """light_sweep = 2: passes whose lights pull two ways take the chained kernel, as they did before the two-launch form."""
+    tunables("light_sweep", 2)
     dims = (64, 64, 64)
     world = S.default_world()
     res, orc = scene(oracle_mod, dims, seed=0x5EED0902)
     with res:
         old, new = abi.DirLightParams((1, .3, .04), 0.6), abi.DirLightParams((1, .3, -.04), 0.6)
-        pa, na = abi.host_light_passes(old, world, dims)
-        pb, nb = abi.host_light_passes(new, world, dims)
-        assert (pa[0].face, pa[1].face) == (pb[0].face, pb[1].face), "meant to be a fused Change"
         res.add_dir_light(old, True, world)
         orc.add_dir_light(old, True, world)
         before = res.launch_counters()
@@ -108,7 +147,7 @@ def test_lights_that_pull_two_ways_take_the_chain_for_that_pass(gpu, oracle_mod)
         orc.change_dir_light(old, new, world)
         after = res.launch_counters()
         assert after["chunk"] - before["chunk"] > after["sweep"] - before["sweep"], (before, after)
-        same(res, orc, "two-way change")
+        same(res, orc, "two-way change on the chain")
 
 
 def test_more_tiles_than_the_device_keeps_resident(gpu, oracle_mod, tunables):
