@@ -268,6 +268,7 @@ enum Tunable : int {
     TUNE_SWEEP_ROWS,         // (unused: a sweep lane owns two rows)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
     TUNE_SWEEP_STAGGER_NS,   // start delay of a sweep tile per tile of distance from the upstream corner, ns (0: default; < 0: none)
+    TUNE_OCC_PRIORITY,       // the occlusion stream's priority: 0 = the lowest the device offers, 1 = the handle's stream's
     TUNE_SWEEP_DEBUG,        // timing diagnostics of the sweep kernel; non-zero values give WRONG light volumes (SweepParams::debug)
     TUNE_COUNT
 };

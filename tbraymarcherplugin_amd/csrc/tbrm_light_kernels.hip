@@ -367,7 +367,10 @@ hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStr
 }
 
 template <int DFMT, int MODE, int AXIS>
-__global__ __launch_bounds__(256) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
+#ifndef TBRM_OCC_WAVES_PER_EU
+#define TBRM_OCC_WAVES_PER_EU 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WAVES_PER_EU, 8))) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NS = (MODE == PASS_ADD || MODE == PASS_CHANGE_ONE) ? 1 : 2; // PASS_CHANGE_ONE: one stream with the Change shader's rules

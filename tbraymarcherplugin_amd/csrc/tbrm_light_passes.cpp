@@ -8,7 +8,9 @@
 
 #include <algorithm>
 #include <climits>
+#include <chrono>
 #include <cmath>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -464,7 +466,7 @@ static int ensure_occ_stream(tbrm_resources* r)
     if (r->occ_stream) return TBRM_OK;
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least));
+    HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, tune(TUNE_OCC_PRIORITY) == 1 ? 0 : least));
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], hipEventDisableTiming));
@@ -1226,6 +1228,25 @@ struct PassSpec {
 
 // Runs the axis passes of one operator in order. Every pass is planned before anything is enqueued: a pass the chunk
 // kernels decline takes the one-slice-per-launch path, any other planning failure leaves the light volume untouched.
+// diagnostics (sweep_debug bit 2): where the host's time goes while an operator is enqueued
+struct HostProbe {
+    const char* what;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    std::string line;
+    explicit HostProbe(const char* w) : what(w), on((tune(TUNE_SWEEP_DEBUG) & 4) != 0), t(std::chrono::steady_clock::now()) {}
+    void lap(const char* name)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        char buf[64];
+        snprintf(buf, sizeof(buf), " %s %.0f us", name, std::chrono::duration<double, std::micro>(now - t).count());
+        line += buf;
+        t = now;
+    }
+    ~HostProbe() { if (on) fprintf(stderr, "[tbrm host] %s:%s\n", what, line.c_str()); }
+};
+
 int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs)
 {
     if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)
@@ -1236,6 +1257,7 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
     } unpin{r};
     std::vector<PassPlan> plans;
     std::vector<char> chunked;
+    HostProbe probe("run_passes");
     for (size_t i = 0; i < specs.size(); ++i) {
         const PassSpec q = specs[i];
         PassPlan plan;
@@ -1254,6 +1276,7 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         if (e != TBRM_OK && e != TBRM_ERR_UNSUPPORTED) return e;
         plans.push_back(plan);
         chunked.push_back(e == TBRM_OK ? 1 : 0);
+        probe.lap("plan");
     }
     for (size_t i = 0; i < specs.size(); ++i) {
         const PassSpec& q = specs[i];
@@ -1269,8 +1292,10 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         if (int e = enqueue_sweep_occlusion(r, plans[i])) { quiesce_occ_stream(r); return e; }
         if (next)
             if (int e = enqueue_sweep_occlusion(r, *next)) { quiesce_occ_stream(r); return e; }
+        probe.lap("occlusion");
         for (int c = 0; c < plans[i].n_chunks; ++c)
             if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e; // (enqueue_plan_chunk has drained the second stream)
+        probe.lap("pass");
     }
     return TBRM_OK;
 }

@@ -52,20 +52,32 @@
 namespace tbrm {
 
 constexpr int kSweepTile = 32;
-constexpr int kSweepRS = 48, kSweepRows = 48;          // LDS plane: row stride / rows (tile + halo <= 14 + guard ring)
-constexpr int kSweepPlane = kSweepRS * kSweepRows;
+// LDS plane: 48 x 48 cells (tile + halo <= 14 + guard ring), COLUMN-major — a pixel's two taps of one column (rows iy, iy + 1)
+// are neighbours in memory and arrive as one register pair, ready for a packed lerp along x over (top, bottom) — with a
+// column stride of 49 floats: the 32 columns of a wave's lanes fall into 32 different banks
+constexpr int kSweepCols = 48, kSweepCS = 49;
+constexpr int kSweepPlane = kSweepCols * kSweepCS;
 constexpr int kSweepLvBrick = 528;                     // bytes per staged light-volume brick: 512 + 16, so that the four bricks
                                                        // under a tile row start 4 banks apart
-constexpr int kSweepRing = 8;                          // register ring of requested factors / hand-off words (slices)
-constexpr int kSweepFactorAhead = 6;                   // slices ahead that the occlusion factors are requested
+constexpr int kSweepRing = 8;                          // register ring of requested hand-off words (slices)
 constexpr int kSweepComputeWaves = 8;
-constexpr int kSweepThreads = (kSweepComputeWaves + 1) * 64;
+// + the hand-off wave + one factor loader per stream (an LDS-DMA costs its wave 60 - 180 cycles of issue: the eight of a
+// two-stream slice in one wave took longer than the slice)
+constexpr int sweep_threads(int mode) { return (kSweepComputeWaves + 1 + (mode == PASS_CHANGE ? 2 : 1)) * 64; }
 constexpr int kSweepFlagGroups = 128;                  // slice groups of a span (1024 slices)
+constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x 16 block slice of occlusion factors: the four
+                                                       // blocks under a tile start 16 banks apart (a lane pair's columns c, c + 16)
+
+// slots of the LDS ring of factor slices; the loader runs one less ahead. One-stream slices are short: 8; a two-stream pass
+// leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
+constexpr int sweep_factor_slots(int mode) { return mode == PASS_CHANGE ? 4 : 8; }
 
 size_t sweep_lds_bytes(int mode)
 {
     const int ns = mode == PASS_CHANGE ? 2 : 1;
-    return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * kSweepFlagGroups * 4; // planes, three brick layers, block ranks
+    // planes, three brick layers, block ranks, the ring of factor slices
+    return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * kSweepFlagGroups * 4 +
+           (size_t) sweep_factor_slots(mode) * ns * 4 * kSweepFBlock * 4;
 }
 
 int sweep_max_slices() { return 8 * kSweepFlagGroups; }
@@ -94,6 +106,18 @@ __device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch,
     return w;
 }
 
+// One block slice of occlusion factors (64 lanes x 16 bytes = the 256 floats of a 16 x 16 block) from global memory straight
+// into LDS at `lds_dst` (wave-uniform byte address) + lane * 16: no registers, counted by vmcnt like any load — but invisible
+// to the compiler's own wait-count bookkeeping, which is the point: the loader waits with sweep_wait_loads<N>() for exactly
+// the slices it needs (cdna_hip_programming.md, "LDS-DMA recipe").
+__device__ __forceinline__ void sweep_dma_block(const void* src, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void sweep_wait_loads() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // two pixels (the two rows of a compute lane) per instruction
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -115,17 +139,17 @@ __device__ __forceinline__ v2f quantize2(v2f x)                                 
 // HC: 64-word chunks of hand-off words per slice. RREC (PASS_CHANGE): stream r's halo comes from the records of an earlier
 // PASS_PLANES launch (SweepParams::r_from_records). MODE PASS_PLANES: one stream, the light volume untouched.
 template <int MODE, int AXIS, int PF, int HC, bool RREC = false>
-__global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams p, const SweepParams q)
+__global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const ChunkParams p, const SweepParams q)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
-    constexpr int T = kSweepTile, RS = kSweepRS, PLANE = kSweepPlane, LVB = kSweepLvBrick;
-    constexpr int R = 2, NWC = kSweepComputeWaves, NTC = NWC * 64, NT = kSweepThreads;
+    constexpr int T = kSweepTile, CS = kSweepCS, PLANE = kSweepPlane, LVB = kSweepLvBrick;
+    constexpr int R = 2, NWC = kSweepComputeWaves, NTC = NWC * 64, NT = sweep_threads(MODE);
     constexpr int NS = MODE == PASS_CHANGE ? 2 : 1;
     constexpr bool LV = MODE != PASS_PLANES; // the light volume is updated
     static_assert(!RREC || MODE == PASS_CHANGE, "only a fused Change takes a stream from records");
-    constexpr int RING = kSweepRing, FA = kSweepFactorAhead;
-    static_assert(PF >= 1 && PF < RING && FA < RING, "the request rings hold 8 slices");
+    constexpr int RING = kSweepRing;
+    static_assert(PF >= 1 && PF < RING, "the request ring holds 8 slices");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
 
     // ---- which tile: tickets in upstream-first order -------------------------------------------------------------------
@@ -150,11 +174,15 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
     auto plane = [&](int buf, int si) -> float* { return lds + (buf * NS + si) * PLANE; };
     uint8_t* const lvt = (uint8_t*) (lds + 2 * NS * PLANE);
     int32_t* const sslot = (int32_t*) (lvt + 3 * 16 * LVB); // [si][2 x 2 blocks][slice group]: rank of the block, < 0: flagged empty
+    // the ring of factor slices, [slot][si][2 x 2 blocks][kSweepFBlock]: filled FS - 1 slices ahead by the loader wave
+    float* const fring = (float*) (sslot + NS * 4 * kSweepFlagGroups);
+    constexpr int FS = sweep_factor_slots(MODE); // (divides the loop's eight slices: a slice's slot is a constant)
+    constexpr int kFSlot = NS * 4 * kSweepFBlock; // floats per slot
     auto stream = [&](int si) -> const ChunkStream& { return si == 0 ? p.a : p.r; };
 
     // ---- the planes before the span's first slice ------------------------------------------------------------------------
     for (int i = threadIdx.x; i < PLANE; i += NT) {
-        const int cy = i / RS, cx = i - cy * RS;
+        const int cx = i / CS, cy = i - cx * CS;
         const int gx = base_x + cx - ox, gy = base_y + cy - oy;
         const bool in = (unsigned) gx < (unsigned) p.W && (unsigned) gy < (unsigned) p.H;
 #pragma unroll
@@ -237,7 +265,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                 const bool on = w < RW;
                 if (w < T * hx) { cy = w / max(hx, 1); cx = e0x + (w - cy * hx); }
                 else { const int m = w - T * hx; cy = e0y + m / T; cx = m % T; }
-                pub_cell[h] = on ? (oy + cy) * RS + ox + cx : -1;
+                pub_cell[h] = on ? (ox + cx) * CS + oy + cy : -1;
             }
             const int nx = T * hx, ny = T * hy, nc = hx * hy;
             int ntx = tile_x, nty = tile_y, word = 0, cxh = 0, cyh = 0; // neighbour tile, its word, the halo cell in tile coordinates
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                  (unsigned) (base_x + cxh) < (unsigned) p.W && (unsigned) (base_y + cyh) < (unsigned) p.H;
             if (q.debug & 1) on = false;
             hal_on[h] = on;
-            hal_dst[h] = (oy + cyh) * RS + ox + cxh;
+            hal_dst[h] = (ox + cxh) * CS + oy + cyh;
             hal_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * RW + word) : 0u;
         }
         // RREC: stream r's halo cells, the same construction with stream r's geometry; their words were written by the launch
@@ -287,7 +315,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                 on = on && (unsigned) ntx < (unsigned) p.tiles_x && (unsigned) nty < (unsigned) p.tiles_y &&
                      (unsigned) (base_x + cxh) < (unsigned) p.W && (unsigned) (base_y + cyh) < (unsigned) p.H;
                 rh_on[h] = on;
-                rh_dst[h] = (oy + cyh) * RS + ox + cxh;
+                rh_dst[h] = (ox + cxh) * CS + oy + cyh;
                 rh_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * r_RW + word) : 0u;
             }
         }
@@ -308,6 +336,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
             if constexpr (SL < PF) request_halo(SL, sl); // (n >= 8 > PF)
         }, std::make_integer_sequence<int, RING>{});
 
+        lds_barrier(); // (the loader's first factor slice is in LDS)
         __builtin_amdgcn_s_setprio(3); // (its few instructions go first: what it publishes is what the neighbours wait for)
         auto group = [&](int g, auto last_c) {
             constexpr bool LAST = decltype(last_c)::value;
@@ -354,6 +383,65 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
         };
         for (int g = 0; g < G - 1; ++g) group(g, std::false_type{});
         group(G - 1, std::true_type{});
+    } else if (wave > NWC) {
+        // ================================================= the factor loader =====================================================
+        // Block-compact hand-over (ChunkStream::fs_*): per slice group each of the tile's 2 x 2 occlusion blocks of a stream
+        // is 8 slices x 1 KiB, found through the block's rank among the pass's live blocks — in the cache entry being filled
+        // or read, or in the scratch store beyond the entry's capacity; a flagged-empty block (k_occ_flags) was never
+        // computed: its factor 1 - 0 comes from a page of ones. One wave per stream, one LDS-DMA per block slice, FS - 1
+        // slices ahead of the compute waves; per slice the wave waits until the NEXT slice's 4 loads have landed, then joins
+        // the barrier behind which that slice is read. (Past the last slice the last one is requested again, into slots already
+        // consumed: the count of loads in flight stays what the waits assume.)
+        constexpr int L = 4; // loads per slice
+        constexpr int A = FS - 1;
+        const int lsi = NS > 1 ? wave - (NWC + 1) : 0;
+        const ChunkStream& st = stream(lsi);
+        const int32_t* const ranks = sslot + lsi * 4 * kSweepFlagGroups;
+        const uint8_t* src[4]; // of the slice requested next
+        uint32_t step[4];
+        auto rebase = [&](int zg) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int32_t slot = ranks[b * kSweepFlagGroups + zg];
+                const bool one = slot < 0;
+                const float* const base = one ? p.ones : ((uint32_t) slot < st.fs_cap ? st.fs_keep + (size_t) (uint32_t) slot * 2048 : st.fs_spill + (size_t) ((uint32_t) slot - st.fs_cap) * 2048);
+                src[b] = (const uint8_t*) base + lane * 16;
+                step[b] = one ? 0u : 1024u;
+            }
+        };
+        const uint32_t ring_lds = (uint32_t) (uintptr_t) fring + (uint32_t) (lsi * 4 * kSweepFBlock * 4); // (a flat LDS address: its low half is the LDS byte address)
+        int req = 0;       // slice requested next
+        int req_slot = 0;  // its ring slot
+        auto request = [&]() {
+            if constexpr (!(TBRM_SWEEP_EXP & 2)) {
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t) req_slot * (uint32_t) (kFSlot * 4));
+#pragma unroll
+                for (int b = 0; b < 4; ++b) sweep_dma_block(src[b], dst + (uint32_t) (b * kSweepFBlock * 4));
+            }
+            req_slot = req_slot + 1 == FS ? 0 : req_slot + 1;
+            if (req + 1 < n) {
+                ++req;
+                if ((req & 7) == 0) rebase(req >> 3);
+                else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) src[b] += step[b];
+                }
+            }
+        };
+        auto landed = [&]() { // everything but the last A - 1 slices' loads
+            sweep_wait_loads<(A - 1) * L>();
+        };
+        __builtin_amdgcn_s_setprio(3); // (like the hand-off wave: few instructions, and every other wave waits for them at the barrier)
+        rebase(0);
+        for (int t = 0; t < A; ++t) request();
+        landed(); // slice 0
+        lds_barrier();
+        for (int s = 0; s < n; ++s) {
+            request(); // slice s + A, into the slot slice s - 1 was read from
+            landed();  // slice s + 1
+            if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
+        }
+        sweep_wait_loads<0>();
     } else {
         // =================================================== the compute waves ===================================================
         const int c = lane & 31, r0 = (wave * 2 + (lane >> 5)) * R;
@@ -371,7 +459,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
         for (int k = 0; k < R; ++k) {
             const int r = r0 + k, py = base_y + r;
             in_pl[k] = in_x && py < p.H;
-            own[k] = (oy + r) * RS + ox + c;
+            own[k] = (ox + c) * CS + oy + r;
             own_idx[k] = in_pl[k] ? (uint32_t) (py * p.W + px) : 0u;
             const uint32_t lb = (uint32_t) ((r >> 3) * 4 + (c >> 3)) * (uint32_t) LVB;
             if (AXIS == 0) lv_at[k] = lb + (uint32_t) (r & 7) * 64u + (uint32_t) (c & 7) * 8u;
@@ -410,7 +498,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     bad = bad || (gsy >= 0 ? (lo < 0 || hi > ghy) : (lo < -ghy || hi > 0));
                 }
                 fy2[k] = fy;
-                tap[si][k] = own[k] + (in_pl[k] ? iy * RS + ix : 0);
+                tap[si][k] = own[k] + (in_pl[k] ? ix * CS + iy : 0);
             }
             wfy[si].x = fy2[0]; wfy[si].y = fy2[1];
         }
@@ -422,44 +510,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                 for (int k = 0; k < R; ++k) tap[si][k] = own[k];
         }
 
-        // ---- occlusion factors: requested FA slices ahead, one register per pixel and slice -------------------------------------
-        // Block-compact hand-over (ChunkStream::fs_*): per slice group a lane's two pixels lie in one 16 x 16 x 8 block, whose
-        // rank among the pass's live blocks says where its factors are — the cache entry being filled or read, or the scratch
-        // store beyond the entry's capacity; a flagged-empty block (k_occ_flags) was never computed: its factor 1 - 0 comes
-        // from a page of ones, as does that of a pixel beyond the buffer. One pointer per pixel, advanced by a slice per slice.
-        const int blk = ((r0 >> 4) << 1) | (c >> 4);
-        float freg[RING][NS][R];
-        const float* f_ptr[NS][R]; // of the slice being requested next
-        uint32_t f_step[NS];
-        auto new_group = [&](int zg) { // the requests move on to slice group zg
-#pragma unroll
-            for (int si = 0; si < NS; ++si) {
-                const ChunkStream& st = stream(si);
-                const int32_t slot = sslot[(si * 4 + blk) * kSweepFlagGroups + zg];
-                const bool one = slot < 0;
-                const float* const blk_base = (uint32_t) slot < st.fs_cap ? st.fs_keep + (size_t) (uint32_t) slot * 2048 : st.fs_spill + (size_t) ((uint32_t) slot - st.fs_cap) * 2048;
-                f_step[si] = one ? 0u : 256u;
-#pragma unroll
-                for (int k = 0; k < R; ++k)
-                    f_ptr[si][k] = (one || !in_pl[k]) ? p.ones + lane : blk_base + ((r0 + k) & 15) * 16 + (c & 15);
-            }
-        };
-        auto request_factors = [&](auto slot_c) { // the next slice into ring slot SLOT
-            constexpr int SLOT = decltype(slot_c)::value;
-#pragma unroll
-            for (int si = 0; si < NS; ++si)
-#pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    if constexpr (TBRM_SWEEP_EXP & 2) freg[SLOT][si][k] = 1.0f;
-                    else freg[SLOT][si][k] = *f_ptr[si][k];
-                    f_ptr[si][k] += in_pl[k] ? f_step[si] : 0u;
-                }
-        };
-        new_group(0);
-        sweep_each_const([&](auto sl) {
-            constexpr int SL = decltype(sl)::value;
-            if constexpr (SL < FA) request_factors(sl);
-        }, std::make_integer_sequence<int, RING>{});
+        // ---- occlusion factors: out of the LDS ring the loader wave fills (one block slice = 16 x 16 floats, blocks 272 apart) ----
+        const float* const f_lane = fring + (((r0 >> 4) << 1) | (c >> 4)) * kSweepFBlock + (r0 & 15) * 16 + (c & 15);
+        lds_barrier();  // (the loader's first factor slice is in LDS)
 
         const float thresh = 1e-3f;
         // The light-volume update of a slice (:123-126 / ChangeDirLightShader.usf:152-154) runs one slice late, between the
@@ -492,39 +545,63 @@ __global__ __launch_bounds__(kSweepThreads) void k_light_sweep(const ChunkParams
                     *(uint4*) ((uint8_t*) piece_lds + ((g + 1) % 3) * kLvBuf) = lv_next;
                     lv_next = load_layer(g + 2);
                 }
-                // the factors of the slice FA ahead
-                if constexpr (K8 + FA < 8) request_factors(std::integral_constant<int, K8 + FA>{});
-                else if constexpr (!LAST) {
-                    if constexpr (K8 + FA == 8) new_group(g + 1);
-                    request_factors(std::integral_constant<int, (K8 + FA) & 7>{});
-                }
                 // LDS reads: the voxels of the slice before, this slice's taps
                 uint32_t code_old[R] = {0, 0};
                 if constexpr (LV) {
 #pragma unroll
                     for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
                 }
-                v2f t00[NS], t01[NS], t10[NS], t11[NS];
+                // per stream and row: the taps' two columns, each (row iy, row iy + 1)
+                v2f ca[NS][R], cb[NS][R], fac[NS];
+                const float* const f_at = f_lane + (K8 % FS) * kFSlot;
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
-                    const float *pa = plane(CUR, si) + tap[si][0], *pb = plane(CUR, si) + tap[si][1];
-                    t00[si].x = pa[0]; t01[si].x = pa[1]; t10[si].x = pa[RS]; t11[si].x = pa[RS + 1];
-                    t00[si].y = pb[0]; t01[si].y = pb[1]; t10[si].y = pb[RS]; t11[si].y = pb[RS + 1];
+                    if constexpr (TBRM_SWEEP_EXP & 2) fac[si] = (v2f) 1.0f;
+                    else { fac[si].x = f_at[si * 4 * kSweepFBlock]; fac[si].y = f_at[si * 4 * kSweepFBlock + 16]; }
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const float* const pt = plane(CUR, si) + tap[si][k];
+                        ca[si][k].x = pt[0]; ca[si][k].y = pt[1];
+                        cb[si][k].x = pt[CS]; cb[si][k].y = pt[CS + 1];
+                    }
                 }
                 if constexpr (LV && !(TBRM_SWEEP_EXP & 1))
                     if (K8 > 0 || g > 0) light_volume_update(code_old);
-                // this slice
-                v2f pval[NS];
+                // this slice, operation by operation over the streams: a slice is one dependent chain per stream, and the two
+                // chains of a Change are independent — side by side they fill each other's issue gaps
+                v2f pval[NS], xa[NS], qc[NS];
+                // previous slice, bilinear with border colour (AddDirLightShader.usf:81-82): along x for (top, bottom) at once,
+                // then along y; times 1 - CurrentSample (:117)
+#pragma unroll
+                for (int si = 0; si < NS; ++si)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) cb[si][k] = cb[si][k] - ca[si][k];
+#pragma unroll
+                for (int si = 0; si < NS; ++si)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) ca[si][k] = fma2((v2f) wfx[si], cb[si][k], ca[si][k]);
+#pragma unroll
+                for (int si = 0; si < NS; ++si) {
+                    const float d0 = ca[si][0].y - ca[si][0].x, d1 = ca[si][1].y - ca[si][1].x;
+                    xa[si].x = __builtin_fmaf(wfy[si].x, d0, ca[si][0].x);
+                    xa[si].y = __builtin_fmaf(wfy[si].y, d1, ca[si][1].x);
+                }
+#pragma unroll
+                for (int si = 0; si < NS; ++si) lv_l[si] = xa[si] * fac[si];
+                // WriteBuffer[PixelLoc] = L (:120), as a read of it returns it: quantize_u8, decode_u8f
+#pragma unroll
+                for (int si = 0; si < NS; ++si) { qc[si].x = __builtin_amdgcn_fmed3f(lv_l[si].x, 0.0f, 1.0f); qc[si].y = __builtin_amdgcn_fmed3f(lv_l[si].y, 0.0f, 1.0f); }
+#pragma unroll
+                for (int si = 0; si < NS; ++si) qc[si] = qc[si] * (v2f) 255.0f;
+#pragma unroll
+                for (int si = 0; si < NS; ++si) qc[si] = qc[si] + (v2f) 0.5f;
+#pragma unroll
+                for (int si = 0; si < NS; ++si) { qc[si].x = __builtin_floorf(qc[si].x); qc[si].y = __builtin_floorf(qc[si].y); }
+#pragma unroll
+                for (int si = 0; si < NS; ++si) pval[si] = decode2(qc[si]);
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
                     const ChunkStream& st = stream(si);
-                    // previous slice, bilinear with border colour (AddDirLightShader.usf:81-82), times 1 - CurrentSample (:117)
-                    const v2f fx = (v2f) wfx[si];
-                    const v2f prev = lerp2(lerp2(t00[si], t01[si], fx), lerp2(t10[si], t11[si], fx), wfy[si]);
-                    v2f fac;
-                    fac.x = freg[K8][si][0]; fac.y = freg[K8][si][1];
-                    lv_l[si] = prev * fac;
-                    pval[si] = decode2(quantize2(lv_l[si])); // WriteBuffer[PixelLoc] = L (:120), as a read of it returns it
                     plane(CUR ^ 1, si)[own[0]] = in_pl[0] ? pval[si].x : st.border_light;
                     plane(CUR ^ 1, si)[own[1]] = in_pl[1] ? pval[si].y : st.border_light;
                 }
@@ -573,8 +650,8 @@ template <int MODE, int AXIS, int PF, int HC, bool RREC = false>
 static hipError_t launch_sweep5(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC>, attr_done, 96 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC>), dim3(p.tiles_x * p.tiles_y), dim3(kSweepThreads), sweep_lds_bytes(MODE), s, p, q);
+    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC>, attr_done, 159 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE)), sweep_lds_bytes(MODE), s, p, q);
     return hipGetLastError();
 }
 template <int MODE, int AXIS, int PF>
