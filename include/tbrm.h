@@ -178,7 +178,7 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * load; 4 / 8), chain_fast_loop (1), chain_rect_planes (1), occ_overlap (2 = workgroups per CU of an occlusion launch that
  * runs beside a chunked chain; 0 = one after the other), light_sweep (1 = axis passes take the pipelined sweep kernel where
  * it applies; 2 = except the passes of a Change whose two lights pull opposite ways, which otherwise take two sweeps; 0 = the
- * chunked chain everywhere), sweep_prefetch (0 = 3 slices), sweep_stagger_ns (0 = default start delay per
+ * chunked chain everywhere), sweep_prefetch (0 = 2 slices), sweep_stagger_ns (0 = default start delay per
  * tile of distance, < 0 none), sweep_rows (unused), sweep_debug (timing diagnostics; non-zero bit 0 gives WRONG light
  * volumes). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
