@@ -153,11 +153,13 @@ PropParams base_prop_params(const tbrm_resources* r, const tbrm_world_params& wo
 
 int begin_timed(tbrm_resources* r, int kind)
 {
+    if (tune(TUNE_SWEEP_DEBUG) & 32) return TBRM_OK;
     HIP_TRY(hipEventRecord(r->ev[kind][0], r->stream));
     return TBRM_OK;
 }
 int end_timed(tbrm_resources* r, int kind)
 {
+    if (tune(TUNE_SWEEP_DEBUG) & 32) return TBRM_OK;
     HIP_TRY(hipEventRecord(r->ev[kind][1], r->stream));
     r->ev_valid[kind] = true;
     return TBRM_OK;

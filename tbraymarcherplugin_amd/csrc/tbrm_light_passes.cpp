@@ -951,8 +951,8 @@ int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
     FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
     hipStream_t s = r->occ_stream;
     // the buffers about to be overwritten may still be read by an earlier sweep
-    if (f.used) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
-    if (e && e->read_yet) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
+    if (f.used && !(tune(TUNE_SWEEP_DEBUG) & 8)) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
+    if (e && e->read_yet && !(tune(TUNE_SWEEP_DEBUG) & 16)) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
     ChunkParams p = plan.p;
     p.occ_flags_out = f.flags;
     p.occ_list_out = f.list;
