@@ -34,7 +34,7 @@ struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
-    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
+    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -375,7 +375,12 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     } while (0)
 
     CREATE_TRY(hipSetDevice(desc->device));
-    CREATE_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        CREATE_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int want = tune(TUNE_STREAM_PRIORITY);
+        CREATE_TRY(hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, want > 0 ? greatest : (want < 0 ? least : 0)));
+    }
     if (hipDeviceGetAttribute(&r->n_cus, hipDeviceAttributeMultiprocessorCount, desc->device) != hipSuccess || r->n_cus <= 0) r->n_cus = 256;
     {
         tbrm_resources::Residency& q = r->res_data;

@@ -268,6 +268,8 @@ enum Tunable : int {
     TUNE_SWEEP_ROWS,         // (unused: a sweep lane owns two rows)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
     TUNE_SWEEP_STAGGER_NS,   // start delay of a sweep tile per tile of distance from the upstream corner, ns (0: default; < 0: none)
+    TUNE_STREAM_PRIORITY,    // priority of a handle's own stream, read when the handle is created: 0 = default, 1 = the highest the
+                             // device offers, -1 = the lowest
     TUNE_OCC_PRIORITY,       // the occlusion stream's priority: 0 = the lowest the device offers, 1 = the handle's stream's
     TUNE_SWEEP_DEBUG,        // diagnostics. 1: sweep tiles do not wait for each other (WRONG results), 2: per-tile time stamps, 4: host
                              // time per operator phase on stderr, 8 / 16: the occlusion stream skips its waits for the scratch

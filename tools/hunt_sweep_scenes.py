@@ -28,4 +28,6 @@ for seed in range(lo, hi):
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("SEED", seed, "FAILED:", str(e)[:300], flush=True)
+    if (seed - lo) % 50 == 49:
+        print("... through seed", seed, "failures", bad, flush=True)
 print("sweep-scene hunt seeds", lo, hi, "failures", bad, "sweep launches", sweeps, "chain launches", chunks, flush=True)
