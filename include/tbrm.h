@@ -179,7 +179,8 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * runs beside a chunked chain; 0 = one after the other), light_sweep (1 = axis passes take the pipelined sweep kernel where
  * it applies; 2 = except the passes of a Change whose two lights pull opposite ways, which otherwise take two sweeps; 0 = the
  * chunked chain everywhere), sweep_prefetch (0 = 2 slices), sweep_stagger_ns (0 = default start delay per
- * tile of distance, < 0 none), sweep_rows (unused), occ_priority (0 = the occlusion stream has the lowest priority the device
+ * tile of distance, < 0 none), sweep_rows (unused), stream_priority (of a handle's own stream, read by tbrm_resources_create: 0 = default, 1 = highest, -1 = lowest),
+ * occ_priority (0 = the occlusion stream has the lowest priority the device
  * offers, 1 = the handle's stream's; read when the handle first needs the stream), sweep_debug (diagnostics: bit 0 tiles do not
  * wait for each other, bits 3 / 4 skip buffer hazards — WRONG light volumes —; bit 1 prints per-tile time stamps at tbrm_flush,
  * bit 2 the host's time per operator phase, bit 5 leaves out the events behind tbrm_last_gpu_time_ms). Unknown name: TBRM_ERR_INVALID_ARG. */
