@@ -409,7 +409,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
     if (!p.occ_list && p.occ_flags && p.occ_flags[id]) continue; // list off (A/B runs)
     if (gy < p.roi_by0 || gy >= p.roi_by1) continue;             // dense span of a slab-partitioned pass
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
-    const int nk = min(kOccDepth, p.n_steps - k0);
+#ifndef TBRM_OCC_EXP
+#define TBRM_OCC_EXP 0 // timing experiments (WRONG results): 1 = no sample loop (what the per-workgroup setup costs), 2 = no brick staging
+#endif
+    const int nk = (TBRM_OCC_EXP & 1) ? 0 : min(kOccDepth, p.n_steps - k0);
 
     s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
     if (threadIdx.x < NS * kOccDepth) { // slice-axis taps of each step of this workgroup (wave-uniform values)
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
         const int wave_base = (threadIdx.x >> 6) * 64, lane = threadIdx.x & 63;
         for (int cb = wave_base; cb < total; cb += 256) {
             const int c = cb + lane;
-            if (c < total) {
+            if (c < total && !(TBRM_OCC_EXP & 2)) {
                 const uint32_t gb = s_brick[c / PIECES];
                 dma_16((const char*) p.data.data + ((size_t) gb * 512 * ESZ + (size_t) (c % PIECES) * 16), smem + (size_t) cb * 16);
             }

@@ -13,7 +13,7 @@ hipcc $FLAGS -c -x hip $CS/tbrm_kernels.hip -o $OUT/tbrm_kernels.o &
 hipcc $FLAGS -c -x hip $CS/tbrm_light_sweep.hip -o $OUT/sweep.o &
 hipcc $FLAGS -DTBRM_CHAIN_LFMT=0 -c -x hip $CS/tbrm_light_chain.hip -o $OUT/chain_u8.o &
 hipcc $FLAGS -DTBRM_CHAIN_LFMT=2 -c -x hip $CS/tbrm_light_chain.hip -o $OUT/chain_f32.o &
-for e in "$@"; do hipcc $FLAGS -DTBRM_OCC_WAVES_PER_EU=$e -c -x hip $CS/tbrm_light_kernels.hip -o $OUT/lk_$e.o & done
+for e in "$@"; do hipcc $FLAGS ${OCC_DEFS:--DTBRM_OCC_WAVES_PER_EU=$e} -DTBRM_OCC_TAG=$e -c -x hip $CS/tbrm_light_kernels.hip -o $OUT/lk_$e.o & done
 wait
 for e in "$@"; do
   hipcc --offload-arch=gfx950 -shared -fPIC -fvisibility=hidden $OUT/tbrm_api.o $OUT/tbrm_light_passes.o $OUT/tbrm_host_math.o $OUT/tbrm_kernels.o $OUT/lk_$e.o $OUT/chain_u8.o $OUT/chain_f32.o $OUT/sweep.o -o $OUT/libtbrm_occ$e.so
