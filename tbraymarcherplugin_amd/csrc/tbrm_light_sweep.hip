@@ -665,7 +665,7 @@ static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipS
     if constexpr (MODE == PASS_CHANGE) {
         if (q.r_from_records) { // (sweep_fit: both streams' words fit three per lane)
             const int hc2 = std::max(hc, sweep_halo_chunks(q.r_hx, q.r_hy));
-            if (hc2 <= 3) return launch_sweep5<MODE, AXIS, 3, 3, true>(p, q, s);
+            if (hc2 <= 3) return launch_sweep5<MODE, AXIS, 2, 3, true>(p, q, s);
             if (hc2 <= 6) return launch_sweep5<MODE, AXIS, 3, 6, true>(p, q, s);
             return hipErrorInvalidConfiguration;
         }
