@@ -289,7 +289,7 @@ hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStr
 hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s);
-size_t sweep_lds_bytes(int mode);
+size_t sweep_lds_bytes(int mode, int slices);
 int sweep_halo_chunks(int hx, int hy);
 int sweep_max_slices();
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);

@@ -72,11 +72,12 @@ constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x
 // leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
 constexpr int sweep_factor_slots(int mode) { return mode == PASS_CHANGE ? 4 : 8; }
 
-size_t sweep_lds_bytes(int mode)
+size_t sweep_lds_bytes(int mode, int slices)
 {
     const int ns = mode == PASS_CHANGE ? 2 : 1;
+    const int groups = (slices + 7) / 8; // (the rank table is as long as the pass: every KiB not taken is the occlusion workgroups')
     // planes, three brick layers, block ranks, the ring of factor slices
-    return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * kSweepFlagGroups * 4 +
+    return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * groups * 4 +
            (size_t) sweep_factor_slots(mode) * ns * 4 * kSweepFBlock * 4;
 }
 
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     uint8_t* const lvt = (uint8_t*) (lds + 2 * NS * PLANE);
     int32_t* const sslot = (int32_t*) (lvt + 3 * 16 * LVB); // [si][2 x 2 blocks][slice group]: rank of the block, < 0: flagged empty
     // the ring of factor slices, [slot][si][2 x 2 blocks][kSweepFBlock]: filled FS - 1 slices ahead by the loader wave
-    float* const fring = (float*) (sslot + NS * 4 * kSweepFlagGroups);
+    float* const fring = (float*) (sslot + NS * 4 * G);
     constexpr int FS = sweep_factor_slots(MODE); // (divides the loop's eight slices: a slice's slot is a constant)
     constexpr int kFSlot = NS * 4 * kSweepFBlock; // floats per slot
     auto stream = [&](int si) -> const ChunkStream& { return si == 0 ? p.a : p.r; };
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         }
     }
     // the tile's 2 x 2 occlusion blocks in every slice group of the span: their ranks among the pass's live blocks
-    for (int i = threadIdx.x; i < NS * 4 * kSweepFlagGroups; i += NT) {
-        const int si = i / (4 * kSweepFlagGroups), blk = (i / kSweepFlagGroups) & 3, zg = i % kSweepFlagGroups;
+    for (int i = threadIdx.x; i < NS * 4 * G; i += NT) {
+        const int si = i / (4 * G), blk = (i / G) & 3, zg = i % G;
         const int bx = (base_x >> 4) + (blk & 1), by = (base_y >> 4) + (blk >> 1);
         int32_t slot = -1;
         if (zg < G && bx < p.occ_blocks_x && by < p.occ_blocks_y) slot = stream(si).fs_slot[((size_t) zg * p.occ_blocks_y + by) * p.occ_blocks_x + bx];
@@ -396,13 +397,13 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         constexpr int A = FS - 1;
         const int lsi = NS > 1 ? wave - (NWC + 1) : 0;
         const ChunkStream& st = stream(lsi);
-        const int32_t* const ranks = sslot + lsi * 4 * kSweepFlagGroups;
+        const int32_t* const ranks = sslot + lsi * 4 * G;
         const uint8_t* src[4]; // of the slice requested next
         uint32_t step[4];
         auto rebase = [&](int zg) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int32_t slot = ranks[b * kSweepFlagGroups + zg];
+                const int32_t slot = ranks[b * G + zg];
                 const bool one = slot < 0;
                 const float* const base = one ? p.ones : ((uint32_t) slot < st.fs_cap ? st.fs_keep + (size_t) (uint32_t) slot * 2048 : st.fs_spill + (size_t) ((uint32_t) slot - st.fs_cap) * 2048);
                 src[b] = (const uint8_t*) base + lane * 16;
@@ -651,7 +652,7 @@ static hipError_t launch_sweep5(const ChunkParams& p, const SweepParams& q, hipS
 {
     static std::atomic<uint64_t> attr_done{0};
     if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC>, attr_done, 159 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE)), sweep_lds_bytes(MODE), s, p, q);
+    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE)), sweep_lds_bytes(MODE, p.n_steps), s, p, q);
     return hipGetLastError();
 }
 template <int MODE, int AXIS, int PF>
