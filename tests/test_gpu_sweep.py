@@ -270,3 +270,26 @@ def test_random_operator_sequences_on_whole_brick_layers(gpu, oracle_mod, tunabl
     after every operator the UNORM8 light volume is the oracle's, bit for bit."""
     c = run_random_sweep_scene(oracle_mod, seed, tunables)
     assert c["slice"] == 0 or c["sweep"] > 0, c
+
+
+@pytest.mark.parametrize("dims", [(40, 32, 8), (8, 48, 40), (16, 16, 16), (32, 8, 24)])
+def test_passes_of_one_and_two_brick_layers(gpu, oracle_mod, dims):
+    """The shortest passes the sweep takes (8 and 16 slices: the factor ring is longer than the pass, the loader's requests
+    run past its end from the start): Adds, a fused Change, a removal."""
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, np.uint8, seed=0x5EED0905)
+    with res:
+        ls = [abi.DirLightParams(d, i) for d, i in [((1, .3, -.2), 0.5), ((-.2, 1, .3), 0.6), ((.25, -.3, -1), 0.7)]]
+        for l in ls:
+            res.add_dir_light(l, True, world)
+            orc.add_dir_light(l, True, world)
+        same(res, orc, f"{dims} adds")
+        for l in ls:
+            new = abi.DirLightParams(S.rotate_z((l.light_direction.x, l.light_direction.y, l.light_direction.z), 4.0), l.light_intensity)
+            res.change_dir_light(l, new, world)
+            orc.change_dir_light(l, new, world)
+        same(res, orc, f"{dims} changes")
+        res.add_dir_light(ls[0], False, world)
+        orc.add_dir_light(ls[0], False, world)
+        same(res, orc, f"{dims} removal")
+        assert res.launch_counters()["sweep"] > 0
