@@ -149,6 +149,19 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // in order. The stage takes the ray's LightEnergy as the slabs before it left it (p.out, in place), accumulates the
 // samples it owns exactly where the unpartitioned loop would, and hands the state on. Positions are still reached by
 // performing every addition of the ray, so every sample, and the early exit, are bit for bit those of the whole march.
+#ifdef TBRM_RAY_STATS // diagnostics build (tools/ray_stats.sh): how full the waves of the lit march are
+__device__ unsigned long long g_ray_stats[4]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples
+extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(g_ray_stats)) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
+
 template <int DFMT, int LFMT, int DMODE, int kRayLanes, bool SLAB = false>
 __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6 waves per SIMD (80 VGPRs): measured 3-8 % faster than 5 or 8
 {
@@ -198,6 +211,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
     // empty-space leaping: texels the position moves per full step along its fastest axis
     const float inv_texels_per_step = 1.0f / fmaxf(fmaxf(fabsf(sv0) * nx, fabsf(sv1) * ny), fabsf(sv2) * nz);
     int safe_until = -1; // this lane's samples with index <= safe_until are known to be based in empty bricks
+    bool eager = false;  // the wave's last trip sampled nothing (wave-uniform)
 
     float le0 = 0.0f, le1 = 0.0f, le2 = 0.0f, le3 = 0.0f; // LightEnergy, replicated in the 8 lanes of the ray
     bool done = n_samples == 0;
@@ -241,7 +255,10 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         }
         int ix = 0, iy = 0, iz = 0;
         float fx = 0.0f, fy = 0.0f, fz = 0.0f;
-        if (live) {
+        // (after a trip in which no lane of the wave sampled, the lanes inside their proven-empty range look their brick up
+        // again as well: all ranges then start from here, and the wave can take the trips they share in one go — below)
+        const bool renew = eager && has && !live && idx <= safe_until && p.skip_dist != nullptr;
+        if (live || renew) {
             texel_split(q0, nx, ix, fx);
             texel_split(q1, ny, iy, fy);
             texel_split(q2, nz, iz, fz);
@@ -250,13 +267,20 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
                 const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
                 const int dist = p.skip_dist[(bz * p.bny + by) * p.bnx + bx];
-                live = dist == 0;
+                live = live && dist == 0;
                 // Every brick within Chebyshev distance < dist is empty as well. From anywhere inside this brick a base
                 // tap has to move more than 8*(dist-1) texels along some axis to leave them, and a base tap moves at
                 // most 1 texel more than the position does: the lane's samples up to that many steps ahead need no test.
-                if (dist >= 2) safe_until = idx + (int) fminf(((float) (8 * (dist - 1)) - 1.25f) * inv_texels_per_step, 1.0e6f);
+                if (dist >= 2) safe_until = max(safe_until, idx + (int) fminf(((float) (8 * (dist - 1)) - 1.25f) * inv_texels_per_step, 1.0e6f));
             }
         }
+        const bool any_live = __builtin_amdgcn_ballot_w64(live) != 0;
+#ifdef TBRM_RAY_STATS
+        {
+            const unsigned long long nd = __builtin_popcountll(__builtin_amdgcn_ballot_w64(!done)), nl = __builtin_popcountll(__builtin_amdgcn_ballot_w64(live));
+            if (lane == 0) { atomicAdd(&g_ray_stats[0], 1ull); atomicAdd(&g_ray_stats[1], nd); atomicAdd(&g_ray_stats[2], nl); if (nl) atomicAdd(&g_ray_stats[3], 1ull); }
+        }
+#endif
         if (live) {
             RawTaps<DFMT> dtaps;
             RawTaps<LFMT> ltaps;
@@ -311,6 +335,28 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
             __builtin_amdgcn_wave_barrier();
         }
         if (base + kRayLanes >= n_samples) done = true;
+        // Empty space, wave-wide: when no lane of the wave had anything to sample in this trip, the trips that EVERY marching
+        // lane would spend the same way — its sample still within its proven-empty range (safe_until), the ray still in its
+        // full steps — are taken in one go: their only effect is the positions' additions, performed one by one as before
+        // (a position is reached by performing every addition of the ray). 70 % of the benchmark's trips are of this kind.
+        eager = !any_live;
+        if (!any_live && p.skip_dist) {
+            int k_lane = INT32_MAX; // whole trips this lane can take blind after this one
+            if (!done) {
+                const int ahead = safe_until - base - b; // its sample of trip t from now is base + kRayLanes t + b
+                const int by_safe = ahead >= kRayLanes ? ahead / kRayLanes : 0;
+                const int left = max_steps - 1 - (base + kRayLanes); // full steps behind the end of this trip, but for the last
+                const int by_length = left >= kRayLanes ? left / kRayLanes : 0;
+                k_lane = min(by_safe, by_length);
+            }
+            int k = 0; // the wave's minimum (small: counted up with ballots)
+            while (k < 64 && __builtin_amdgcn_ballot_w64(k_lane <= k) == 0) ++k;
+            if (k > 0) {
+                for (int t = 0; t < k * kRayLanes; ++t) { pos0 = pos0 + sv0; pos1 = pos1 + sv1; pos2 = pos2 + sv2; }
+                adds += k * kRayLanes;
+                base += k * kRayLanes;
+            }
+        }
     }
     if ((SLAB ? mine : valid) && b == 0) reinterpret_cast<float4*>(p.out)[(size_t) j * p.tile_w + i] = make_float4(le0, le1, le2, le3);
 }
