@@ -174,7 +174,8 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * host needs to call). Each starts from the environment variable TBRM_<NAME IN CAPITALS>, read once when the library is
  * loaded; no operator reads the environment. Names (default): force_slice_kernel (0), chunk_steps (0 = by fit),
  * occ_slices (0 = 128; the chunked chain's occlusion spans), sparse_occ (1), occ_list (1), light_cache_mb (-1 = an eighth of
- * the device's memory at most, 0 = off, else MiB), light_batching (1; 0 never, 2 always), share_grid (1), ray_lanes (0 = by
+ * the device's memory at most, 0 = off, else MiB), light_batching (1; 0 never, 2 always), share_grid (1), ray_wave_skip (the lit march takes the empty trips a whole wave shares in one go: 1 on, 0 off,
+ * -1 = for data volumes of at least 384 voxels a side), ray_lanes (0 = by
  * load; 4 / 8), chain_fast_loop (1), chain_rect_planes (1), occ_overlap (2 = workgroups per CU of an occlusion launch that
  * runs beside a chunked chain; 0 = one after the other), light_sweep (1 = axis passes take the pipelined sweep kernel where
  * it applies; 2 = except the passes of a Change whose two lights pull opposite ways, which otherwise take two sweeps; 0 = the

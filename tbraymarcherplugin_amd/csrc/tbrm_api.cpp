@@ -33,7 +33,7 @@ thread_local char g_error[512] = "";
 struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
-    {"light_batching", 1}, {"share_grid", 1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
+    {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
 };
 struct TunableStore {
@@ -203,6 +203,10 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     host_world_to_local(world->volume_transform, p.m);
     host_local_clipping(*world, p.cc, p.cd);
     p.clip_mode = raymarch_clip_mode(p.cc, p.cd);
+    {   // (measured: frames of 128^3 / 256^3 volumes lose 15 % to the bookkeeping, 512^3 is even, 2048^2 rays through 512^3 gain 12 %)
+        const int ws = tune(TUNE_RAY_WAVE_SKIP);
+        p.wave_skip = ws > 0 || (ws < 0 && std::min(r->desc.dim_x, std::min(r->desc.dim_y, r->desc.dim_z)) >= 384) ? 1 : 0;
+    }
     p.share_grid = (r->lv_dims[0] == r->desc.dim_x && r->lv_dims[1] == r->desc.dim_y && r->lv_dims[2] == r->desc.dim_z &&
                     !r->resident && tune(TUNE_SHARE_GRID)) ? 1 : 0; // (the two volumes of a slab-resident handle relocate different layers)
     p.tile_x0 = tile->x0; p.tile_y0 = tile->y0; p.tile_w = tile->w; p.tile_h = tile->h;

@@ -183,6 +183,7 @@ struct RayParams {
     float cc[3], cd[3];
     int clip_mode;      // 0: clip plane provably never clips a sample position; 1: general
     int share_grid;     // light volume has the data volume's size and wrap addressing: taps share their offsets
+    int wave_skip;      // k_raymarch_lit takes the empty trips a whole wave shares in one go (pays in large volumes)
     int tile_x0, tile_y0, tile_w, tile_h, row_group_step;
     float steps;
     int jitter_frame;
@@ -260,6 +261,7 @@ enum Tunable : int {
     TUNE_LIGHT_CACHE_MB,     // HBM budget of the factor cache in MiB (0: off, < 0: an eighth of the device's memory): a light's occlusion factors, kept per axis pass
     TUNE_LIGHT_BATCHING,     // tbrm_add_dir_lights: 0 never pair passes, 1 pair when it pays, 2 pair whatever fits
     TUNE_SHARE_GRID,         // 0: the raymarch computes the light volume's tap offsets separately even on a shared grid
+    TUNE_RAY_WAVE_SKIP,      // RayParams::wave_skip: 1 on, 0 off, -1 = where the data volume is at least 384 voxels a side
     TUNE_RAY_LANES,          // lanes per ray of k_raymarch_lit: 4, 8, or 0 = by load
     TUNE_CHAIN_FAST_LOOP,    // 0: full, aligned chunks run the generic slice loop too (A/B of the unrolled, branch-free loop)
     TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)

@@ -927,3 +927,38 @@ def test_contribution_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_
     assert stats[1]["hits"] == 0 and stats[1]["entries"] == 0, stats
     for other in finals[1:]:
         assert np.array_equal(finals[0], other) if not light_32bit else np.abs(finals[0] - other).max() == 0.0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 5, 7, 8, 11, 13])
+def test_random_render_scenes_with_wave_wide_skipping(gpu, oracle_mod, seed, tunables):
+    """The same random scenes with the lit march's wave-wide empty-space skipping forced on (ray_wave_skip = 1; by default
+    it is on for volumes of at least 384 voxels a side only — the full-size tests): every trip it takes blind only performs the
+    positions' additions, so every frame is the oracle's as before."""
+    tunables("ray_wave_skip", 1)
+    test_random_render_scenes_against_oracle(gpu, oracle_mod, seed, tunables)
+
+
+def test_wave_wide_skipping_is_bit_identical_in_a_mostly_empty_volume(gpu, tunables):
+    """A small opaque blob in a 160^3 volume of air, rays of 320 steps: long proven-empty ranges, most trips of a wave blind.
+    Frames with ray_wave_skip on / off and with skipping off altogether are the same bits (lit, with a clip plane, jittered)."""
+    n = 160
+    vol = np.zeros((n, n, n), dtype=np.uint16)
+    zz, yy, xx = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    vol[(xx - 100) ** 2 + (yy - 70) ** 2 + (zz - 90) ** 2 < 14 ** 2] = 52000
+    vol[(xx - 30) ** 2 + (yy - 120) ** 2 + (zz - 40) ** 2 < 9 ** 2] = 40000
+    world = S.default_world()
+    frames = []
+    for ws, skipping in ((1, True), (0, True), (0, False)):
+        tunables("ray_wave_skip", ws)
+        with abi.Resources((n, n, n), abi.FMT_G16) as res:
+            res.upload_volume(vol)
+            res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
+            res.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+            res.clear_light_volume(0.0)
+            res.add_dir_light(S.light(0), True, world)
+            for jitter in (-1, 3):
+                cam = S.default_camera(200, 152)
+                frames.append(res.raymarch_lit(cam, abi.Tile(0, 0, 200, 152, 1), abi.RaymarchParams(320.0, jitter, skipping), world))
+    for k in range(2):
+        assert np.array_equal(frames[k], frames[2 + k]) and np.array_equal(frames[k], frames[4 + k]), k
+    assert float(frames[0][..., 3].max()) > 0.5
