@@ -149,6 +149,9 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // in order. The stage takes the ray's LightEnergy as the slabs before it left it (p.out, in place), accumulates the
 // samples it owns exactly where the unpartitioned loop would, and hands the state on. Positions are still reached by
 // performing every addition of the ray, so every sample, and the early exit, are bit for bit those of the whole march.
+#ifndef TBRM_RAY_EXP
+#define TBRM_RAY_EXP 0 // timing experiments (WRONG frames; tools/ray_ablation.sh): 1 = no pow, 2 = no light-volume taps, 4 = no data taps
+#endif                 // (constant value), 8 = no in-order accumulation (every lane adds its own sample), 16 = no leap-distance look-up
 #ifdef TBRM_RAY_STATS // diagnostics build (tools/ray_stats.sh): how full the waves of the lit march are
 __device__ unsigned long long g_ray_stats[4]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples
 extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsigned long long* out, int reset)
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
             texel_split(q0, nx, ix, fx);
             texel_split(q1, ny, iy, fy);
             texel_split(q2, nz, iz, fz);
-            if (p.skip_dist) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
+            if (p.skip_dist && !(TBRM_RAY_EXP & 16)) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
                 const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
                 const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
                 const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
@@ -301,15 +304,15 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 texel_split(sp2, lnz, lz, gz);
                 ltaps.issue(p.light, tap_offsets<ADDR_WRAP, SLAB>(lightv, lx, ly, lz));
             }
-            const float v = dtaps.filter(fx, fy, fz);
+            const float v = (TBRM_RAY_EXP & 4) ? 0.6f + fx * 0.01f : dtaps.filter(fx, fy, fz);
             // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
             const float tpos = tf_position(v, p.win.center, p.win.width);
             if (!((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f))) {
                 const float4 cs = sample_tf(s_tf, tpos);
                 const float a_sat = saturate_(cs.w);
                 if (a_sat != 0.0f) { // else 1 - pow(1, s) = 0: the sample contributes exactly nothing
-                    const float a = 1.0f - pow_(1.0f - a_sat, step);
-                    const float l = ltaps.filter(gx, gy, gz);
+                    const float a = (TBRM_RAY_EXP & 1) ? a_sat * step * 0.01f : 1.0f - pow_(1.0f - a_sat, step);
+                    const float l = (TBRM_RAY_EXP & 2) ? gx : ltaps.filter(gx, gy, gz);
                     x = make_float4((cs.x * l) * a, (cs.y * l) * a, (cs.z * l) * a, a);
                 }
             }
@@ -319,7 +322,13 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         // the ray; the early exit belongs to the full steps only (:75-79). A trip in which no lane of the wave has
         // anything to accumulate (empty space, windowed-out values) needs no exchange.
         const bool any_x = __builtin_amdgcn_ballot_w64(x.w >= 0.0f || x.w != x.w) != 0;
-        if (any_x) {
+        if (any_x && (TBRM_RAY_EXP & 8)) {
+            if (!done && !(x.w < 0.0f)) {
+                const float om = 1.0f - le3;
+                le0 = le0 + (x.x * om); le1 = le1 + (x.y * om); le2 = le2 + (x.z * om); le3 = le3 + (x.w * om);
+                if (le3 > 0.95f && base < max_steps) { le3 = 1.0f; done = true; }
+            }
+        } else if (any_x) {
             s_x[threadIdx.x] = x;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
