@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
     if (gy < p.roi_by0 || gy >= p.roi_by1) continue;             // dense span of a slab-partitioned pass
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
 #ifndef TBRM_OCC_EXP
-#define TBRM_OCC_EXP 0 // timing experiments (WRONG results): 1 = no sample loop (what the per-workgroup setup costs), 2 = no brick staging
+#define TBRM_OCC_EXP 0 // timing experiments (WRONG results): 1 = no sample loop (what the per-workgroup setup costs), 2 = no brick staging, 4 = write-through (sc1) factor stores (results right)
 #endif
     const int nk = (TBRM_OCC_EXP & 1) ? 0 : min(kOccDepth, p.n_steps - k0);
 
@@ -593,7 +593,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                 if constexpr (GUARD) inside = guard_uv && (fl & 4);
                 float occ = 0.0f;
                 if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
-                out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
+                if constexpr (TBRM_OCC_EXP & 4) __hip_atomic_store(out + q * out_step, 1 - occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (write-through: what a finer hand-over to the sweep would need)
+                else out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }
         }
     };
