@@ -132,6 +132,7 @@ struct ChunkParams {
     int occ_grid_cap;             // occlusion launch: at most this many workgroups, each walking several blocks (0: one per block)
     uint32_t* occ_list_out;       // k_occ_compact: the whole pass, [chunk][per-chunk capacity]
     int* occ_count_out;           // k_occ_compact: [chunk]
+    int* occ_count_host;          // (one-chunk launches) the same count into pinned host memory as well: no copy behind the kernel
     int32_t* occ_slot_out;        // k_occ_compact: rank of every block in its chunk's list, -1 for the flagged ones (null: not wanted)
     int compact;                  // occlusion launch / sweep: the factors are handed over block-compact (ChunkStream::fs_*)
     const float* ones;            // sweep: 1024 floats of 1.0 (the factor of flagged-empty blocks and of pixels beyond the buffer)

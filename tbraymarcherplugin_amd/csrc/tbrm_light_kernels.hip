@@ -343,7 +343,10 @@ __global__ __launch_bounds__(256) void k_occ_compact(const ChunkParams p, int se
         if (slot) slot[i] = flagged ? -1 : pos;
         if (!flagged) list[pos++] = (uint32_t) i;
     }
-    if (seg == segs - 1 && threadIdx.x == NT - 1) p.occ_count_out[c] = base + s_scan[NT - 1];
+    if (seg == segs - 1 && threadIdx.x == NT - 1) {
+        p.occ_count_out[c] = base + s_scan[NT - 1];
+        if (p.occ_count_host && c == 0) *p.occ_count_host = base + s_scan[NT - 1]; // (visible to the host once an event behind the launch has completed)
+    }
 }
 
 template <int MODE>

@@ -958,11 +958,11 @@ int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
     p.occ_list_out = f.list;
     p.occ_count_out = f.count;
     p.occ_slot_out = e ? e->slot : f.slot;
+    // how many blocks the entry has to hold is known on the device only (resolve_entry): the compaction leaves the count in the
+    // entry's pinned host word too
+    p.occ_count_host = e ? e->count_host : nullptr;
     HIP_TRY(launch_occ_flags(p, plan.occ_mode, 1, s));
-    if (e) { // how many blocks the entry has to hold: known on the device only (resolve_entry)
-        HIP_TRY(hipMemcpyAsync(e->count_host, f.count, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(e->ev_count, s));
-    }
+    if (e) HIP_TRY(hipEventRecord(e->ev_count, s));
     p.j0 = plan.start;
     p.n_steps = plan.D;
     p.occ_flags = nullptr;
