@@ -162,9 +162,10 @@ typedef struct tbrm_resources tbrm_resources; /* opaque: FBasicRaymarchRendering
 /* ------------------------------------------------------------------------------------------------ */
 /* library                                                                                           */
 /* Bumped whenever an entry point changes its signature or meaning (3: round 3 — tbrm_change_dir_light has carried its
- * trailing gpu_sync argument since 2; 3 adds tbrm_abi_version itself and the error report of tbrm_flush). A host built
- * against another number must not call into the library. */
-#define TBRM_ABI_VERSION 3
+ * trailing gpu_sync argument since 2; 3 adds tbrm_abi_version itself and the error report of tbrm_flush; 4 adds
+ * tbrm_path_counters, and every entry point that waits for the handle's stream now reports a failed sweep like tbrm_flush).
+ * A host built against another number must not call into the library. */
+#define TBRM_ABI_VERSION 4
 TBRM_API int tbrm_abi_version(void);
 TBRM_API const char* tbrm_version(void);
 TBRM_API const char* tbrm_last_error(void);       /* thread-local message of the last failing call */
@@ -184,7 +185,10 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * occ_priority (0 = the occlusion stream has the lowest priority the device
  * offers, 1 = the handle's stream's; read when the handle first needs the stream), sweep_debug (diagnostics: bit 0 tiles do not
  * wait for each other, bits 3 / 4 skip buffer hazards — WRONG light volumes —; bit 1 prints per-tile time stamps at tbrm_flush,
- * bit 2 the host's time per operator phase, bit 5 leaves out the events behind tbrm_last_gpu_time_ms). Unknown name: TBRM_ERR_INVALID_ARG. */
+ * bit 2 the host's time per operator phase, bit 5 leaves out the events behind tbrm_last_gpu_time_ms), occ_dual (1 = the two
+ * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
+ * 0 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
+ * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
 
@@ -388,6 +392,14 @@ TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, s
 TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
 /* Of out[0] above, the launches of the pipelined sweep kernel (one per axis pass; the rest are chunks of the chained kernel). */
 TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);
+/* Which path the light operators took since creation, per AXIS PASS and per launch (what a benchmark line or a test needs to
+ * say which kernels it measured): out[0] axis passes run as a pipelined sweep, out[1] as the chunked chain, out[2] one slice
+ * per launch; out[3] sweep launches (a two-way Change takes two per pass), out[4] chain launches, out[5] slice launches;
+ * out[6] occlusion launches that served one pass, out[7] occlusion launches that served both passes of a light
+ * (tunable occ_dual); out[8] stream-passes whose occlusion came from the factor cache; out[9] lit-raymarch launches;
+ * out[10..15] reserved (0). */
+#define TBRM_PATH_COUNTERS 16
+TBRM_API int tbrm_path_counters(const tbrm_resources* res, uint64_t out[TBRM_PATH_COUNTERS]);
 /* The factor cache of the light operators (no counterpart in the reference, invisible in the results). The expensive half
  * of an axis pass of the Add / Change shaders is its occlusion: the factors 1 - CurrentSample
  * (AddDirLightShader.usf:85-117, ChangeDirLightShader.usf:100-145) of every voxel, which depend on the volume, the transfer
@@ -406,7 +418,10 @@ TBRM_API int tbrm_light_cache_stats(const tbrm_resources* res, uint64_t out[4]);
 TBRM_API int tbrm_light_cache_clear(tbrm_resources* res);
 /* FlushRenderingCommands(). Also reports a light-propagation sweep that failed on the device (TBRM_ERR_NO_DEVICE with the
  * reason in tbrm_last_error: a tile gave up waiting for its neighbours — the device was reset or starved for seconds —; the
- * light volume is then undefined and has to be rebuilt: ClearResourceLightVolumes + the lights again). */
+ * light volume is then undefined and has to be rebuilt: ClearResourceLightVolumes + the lights again). The condition is
+ * sticky and not tbrm_flush's alone: tbrm_download_light_volume / _slices, tbrm_raymarch_lit (the host-buffer form),
+ * tbrm_last_gpu_time_ms and every later light operator return the same error until tbrm_clear_light_volume or
+ * tbrm_upload_light_volume defines the light volume again; meanwhile axis passes take the chained kernel. */
 TBRM_API int tbrm_flush(tbrm_resources* res);
 TBRM_API int tbrm_stream(tbrm_resources* res, void** out_hip_stream);
 /* GPU time (ms) of the most recent operator call of each kind, measured with HIP events on the handle's

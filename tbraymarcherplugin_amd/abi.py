@@ -125,9 +125,11 @@ SYMBOLS = [
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_sweep_launches", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_launch_counters", "tbrm_sweep_launches", "tbrm_path_counters", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
+
+ABI_VERSION = 4  # TBRM_ABI_VERSION of include/tbrm.h (tests/test_abi.py compares the two)
 
 _lib = None
 
@@ -148,6 +150,12 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension with `python tbraymarcherplugin_amd/build.py` "
             "(__graft_entry__.build()). There is no CPU fallback for this path.")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    # include/tbrm.h: a host built against another TBRM_ABI_VERSION must not call in (a stale libtbrm.so that build.py's
+    # time-stamp check let through would otherwise be used silently)
+    have = lib.tbrm_abi_version() if hasattr(lib, "tbrm_abi_version") else -1
+    if have != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {have}, this binding is written against {ABI_VERSION}: rebuild it "
+                          "(`python tbraymarcherplugin_amd/build.py --force`)")
     lib.tbrm_version.restype = C.c_char_p
     lib.tbrm_last_error.restype = C.c_char_p
     lib.tbrm_host_data_border.restype = C.c_float
@@ -197,6 +205,7 @@ def load():
     lib.tbrm_light_volume_device_ptr.argtypes = [vp, P(vp), P(C.c_size_t)]
     lib.tbrm_launch_counters.argtypes = [vp, P(C.c_uint64 * 3)]
     lib.tbrm_sweep_launches.argtypes = [vp, P(C.c_uint64)]
+    lib.tbrm_path_counters.argtypes = [vp, P(C.c_uint64 * 16)]
     lib.tbrm_selftest_unorm_decode.argtypes = [C.c_int, vp, vp]
     lib.tbrm_selftest_unorm8_roundtrip.argtypes = [C.c_int, vp, C.c_size_t, vp]
     lib.tbrm_flush.argtypes = [vp]
@@ -512,6 +521,15 @@ class Resources:
         sweeps = C.c_uint64(0)
         check(self.lib.tbrm_sweep_launches(self.handle, C.byref(sweeps)))
         return {"chunk": int(out[0]), "slice": int(out[1]), "raymarch": int(out[2]), "sweep": int(sweeps.value)}
+
+    PATH_COUNTERS = ("passes_sweep", "passes_chain", "passes_slice", "launches_sweep", "launches_chain", "launches_slice",
+                     "occlusion_single", "occlusion_dual", "occlusion_cached", "raymarch")
+
+    def path_counters(self):
+        """tbrm_path_counters: which kernels the light operators took (per axis pass and per launch)."""
+        out = (C.c_uint64 * 16)()
+        check(self.lib.tbrm_path_counters(self.handle, C.byref(out)))
+        return {k: int(out[i]) for i, k in enumerate(self.PATH_COUNTERS)}
 
     def light_cache_stats(self):
         out = (C.c_uint64 * 4)()

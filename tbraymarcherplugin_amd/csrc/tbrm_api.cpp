@@ -35,6 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
+    {"sweep_timeout_ms", 0}, {"occ_dual", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -267,6 +268,7 @@ int ensure_skipping(tbrm_resources* r)
             HIP_TRY(launch_brick_dist(dp, mode, r->stream));
         }
         r->empty_valid = true;
+        r->occ_inputs_changed = true; // (the occlusion stream orders itself behind this: order_behind_inputs)
     }
     return TBRM_OK;
 }
@@ -277,7 +279,7 @@ int ensure_skipping(tbrm_resources* r)
 
 extern "C" {
 
-const char* tbrm_version(void) { return "tbrm-mi355x 0.3.0 (gfx950)"; }
+const char* tbrm_version(void) { return "tbrm-mi355x 0.4.0 (gfx950)"; }
 int tbrm_abi_version(void) { return TBRM_ABI_VERSION; }
 const char* tbrm_last_error(void) { return g_error; }
 
@@ -780,7 +782,7 @@ int tbrm_download_light_slices(tbrm_resources* r, int32_t z_begin, int32_t z_cou
     (void) hipFree(staging);
     if (code != TBRM_OK) return code;
     HIP_TRY(e1);
-    return TBRM_OK;
+    return sweep_failed(r); // (the slices of a light volume a failed sweep left undefined are not handed out as good)
 }
 
 int tbrm_slab_light_halo(tbrm_resources* r, int32_t side, void** send_layer, void** recv_layer, size_t* layer_bytes)
@@ -803,6 +805,7 @@ int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)
     if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!r->d_light) return TBRM_OK; // RaymarchUtils.cpp:106-109
     if (int e = bind(r)) return e;
+    sweep_failure_cleared(r); // (a sweep that failed left the light volume undefined: this call defines it again)
     if (int e = begin_timed(r, 0)) return e;
     const tbrm_resources::Residency& q = r->res_light; // (all layers of an ordinary handle); padding voxels are never sampled
     const size_t n = (size_t) r->lbn[0] * r->lbn[1] * 512 * (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0));
@@ -881,7 +884,7 @@ int tbrm_raymarch_lit(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile
     if (int e = tbrm_raymarch_lit_device(r, cam, tile, rp, world, nullptr, r->d_out)) return e;
     HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return TBRM_OK;
+    return sweep_failed(r); // (a frame lit by a light volume that a failed sweep left undefined is not handed out as good)
 }
 
 int tbrm_raymarch_intensity_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
@@ -1042,7 +1045,7 @@ int tbrm_download_light_volume(tbrm_resources* r, void* host_out, size_t n_bytes
     if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
     (void) hipFree(staging);
     HIP_TRY(e1);
-    return TBRM_OK;
+    return sweep_failed(r); // (the slices of a light volume a failed sweep left undefined are not handed out as good)
 }
 
 int tbrm_upload_light_volume(tbrm_resources* r, const void* host_in, size_t n_bytes)
@@ -1059,6 +1062,7 @@ int tbrm_upload_light_volume(tbrm_resources* r, const void* host_in, size_t n_by
     if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
     (void) hipFree(staging);
     HIP_TRY(e1);
+    sweep_failure_cleared(r); // (the light volume is defined again)
     return TBRM_OK;
 }
 
@@ -1114,6 +1118,18 @@ int tbrm_sweep_launches(const tbrm_resources* r, uint64_t* out)
     return TBRM_OK;
 }
 
+int tbrm_path_counters(const tbrm_resources* r, uint64_t out[TBRM_PATH_COUNTERS])
+{
+    if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < TBRM_PATH_COUNTERS; ++k) out[k] = 0;
+    out[0] = r->passes[0]; out[1] = r->passes[1]; out[2] = r->passes[2];
+    out[3] = r->sweep_launches; out[4] = r->launches[0] - r->sweep_launches; out[5] = r->launches[1];
+    out[6] = r->occ_launches; out[7] = r->dual_launches;
+    out[8] = r->kept_hits;
+    out[9] = r->launches[2];
+    return TBRM_OK;
+}
+
 int tbrm_light_cache_stats(const tbrm_resources* r, uint64_t out[4])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
@@ -1156,7 +1172,7 @@ int tbrm_last_gpu_time_ms(tbrm_resources* r, int kind, float* out_ms)
     if (int e = bind(r)) return e;
     HIP_TRY(hipEventSynchronize(r->ev[kind][1]));
     HIP_TRY(hipEventElapsedTime(out_ms, r->ev[kind][0], r->ev[kind][1]));
-    return TBRM_OK;
+    return sweep_failed(r); // (the time of an operator whose sweep gave up is not a time worth reporting)
 }
 
 int tbrm_host_light_passes(const tbrm_dir_light_params* light, const tbrm_world_params* world, const int32_t lv_dims[3],

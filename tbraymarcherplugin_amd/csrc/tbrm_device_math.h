@@ -71,6 +71,16 @@ __device__ __forceinline__ float pow_(float x, float y)
     return exp2_poly(y * log2_poly(x));
 }
 
+// pow_(x, y0) and pow_(x, y1), bit for bit, with the logarithm computed once (the two axis passes of a light correct the same
+// opacity for two step sizes: k_light_occlusion<..., DUAL>)
+__device__ __forceinline__ void pow2_(float x, float y0, float y1, float& r0, float& r1)
+{
+    if (!(x >= 0x1p-126f) || x == __builtin_inff()) { r0 = pow_(x, y0); r1 = pow_(x, y1); return; }
+    const float l = log2_poly(x);
+    r0 = exp2_poly(y0 * l);
+    r1 = exp2_poly(y1 * l);
+}
+
 // ---- UNORM conversion (D3D11 functional spec: load c/(2^n-1); store trunc(clamp(x,0,1)*255+0.5), NaN->0)
 // Load: c/d as fma(c, r, c*r2) with r = RN(1/d) and r2 = RN(1/d - r), the reciprocal split in two floats: 2 instructions
 // instead of the ~10 of a correctly rounded v_div sequence, and bit-identical to IEEE c/d for every UNORM8 and UNORM16

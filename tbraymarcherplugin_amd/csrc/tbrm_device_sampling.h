@@ -220,6 +220,21 @@ __device__ __forceinline__ float windowed_alpha(float value, float step, const f
     return 1.0f - pow_(1.0f - a, step);
 }
 
+// windowed_alpha(value, step0, ...) and windowed_alpha(value, step1, ...), bit for bit, sharing everything up to the opacity
+// correction's exponent (one sample position, two axis passes)
+__device__ __forceinline__ void windowed_alpha2(float value, float step0, float step1, const float* tf_alpha, const WindowDev& w, float& a0, float& a1)
+{
+    a0 = 0.0f; a1 = 0.0f;
+    const float pos = tf_position(value, w.center, w.width);
+    if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return;
+    const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
+    if (a == 0.0f) return;
+    float p0, p1;
+    pow2_(1.0f - a, step0, step1, p0, p1);
+    a0 = 1.0f - p0;
+    a1 = 1.0f - p1;
+}
+
 // AlphaWeight (AddDirLightShader.usf:87-105)
 __device__ __forceinline__ float clip_alpha_weight(float u, float v, float w, const float* cc, const float* cd, const int* res)
 {

@@ -139,6 +139,30 @@ struct ChunkParams {
     ChunkStream a, r;
 };
 
+// The two axis passes of ONE light sample the data volume at the same positions: UVWOffset = normalize(lightPos) / min(TD)
+// whichever axis the pass runs along (LightingShaders.cpp:114-124) — only StepSize differs. A "dual" occlusion launch
+// (k_light_occlusion<..., DUAL>) therefore filters, windows and looks the transfer function up ONCE per voxel and emits the
+// factor 1 - CurrentSample of BOTH passes (AddDirLightShader.usf:85-117 with the two StepSize * 100 exponents, the logarithm
+// of the opacity correction shared). Its work unit is 16 x 16 voxels in x and y times 8 in z, a thread walking z — whatever
+// the two pass axes are (ChunkParams describes that virtual pass along z): a block of any pass holds its factors as
+// [slice][row][column] with x the column axis unless the pass runs along x (then y), so lanes that span x and y write every
+// pass's block-compact store in the same 32-byte segments as the pass's own launch would (measured: looping along x or y
+// instead scatters one or both stores over 64 lines per instruction and costs 1.3 - 1.9x the launch).
+struct DualPass {
+    int axis, start, dir;       // the pass: axis, first slice, direction (tbrm_light_pass)
+    int blocks_x, blocks_y;     // its 16 x 16 blocks per plane row / column
+    float step100[2];           // StepSize * VOLUME_DENSITY per stream (0: a, 1: r)
+    float* fs_keep[2];          // per stream: ChunkStream::fs_keep / fs_spill / fs_cap of THIS pass
+    float* fs_spill[2];
+    uint32_t fs_cap[2];
+    const int32_t* fs_slot;     // rank of every block of this pass (k_occ_compact), shared by the streams; -1: flagged empty
+    const uint8_t* flags;       // k_unit_flags: the pass's empty-block flags, [slice group][block y][block x]
+};
+struct DualOcc {
+    int on;
+    DualPass pass[2];
+};
+
 // k_light_sweep (tbrm_light_sweep.hip): one launch advances every 32x32 tile of the slice plane through a whole span of
 // slices. The previous-slice taps of a pass lie on ONE side of the pixel per plane axis (the constant PrevPixelOffset,
 // AddDirLightShader.usf:81-82), so a tile depends on at most three neighbours — the ones towards the light — and the tiles
@@ -166,6 +190,7 @@ struct SweepParams {
                             // bit 1 = every tile leaves four time stamps (10 ns units) in `stamps`
     unsigned long long* stamps; // [tile][4]: start of slice 0, end of slice 63, end of the last slice, after the write-back
     int* error;             // set when a tile gave up waiting (bit 0) or found its taps outside the halo (bit 1)
+    unsigned long long give_up_ticks; // how long a poll waits for a neighbour's word, in 10 ns ticks of wall_clock64 (tunable sweep_timeout_ms)
 };
 
 struct RayParams {
@@ -277,6 +302,10 @@ enum Tunable : int {
     TUNE_SWEEP_DEBUG,        // diagnostics. 1: sweep tiles do not wait for each other (WRONG results), 2: per-tile time stamps, 4: host
                              // time per operator phase on stderr, 8 / 16: the occlusion stream skips its waits for the scratch
                              // store / the cache entry to be idle (WRONG results: what gates its start?), 32: no timing events
+    TUNE_SWEEP_TIMEOUT_MS,   // how long a sweep tile waits for a neighbour's hand-off word before it gives up and raises the handle's error
+                             // word (0: 2 s; < 0: not at all — a test hook: every word that is not there yet fails the launch)
+    TUNE_OCC_DUAL,           // 1: the two axis passes of a light share ONE occlusion launch where their sampling positions are bit-equal
+                             // (DualOcc); 0: one launch per pass
     TUNE_COUNT
 };
 int tune(Tunable t);
@@ -289,7 +318,8 @@ size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt);
 size_t occlusion_lds_bytes(const ChunkParams& p); // dynamic LDS of an occlusion workgroup (the bricks it stages)
 constexpr int kPlaneGuard = 4096; // floats of slack on both sides of every plane/occlusion buffer (16-byte row copies overrun rows)
 hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStream_t s); // + the work lists
-hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s);
+hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s, const DualOcc* dual = nullptr);
+hipError_t launch_unit_flags(const ChunkParams& pc, const DualOcc& d, hipStream_t s); // + the units' work list (pc: the virtual pass along the third axis)
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s);
 size_t sweep_lds_bytes(int mode, int slices);

@@ -10,6 +10,8 @@
 // Compiled with -ffp-contract=off; see tbrm_device_math.h for the arithmetic contract.
 #include "tbrm_device_sampling.h"
 
+#include <type_traits>
+
 namespace tbrm {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -164,6 +166,18 @@ extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsig
     return 0;
 }
 #endif
+
+// lane t of the caller's DPP quad (lanes 4k .. 4k + 3), in every lane of the quad
+template <int T>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), T * 0x55, 0xf, 0xf, true));
+}
+template <class F>
+__device__ __forceinline__ void sweep4(F&& f)
+{
+    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+}
 
 template <int DFMT, int LFMT, int DMODE, int kRayLanes, bool SLAB = false>
 __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6 waves per SIMD (80 VGPRs): measured 3-8 % faster than 5 or 8
@@ -328,6 +342,22 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 le0 = le0 + (x.x * om); le1 = le1 + (x.y * om); le2 = le2 + (x.z * om); le3 = le3 + (x.w * om);
                 if (le3 > 0.95f && base < max_steps) { le3 = 1.0f; done = true; }
             }
+        } else if (any_x && kRayLanes == 4) {
+            // the four lanes of a ray are one DPP quad: lane t's sample reaches the other three as a quad_perm:[t,t,t,t] operand —
+            // no LDS round trip and no wave barrier on the serial part (every lane of the wave is active here: the loop and this
+            // branch are wave-uniform)
+            sweep4([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const float4 c = make_float4(quad_bcast<t>(x.x), quad_bcast<t>(x.y), quad_bcast<t>(x.z), quad_bcast<t>(x.w));
+                if (!done && !(c.w < 0.0f)) {
+                    const float om = 1.0f - le3;
+                    le0 = le0 + (c.x * om);
+                    le1 = le1 + (c.y * om);
+                    le2 = le2 + (c.z * om);
+                    le3 = le3 + (c.w * om);
+                    if (le3 > 0.95f && base + t < max_steps) { le3 = 1.0f; done = true; }
+                }
+            });
         } else if (any_x) {
             s_x[threadIdx.x] = x;
             __builtin_amdgcn_wave_barrier();

@@ -369,11 +369,13 @@ hipError_t launch_occ_flags(const ChunkParams& p, int mode, int n_chunks, hipStr
     return one ? launch_flags2<PASS_ADD>(p, n_chunks, s) : launch_flags2<PASS_CHANGE>(p, n_chunks, s); // flags only depend on the stream count
 }
 
-template <int DFMT, int MODE, int AXIS>
+// DUAL (tbrm_internal.h DualOcc): the launch walks the light volume as a virtual pass along AXIS (z: see DualOcc) and every
+// voxel's sample serves both real passes — one filter, one transfer-function look-up, one logarithm, two exponents.
+template <int DFMT, int MODE, int AXIS, bool DUAL = false>
 #ifndef TBRM_OCC_WAVES_PER_EU
 #define TBRM_OCC_WAVES_PER_EU 5
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WAVES_PER_EU, 8))) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WAVES_PER_EU, 8))) void k_light_occlusion(const ChunkParams p, int lds_budget_bytes, const DualOcc d)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NS = (MODE == PASS_ADD || MODE == PASS_CHANGE_ONE) ? 1 : 2; // PASS_CHANGE_ONE: one stream with the Change shader's rules
@@ -543,12 +545,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
             const bool k00 = tu.ok0 && tv.ok0, k10 = tu.ok1 && tv.ok0, k01 = tu.ok0 && tv.ok1, k11 = tu.ok1 && tv.ok1;
             // where the factors go: the span's plane stack, or (block-compact hand-over) the block's own 8 x 16 x 16 floats —
             // `entry` is the block's rank in the pass's work list
-            float* out = s.occ_next + k0 * plane_elems + py * p.W + px;
-            int out_step = plane_elems;
-            if (p.compact) {
-                float* const blk_base = (uint32_t) entry < s.fs_cap ? s.fs_keep + (size_t) entry * 2048 : s.fs_spill + (size_t) ((uint32_t) entry - s.fs_cap) * 2048;
-                out = blk_base + (py - py0) * kOccTile + (px - px0);
-                out_step = kOccTile * kOccTile;
+            float* out = nullptr;
+            int out_step = 0;
+            float* out2[2] = {nullptr, nullptr}; // DUAL: where this thread's voxels go in the two passes' stores (null: block flagged empty)
+            int out2_step[2] = {0, 0};
+            if constexpr (DUAL) {
+                int pos[3];
+                pos[dim_u] = px; pos[dim_v] = py; pos[dim_s] = p.j0 + k0 * p.dir;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const DualPass& P = d.pass[k];
+                    const int pa = P.axis == 0 ? pos[0] : (P.axis == 1 ? pos[1] : pos[2]);
+                    const int pu = P.axis == 0 ? pos[1] : pos[0], pv = P.axis == 2 ? pos[1] : pos[2]; // the pass's plane coordinates
+                    const int ks = (pa - P.start) * P.dir;                                              // its slice
+                    const int32_t rank = P.fs_slot[((ks >> 3) * P.blocks_y + (pv >> 4)) * P.blocks_x + (pu >> 4)];
+                    if (rank >= 0) {
+                        float* const blk_base = (uint32_t) rank < P.fs_cap[si] ? P.fs_keep[si] + (size_t) (uint32_t) rank * 2048 : P.fs_spill[si] + (size_t) ((uint32_t) rank - P.fs_cap[si]) * 2048;
+                        out2[k] = blk_base + (ks & 7) * 256 + (pv & 15) * 16 + (pu & 15);
+                    }
+                    // one step along the launch's loop axis, in pass k's block: its own slice axis (a block slice is 256 floats), its
+                    // columns, or its rows
+                    out2_step[k] = (dim_s == P.axis ? 256 * P.dir : (dim_s == (P.axis == 0 ? 1 : 0) ? 1 : kOccTile)) * p.dir;
+                }
+            } else {
+                out = s.occ_next + k0 * plane_elems + py * p.W + px;
+                out_step = plane_elems;
+                if (p.compact) {
+                    float* const blk_base = (uint32_t) entry < s.fs_cap ? s.fs_keep + (size_t) entry * 2048 : s.fs_spill + (size_t) ((uint32_t) entry - s.fs_cap) * 2048;
+                    out = blk_base + (py - py0) * kOccTile + (px - px0);
+                    out_step = kOccTile * kOccTile;
+                }
             }
             // One texel plane of the footprint (4 taps at one slice-axis coordinate), reduced as far as the filter order
             // (x, then y, then z) allows before the slice-axis weight is applied. Consecutive slices of a pass usually
@@ -594,6 +620,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                 }
                 bool inside = true;
                 if constexpr (GUARD) inside = guard_uv && (fl & 4);
+                if constexpr (DUAL) {
+                    float occ0 = 0.0f, occ1 = 0.0f;
+                    if (aw > 0.0f && inside) {
+                        windowed_alpha2(combine(lo, hi, fs), d.pass[0].step100[si], d.pass[1].step100[si], s_alpha, p.win, occ0, occ1);
+                        occ0 = occ0 * aw;
+                        occ1 = occ1 * aw;
+                    }
+                    if (out2[0]) out2[0][q * out2_step[0]] = 1 - occ0;
+                    if (out2[1]) out2[1][q * out2_step[1]] = 1 - occ1;
+                    continue;
+                }
                 float occ = 0.0f;
                 if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
                 if constexpr (TBRM_OCC_EXP & 4) __hip_atomic_store(out + q * out_step, 1 - occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (write-through: what a finer hand-over to the sweep would need)
@@ -612,7 +649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
 }
 
 template <int DFMT, int MODE, int AXIS>
-static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
+static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s, const DualOcc* dual)
 {
     const int blocks = ((p.W + kOccTile - 1) / kOccTile) * ((p.H + kOccTile - 1) / kOccTile) * ((p.n_steps + kOccDepth - 1) / kOccDepth);
     int wgs = 8 * ((blocks + 7) / 8);
@@ -620,31 +657,78 @@ static hipError_t launch_occ3(const ChunkParams& p, hipStream_t s)
     const dim3 grid(wgs), block(256);
     size_t lds = occlusion_lds_bytes(p);
     if (lds > 96 * 1024) lds = 96 * 1024; // workgroups whose bricks do not fit read their taps from global memory
+    if (dual) {
+        if constexpr (MODE == PASS_ADD2 || AXIS != 2) return hipErrorInvalidConfiguration; // (dual launches loop along z: DualOcc)
+        else {
+            if (!p.occ_list || !p.occ_count || p.dir != 1 || p.j0 != 0) return hipErrorInvalidConfiguration; // (the units come from their work list)
+            static std::atomic<uint64_t> attr_done2{0};
+            if (const hipError_t e = allow_big_lds(k_light_occlusion<DFMT, MODE, AXIS, true>, attr_done2, 128 * 1024); e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_light_occlusion<DFMT, MODE, AXIS, true>), grid, block, lds, s, p, (int) lds, *dual);
+            return hipGetLastError();
+        }
+    }
     static std::atomic<uint64_t> attr_done{0};
     if (const hipError_t e = allow_big_lds(k_light_occlusion<DFMT, MODE, AXIS>, attr_done, 128 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_light_occlusion<DFMT, MODE, AXIS>), grid, block, lds, s, p, (int) lds);
+    hipLaunchKernelGGL((k_light_occlusion<DFMT, MODE, AXIS>), grid, block, lds, s, p, (int) lds, DualOcc{});
     return hipGetLastError();
 }
 template <int DFMT, int MODE>
-static hipError_t launch_occ2(const ChunkParams& p, hipStream_t s)
+static hipError_t launch_occ2(const ChunkParams& p, hipStream_t s, const DualOcc* dual)
 {
-    return p.axis == 0 ? launch_occ3<DFMT, MODE, 0>(p, s) : (p.axis == 1 ? launch_occ3<DFMT, MODE, 1>(p, s) : launch_occ3<DFMT, MODE, 2>(p, s));
+    return p.axis == 0 ? launch_occ3<DFMT, MODE, 0>(p, s, dual) : (p.axis == 1 ? launch_occ3<DFMT, MODE, 1>(p, s, dual) : launch_occ3<DFMT, MODE, 2>(p, s, dual));
 }
 template <int DFMT>
-static hipError_t launch_occ1(const ChunkParams& p, int mode, hipStream_t s)
+static hipError_t launch_occ1(const ChunkParams& p, int mode, hipStream_t s, const DualOcc* dual)
 {
-    return mode == PASS_ADD ? launch_occ2<DFMT, PASS_ADD>(p, s)
-           : (mode == PASS_CHANGE ? launch_occ2<DFMT, PASS_CHANGE>(p, s) : (mode == PASS_ADD2 ? launch_occ2<DFMT, PASS_ADD2>(p, s) : launch_occ2<DFMT, PASS_CHANGE_ONE>(p, s)));
+    return mode == PASS_ADD ? launch_occ2<DFMT, PASS_ADD>(p, s, dual)
+           : (mode == PASS_CHANGE ? launch_occ2<DFMT, PASS_CHANGE>(p, s, dual) : (mode == PASS_ADD2 ? launch_occ2<DFMT, PASS_ADD2>(p, s, dual) : launch_occ2<DFMT, PASS_CHANGE_ONE>(p, s, dual)));
 }
-// computes the occlusion of the chunk described by (j0, n_steps) into {a,r}.occ_next
-hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s)
+// computes the occlusion of the chunk described by (j0, n_steps) into {a,r}.occ_next; dual: of BOTH passes of a light, p
+// describing the virtual pass along z (tbrm_internal.h DualOcc)
+hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s, const DualOcc* dual)
 {
     if (p.n_steps <= 0) return hipSuccess;
     switch (p.data.fmt) {
-        case FMT_U8: return launch_occ1<FMT_U8>(p, mode, s);
-        case FMT_U16: return launch_occ1<FMT_U16>(p, mode, s);
-        default: return launch_occ1<FMT_F32>(p, mode, s);
+        case FMT_U8: return launch_occ1<FMT_U8>(p, mode, s, dual);
+        case FMT_U16: return launch_occ1<FMT_U16>(p, mode, s, dual);
+        default: return launch_occ1<FMT_F32>(p, mode, s, dual);
     }
+}
+
+// ---- k_unit_flags: a dual launch's work units that have nothing to do ---------------------------------------------------------
+// A unit (16 x 16 voxels in x and y, 8 in z) is part of up to two 16 x 16 x 8 blocks of each pass (one, when the pass runs along
+// z: then the unit IS the block); it is flagged when all of them are (then none has a rank, and nothing would be stored). One
+// thread per unit.
+__global__ __launch_bounds__(256) void k_unit_flags(const ChunkParams pc, const DualOcc d, int n_units)
+{
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n_units) return;
+    const int gx = id % pc.occ_blocks_x, gy = (id / pc.occ_blocks_x) % pc.occ_blocks_y, gz = id / (pc.occ_blocks_x * pc.occ_blocks_y);
+    const int dim_u = pc.axis == 0 ? 1 : 0, dim_v = pc.axis == 2 ? 1 : 2;
+    int pos0[3];
+    pos0[dim_u] = gx * kOccTile; pos0[dim_v] = gy * kOccTile; pos0[pc.axis] = gz * kOccDepth;
+    bool all_flagged = true;
+    for (int k = 0; k < 2; ++k) {
+        const DualPass& P = d.pass[k];
+        for (int half = 0; half < (P.axis == pc.axis ? 1 : 2); ++half) { // (16 voxels of the pass's axis unless it is the loop axis: two slice groups)
+            int pos[3] = {pos0[0], pos0[1], pos0[2]};
+            pos[P.axis] += 8 * half;
+            if (pos[P.axis] >= pc.lv_dims[P.axis]) continue;
+            const int pu = P.axis == 0 ? pos[1] : pos[0], pv = P.axis == 2 ? pos[1] : pos[2];
+            const int ks = (pos[P.axis] - P.start) * P.dir;
+            all_flagged = all_flagged && P.flags[((ks >> 3) * P.blocks_y + (pv >> 4)) * P.blocks_x + (pu >> 4)] != 0;
+        }
+    }
+    pc.occ_flags_out[id] = all_flagged ? 1 : 0;
+}
+
+hipError_t launch_unit_flags(const ChunkParams& pc, const DualOcc& d, hipStream_t s)
+{
+    const int per_chunk = pc.occ_groups * pc.occ_blocks_y * pc.occ_blocks_x;
+    hipLaunchKernelGGL(k_unit_flags, dim3((per_chunk + 255) / 256), dim3(256), 0, s, pc, d, per_chunk);
+    const int segs = (per_chunk + kCompactSeg - 1) / kCompactSeg;
+    hipLaunchKernelGGL(k_occ_compact, dim3(segs), dim3(256), 0, s, pc, segs);
+    return hipGetLastError();
 }
 
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s)

@@ -73,7 +73,7 @@ static TapSide prev_tap_side(int size, float off)
 // fits the hand-off wave and both fit the planes side by side.
 bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit)
 {
-    if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident) return false;
+    if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident || r->sweep_failed_bits) return false;
     if (mode != PASS_ADD && mode != PASS_CHANGE) return false;
     if (pa.td[2] % 8 != 0 || (pa.start & 7) != (pa.dir > 0 ? 0 : 7)) return false;
     fit = SweepFit{};
@@ -141,12 +141,32 @@ int sweep_check(tbrm_resources* r)
         }
         r->sweep_stamp_tiles = 0;
     }
-    if (!r->sweep_error || *r->sweep_error == 0) return TBRM_OK;
-    const int e = *r->sweep_error;
-    *r->sweep_error = 0;
-    return fail(TBRM_ERR_NO_DEVICE, "a light-propagation sweep failed on the device (%s%s%s): the light volume is undefined",
+    return sweep_failed(r);
+}
+
+// The sweep kernels' error word (pinned host memory: visible as soon as the kernel that raised it has completed, without a
+// copy). Latched into the handle: from then on the light volume is undefined, and every entry point that waits for the
+// handle's stream, and every light operator, says so — until the light volume is defined again (ClearResourceLightVolumes, an
+// upload). Sweeps are not used while it stands (sweep_fit).
+int sweep_failed(tbrm_resources* r)
+{
+    if (r->sweep_error && *r->sweep_error != 0) {
+        r->sweep_failed_bits |= *r->sweep_error;
+        *r->sweep_error = 0;
+    }
+    const int e = r->sweep_failed_bits;
+    if (e == 0) return TBRM_OK;
+    return fail(TBRM_ERR_NO_DEVICE, "a light-propagation sweep failed on the device (%s%s%s): the light volume is undefined until it is cleared",
                 (e & 1) ? "a tile gave up waiting for its neighbours" : "", (e & 2) ? " previous-slice taps outside the planned halo" : "",
                 (e & 4) ? " a removed light's plane records were not there" : "");
+}
+
+void sweep_failure_cleared(tbrm_resources* r)
+{
+    if (r->sweep_failed_bits == 0 && !(r->sweep_error && *r->sweep_error != 0)) return;
+    drain_streams_public(r); // (whatever was in flight when it failed may still raise the word)
+    if (r->sweep_error) *r->sweep_error = 0;
+    r->sweep_failed_bits = 0;
 }
 
 // room for the hand-off records of a pass (words1: of the removed light's own sweep, two-way Changes), the tickets and the
@@ -381,6 +401,7 @@ static void drain_streams(tbrm_resources* r)
     (void) hipStreamSynchronize(r->stream);
     if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
 }
+void drain_streams_public(tbrm_resources* r) { drain_streams(r); }
 
 static void free_entry(FactorEntry* e)
 {
@@ -429,6 +450,11 @@ void release_occ_stores(tbrm_resources* r)
     }
     (void) hipFree(r->d_ones);
     r->d_ones = nullptr;
+    (void) hipFree(r->dual_flags);
+    (void) hipFree(r->dual_list);
+    (void) hipFree(r->dual_count);
+    r->dual_flags = nullptr; r->dual_list = nullptr; r->dual_count = nullptr;
+    r->dual_units = 0;
     release_kept(r);
 }
 
@@ -737,7 +763,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
                 if (!memcmp(&e->key, &k, sizeof(k))) e->spent = true;
         }
     };
-    plan.f_buf = r->f_buf ^ 1;
+    plan.f_buf = (r->f_buf + 1) % tbrm_resources::kFScratch;
     plan.occ_mode = -1;
     if (have_a) { plan.f_entry[0] = have_a; plan.f_hit[0] = true; use_kept(r, have_a, !change && b_added < 0.0f); ++r->kept_hits; }
     if (have_r) { plan.f_entry[1] = have_r; plan.f_hit[1] = true; use_kept(r, have_r, true); ++r->kept_hits; }
@@ -774,6 +800,10 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 2;
     q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : 1500;
     q.debug = tune(TUNE_SWEEP_DEBUG);
+    {
+        const int ms = tune(TUNE_SWEEP_TIMEOUT_MS);
+        q.give_up_ticks = ms < 0 ? 0ull : (unsigned long long) (ms == 0 ? 2000 : ms) * 100000ull;
+    }
     plan.serial = ++r->plan_serial;
     return TBRM_OK;
 }
@@ -933,10 +963,23 @@ static int enqueue_occlusion(tbrm_resources* r, const PassPlan& plan, int sp, in
     if (q.sparse && !plan.work_list) p.occ_flags = fs->flags + (size_t) sp * plan.flags_per_span;
     p.occ_grid_cap = beside ? beside_wgs_per_cu * r->n_cus : 0;
     HIP_TRY(launch_light_occlusion(p, occ_mode, s));
+    ++r->occ_launches;
     if (beside) HIP_TRY(hipEventRecord(r->occ_ev_ready[b], s));
     r->occ_slot[b].plan_serial = plan.serial;
     r->occ_slot[b].span = sp;
     r->occ_slot_async[b] = beside;
+    return TBRM_OK;
+}
+
+// What the sweep passes' occlusion reads — the data volume, the transfer function's tables, the per-brick emptiness bits — is
+// written on the handle's stream; the occlusion stream waits for it ONCE after every change (not per operator: an event
+// recorded behind the previous operator's sweeps would take the occlusion out from beside them).
+static int order_behind_inputs(tbrm_resources* r)
+{
+    if (!r->occ_inputs_changed) return TBRM_OK;
+    HIP_TRY(hipEventRecord(r->occ_ev_fork[0], r->stream));
+    HIP_TRY(hipStreamWaitEvent(r->occ_stream, r->occ_ev_fork[0], 0));
+    r->occ_inputs_changed = false;
     return TBRM_OK;
 }
 
@@ -950,6 +993,7 @@ int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
     FactorScratch& f = r->f_scratch[plan.f_buf];
     FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
     hipStream_t s = r->occ_stream;
+    if (int e2 = order_behind_inputs(r)) return e2;
     // the buffers about to be overwritten may still be read by an earlier sweep
     if (f.used && !(tune(TUNE_SWEEP_DEBUG) & 8)) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
     if (e && e->read_yet && !(tune(TUNE_SWEEP_DEBUG) & 16)) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
@@ -979,12 +1023,119 @@ int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
     p.r.fs_cap = 0;
     p.r.fs_spill = f.store[1];
     HIP_TRY(launch_light_occlusion(p, plan.occ_mode, s));
+    ++r->occ_launches;
     HIP_TRY(hipEventRecord(f.ev_ready, s));
     if (e) {
         HIP_TRY(hipEventRecord(e->ev_filled, s));
         e->enqueued = true;
     }
     plan.occ_enqueued = true;
+    return TBRM_OK;
+}
+
+// May ONE occlusion launch serve both passes (tbrm_internal.h DualOcc)? They are passes of the same operator (same volume,
+// window, transfer function, clip plane); what has to hold is that they sample at the same positions under the same rules —
+// UVWOffset bit-equal per stream, which the reference's host math gives the two passes of a light (LightingShaders.cpp:114-124:
+// normalize(lightPos) / min(TD) whatever the axis) —, that both still have their occlusion to compute, and that they run along
+// different axes.
+bool dual_fit(const PassPlan& a, const PassPlan& b)
+{
+    if (tune(TUNE_OCC_DUAL) == 0 || !a.sweep || !b.sweep || a.occ_mode < 0 || a.occ_mode != b.occ_mode || a.occ_enqueued || b.occ_enqueued) return false;
+    if (a.p.axis == b.p.axis || a.f_buf == b.f_buf) return false;
+    if (memcmp(a.p.a.uvw_off, b.p.a.uvw_off, sizeof(a.p.a.uvw_off))) return false;
+    if (a.occ_mode == PASS_CHANGE && memcmp(a.p.r.uvw_off, b.p.r.uvw_off, sizeof(a.p.r.uvw_off))) return false;
+    return true;
+}
+
+// Both passes' occlusion in one launch: each pass's empty-block flags, work list and block ranks as for its own launch
+// (the sweeps and the cache entries need them), the work units' flags and list, then k_light_occlusion<..., DUAL> over the
+// virtual pass along z.
+int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& pa, const PassPlan& pb)
+{
+    hipStream_t s = r->occ_stream;
+    if (int e2 = order_behind_inputs(r)) return e2;
+    const PassPlan* const plans[2] = {&pa, &pb};
+    const int axc = 2;
+    // the virtual pass: along z, lanes over x and y, whatever the two pass axes are (tbrm_internal.h DualOcc)
+    ChunkParams pc = pa.p;
+    pc.axis = axc;
+    const int dim_u = axc == 0 ? 1 : 0, dim_v = axc == 2 ? 1 : 2;
+    pc.W = pc.lv_dims[dim_u];
+    pc.H = pc.lv_dims[dim_v];
+    pc.dir = 1;
+    pc.j0 = 0;
+    pc.n_steps = pc.lv_dims[axc];
+    pc.pass_start = 0;
+    pc.pass_slices = pc.chunk_slices = pc.n_steps;
+    pc.occ_blocks_x = ceil_div(pc.W, 16);
+    pc.occ_blocks_y = ceil_div(pc.H, 16);
+    pc.occ_groups = ceil_div(pc.n_steps, kOccSlices);
+    pc.roi_by0 = 0;
+    pc.roi_by1 = pc.occ_blocks_y;
+    pc.compact = 1;
+    const size_t units = (size_t) pc.occ_groups * pc.occ_blocks_y * pc.occ_blocks_x;
+    if (units > r->dual_units) {
+        drain_streams(r);
+        (void) hipFree(r->dual_flags); (void) hipFree(r->dual_list); (void) hipFree(r->dual_count);
+        r->dual_flags = nullptr; r->dual_list = nullptr; r->dual_count = nullptr;
+        r->dual_units = 0;
+        HIP_TRY(hipMalloc((void**) &r->dual_flags, units));
+        HIP_TRY(hipMalloc((void**) &r->dual_list, units * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**) &r->dual_count, 16 * sizeof(int)));
+        r->dual_units = units;
+    }
+    DualOcc d{};
+    d.on = 1;
+    for (int k = 0; k < 2; ++k) {
+        const PassPlan& plan = *plans[k];
+        FactorScratch& f = r->f_scratch[plan.f_buf];
+        FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
+        // the buffers about to be overwritten may still be read by an earlier sweep
+        if (f.used && !(tune(TUNE_SWEEP_DEBUG) & 8)) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
+        if (e && e->read_yet && !(tune(TUNE_SWEEP_DEBUG) & 16)) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
+        ChunkParams p = plan.p;
+        p.occ_flags_out = f.flags;
+        p.occ_list_out = f.list;
+        p.occ_count_out = f.count;
+        p.occ_slot_out = e ? e->slot : f.slot;
+        p.occ_count_host = e ? e->count_host : nullptr;
+        HIP_TRY(launch_occ_flags(p, plan.occ_mode, 1, s));
+        if (e) HIP_TRY(hipEventRecord(e->ev_count, s));
+        DualPass& P = d.pass[k];
+        P.axis = plan.p.axis; P.start = plan.start; P.dir = plan.dir;
+        P.blocks_x = plan.p.occ_blocks_x; P.blocks_y = plan.p.occ_blocks_y;
+        P.step100[0] = plan.p.a.step100; P.step100[1] = plan.p.r.step100;
+        P.fs_keep[0] = e ? e->base : nullptr;
+        P.fs_cap[0] = e ? (uint32_t) e->cap_blocks : 0u;
+        P.fs_spill[0] = f.store[0];
+        P.fs_keep[1] = nullptr;
+        P.fs_cap[1] = 0;
+        P.fs_spill[1] = f.store[1];
+        P.fs_slot = p.occ_slot_out;
+        P.flags = f.flags;
+    }
+    pc.occ_flags_out = r->dual_flags;
+    pc.occ_list_out = r->dual_list;
+    pc.occ_count_out = r->dual_count;
+    pc.occ_slot_out = nullptr;
+    pc.occ_count_host = nullptr;
+    HIP_TRY(launch_unit_flags(pc, d, s));
+    pc.occ_flags = nullptr;
+    pc.occ_list = r->dual_list;
+    pc.occ_count = r->dual_count;
+    pc.occ_grid_cap = 0;
+    HIP_TRY(launch_light_occlusion(pc, pa.occ_mode, s, &d));
+    ++r->dual_launches;
+    for (int k = 0; k < 2; ++k) {
+        const PassPlan& plan = *plans[k];
+        FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
+        HIP_TRY(hipEventRecord(r->f_scratch[plan.f_buf].ev_ready, s));
+        if (e) {
+            HIP_TRY(hipEventRecord(e->ev_filled, s));
+            e->enqueued = true;
+        }
+        plan.occ_enqueued = true;
+    }
     return TBRM_OK;
 }
 
@@ -1251,6 +1402,7 @@ struct HostProbe {
 
 int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs)
 {
+    if (int e = sweep_failed(r)) return e; // (an earlier sweep left the light volume undefined: nothing to build on)
     if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)
         if (int e = ensure_skipping(r)) return e;
     struct Unpin { // planning pins cache entries (use_kept / kept_new): released on every way out
@@ -1286,14 +1438,20 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
             PropParams p = base;
             p.b_added = q.b_added;
             if (int e = enqueue_pass_sliced(r, p, q.a, q.two ? &q.r : nullptr)) return e;
+            ++r->passes[2];
             continue;
         }
+        ++r->passes[plans[i].sweep ? 0 : 1];
         const PassPlan* next = i + 1 < specs.size() && chunked[i + 1] ? &plans[i + 1] : nullptr;
         // sweep passes: this pass's occlusion, and the next pass's behind it on the occlusion stream, so that it runs beside
-        // this pass's sweep
-        if (int e = enqueue_sweep_occlusion(r, plans[i])) { quiesce_occ_stream(r); return e; }
-        if (next)
-            if (int e = enqueue_sweep_occlusion(r, *next)) { quiesce_occ_stream(r); return e; }
+        // this pass's sweep — the two passes of a light in ONE launch where they sample the same positions (dual_fit)
+        auto occlusion_of = [&](size_t k) -> int {
+            if (k >= specs.size() || !chunked[k]) return TBRM_OK;
+            if (k + 1 < specs.size() && chunked[k + 1] && dual_fit(plans[k], plans[k + 1])) return enqueue_dual_occlusion(r, plans[k], plans[k + 1]);
+            return enqueue_sweep_occlusion(r, plans[k]);
+        };
+        if (int e = occlusion_of(i)) { quiesce_occ_stream(r); return e; }
+        if (int e = occlusion_of(i + 1)) { quiesce_occ_stream(r); return e; }
         probe.lap("occlusion");
         for (int c = 0; c < plans[i].n_chunks; ++c)
             if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e; // (enqueue_plan_chunk has drained the second stream)

@@ -21,7 +21,7 @@
 //
 // Forward progress. Tiles are dealt by an atomic ticket in upstream-first order: a tile only ever waits for tiles with a
 // smaller ticket, which have started — whatever the number of workgroups the device keeps resident. A poll gives up after
-// ~2^20 tries and raises SweepParams::error instead of hanging the device.
+// SweepParams::give_up_ticks of wall time (2 s by default) and raises SweepParams::error instead of hanging the device.
 //
 // Inside a tile: eight compute waves and one hand-off wave, ONE LDS-only barrier per slice.
 //  - A compute lane owns one column of two consecutive rows. Per slice it reads its pixels' four taps from an LDS plane
@@ -95,12 +95,14 @@ __device__ __forceinline__ void sweep_store_word(uint32_t* p, uint32_t w) { __hi
 // The slow path of a hand-off: the neighbour has not published the word yet. Its load is inline assembly so that the
 // compiler's wait-count bookkeeping of the caller never sees a loop with a memory operation in it (it would answer with
 // s_waitcnt vmcnt(0) at every later use of a request that is still in flight).
-__device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch, int* error)
+__device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch, int* error, unsigned long long give_up_ticks)
 {
     uint32_t w = 0;
-    for (int tries = 0; tries < (1 << 20); ++tries) {
+    const unsigned long long t0 = wall_clock64(); // (100 MHz, constant: a starved or shared device gets wall time, not a poll count)
+    for (;;) {
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
         if ((w >> 16) == epoch) return w;
+        if (wall_clock64() - t0 >= give_up_ticks) break;
         __builtin_amdgcn_s_sleep(2);
     }
     atomicOr(error, 1);
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
 #pragma unroll
                     for (int h = 0; h < HC; ++h) {
                         uint32_t w = hreg[K8][h];
-                        if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error);
+                        if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error, q.give_up_ticks);
                         if (hal_on[h]) {
 #pragma unroll
                             for (int si = 0; si < (RREC ? 1 : NS); ++si) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8((w >> (8 * si)) & 255u);

@@ -139,6 +139,8 @@ struct tbrm_resources {
     uint64_t plan_serial = 0;      // PassPlan::serial of the last plan made
     hipStream_t occ_stream = nullptr; // low priority; created with the first overlapped launch
     hipEvent_t occ_ev_fork[2]{}, occ_ev_ready[2]{};
+    bool occ_inputs_changed = true; // the volume / transfer function / skipping metadata were (re)written on `stream` since the
+                                    // occlusion stream last ordered itself behind it (ensure_skipping sets, order_behind_inputs clears)
     // the pipelined sweep (k_light_sweep, tbrm_light_sweep.hip): hand-off records of the two streams ([slice][tile][word],
     // never cleared: words carry the tag of the launch that wrote them), the tile tickets and the error word
     uint32_t* sweep_rec[2] = {nullptr, nullptr};
@@ -147,6 +149,7 @@ struct tbrm_resources {
     int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
     int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
     uint32_t sweep_epoch = 0;      // tag of the last sweep launch
+    int sweep_failed_bits = 0;     // latched error word (sweep_failed): the light volume is undefined until it is cleared
     unsigned long long* sweep_stamps = nullptr; // diagnostics (sweep_debug & 2): the last launch's per-tile time stamps
     int sweep_stamp_tiles = 0, sweep_stamp_tx = 0, sweep_stamp_sx = 0, sweep_stamp_sy = 0;
     std::vector<FactorEntry*> kept; // the factor cache
@@ -155,8 +158,18 @@ struct tbrm_resources {
     size_t f_est_blocks = 0;       // live blocks per pass seen under f_est_key (what a new entry is sized for)
     uint64_t f_est_key[2] = {0, 0};
     float f_est_win[4] = {0, 0, 0, 0};
-    FactorScratch f_scratch[2];
+    // Four, taken in rotation: a light's two passes are filled by ONE occlusion launch (DualOcc) while the sweeps of the operator
+    // before may still be reading the two before them
+    static constexpr int kFScratch = 4;
+    FactorScratch f_scratch[kFScratch];
     int f_buf = 0;                 // buffer of the most recent sweep pass
+    // work units of a dual occlusion launch (flags, ascending list of the live ones, their count): written and read on the
+    // occlusion stream only, one launch after the other
+    uint8_t* dual_flags = nullptr;
+    uint32_t* dual_list = nullptr;
+    int* dual_count = nullptr;
+    size_t dual_units = 0;
+    uint64_t dual_launches = 0;    // occlusion launches that served two passes (tbrm_launch_counters)
     float* d_ones = nullptr;       // 1024 floats of 1.0
     uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
 
@@ -184,6 +197,8 @@ struct tbrm_resources {
     bool ev_valid[2]{};
     uint64_t launches[3]{}; // chunk, slice, raymarch
     uint64_t sweep_launches = 0; // (of the chunk launches: the pipelined sweep kernel's)
+    uint64_t passes[3]{};        // axis passes run as a sweep / as the chunked chain / one slice per launch (tbrm_path_counters)
+    uint64_t occ_launches = 0;   // occlusion launches that served one pass (dual_launches: both passes of a light)
 };
 
 
@@ -260,11 +275,16 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 struct SweepFit { int sx = 0, sy = 0, hx = 0, hy = 0; bool two_way = false; int r_sx = 0, r_sy = 0, r_hx = 0, r_hy = 0; };
 bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit);
 void release_sweep(tbrm_resources* r);
-int sweep_check(tbrm_resources* r); // after the stream has drained: did a sweep kernel raise its error word?
+int sweep_check(tbrm_resources* r);  // after the stream has drained: did a sweep kernel raise its error word? (+ the stamps' print-out)
+int sweep_failed(tbrm_resources* r); // latches the error word; TBRM_OK or the (sticky) error
+void sweep_failure_cleared(tbrm_resources* r); // the light volume has been defined anew
+void drain_streams_public(tbrm_resources* r);
 float* plan_plane(const tbrm_resources* r, int boundary, int si);
 void* sliced_plane(const tbrm_resources* r, const PassPlan& plan, int boundary, int si);
 int enqueue_plan_chunk(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next = nullptr); // next: the plan enqueued after this one
 int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan); // a sweep pass's occlusion, ahead of its sweep (else: nothing)
+bool dual_fit(const PassPlan& a, const PassPlan& b);                    // may ONE occlusion launch serve both passes?
+int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& a, const PassPlan& b);
 void quiesce_occ_stream(tbrm_resources* r);  // waits for the occlusion stream and forgets what its buffers hold
 void release_kept(tbrm_resources* r);       // frees the factor cache (the streams must be idle)
 void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the factor cache (the streams must be idle)

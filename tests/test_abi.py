@@ -26,7 +26,8 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in tbrm.h but not exported by libtbrm.so"
     assert b"gfx950" in lib.tbrm_version()
-    assert lib.tbrm_abi_version() == 3  # include/tbrm.h TBRM_ABI_VERSION
+    header_version = int(re.search(r"#define\s+TBRM_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.tbrm_abi_version() == header_version == abi.ABI_VERSION  # (abi.load() refuses a library with another number)
 
 
 def test_struct_layouts_match_the_header():
@@ -97,6 +98,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
         "tbrm_light_cache_stats": lambda: lib.tbrm_light_cache_stats(z, None),
         "tbrm_sweep_launches": lambda: lib.tbrm_sweep_launches(z, None),
         "tbrm_light_cache_clear": lambda: lib.tbrm_light_cache_clear(z),
+        "tbrm_path_counters": lambda: lib.tbrm_path_counters(z, None),
         "tbrm_stream": lambda: lib.tbrm_stream(z, None),
         "tbrm_last_gpu_time_ms": lambda: lib.tbrm_last_gpu_time_ms(z, 0, None),
     }

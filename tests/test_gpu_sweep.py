@@ -293,3 +293,122 @@ def test_passes_of_one_and_two_brick_layers(gpu, oracle_mod, dims):
         orc.add_dir_light(ls[0], False, world)
         same(res, orc, f"{dims} removal")
         assert res.launch_counters()["sweep"] > 0
+
+
+# ---- one occlusion launch for both axis passes of a light (tbrm_internal.h DualOcc, tunable occ_dual) ------------------------
+
+DUAL_SCENES = [  # dims, light directions (every pair of pass axes, both orders), window
+    ((64, 48, 56), [(1, .35, -.5), (-.4, 1, -.3), (.2, -.3, -1), (-1, -.6, .4), (.6, -1, -.2), (-.3, .2, 1)]),
+    ((40, 72, 24), [(1, .1, .6), (.3, .2, -1), (-.2, 1, .5)]),           # planes that are not whole 16 x 16 blocks
+    ((88, 40, 104), [(-1, .5, .1), (.1, -.7, 1), (.45, 1, -.2)]),
+]
+
+
+@pytest.mark.parametrize("dims,dirs", DUAL_SCENES)
+@pytest.mark.parametrize("cache", [0, -1])
+def test_both_passes_of_a_light_share_one_occlusion_launch(gpu, oracle_mod, tunables, dims, dirs, cache):
+    """UVWOffset is the same for both axis passes of a light (LightingShaders.cpp:114-124), so one launch filters, windows and
+    looks the transfer function up once per voxel and writes both passes' factors. Forced on and off: the light volumes are the
+    oracle's — and therefore each other's — after every operator (adds, fused changes with one and with both lights sampled,
+    a removal), and the counters say which form ran."""
+    tunables("light_cache_mb", cache)
+    world = S.default_world()
+    results = {}
+    for dual in (1, 0):
+        tunables("occ_dual", dual)
+        res, orc = scene(oracle_mod, dims, seed=0x5EED0A00)
+        with res:
+            cur = list(dirs)
+            lights = [abi.DirLightParams(d, 0.45) for d in cur]
+            for k, light in enumerate(lights):
+                res.add_dir_light(light, True, world)
+                orc.add_dir_light(light, True, world)
+                same(res, orc, f"dual={dual} add {k}")
+            for k, light in enumerate(lights):  # small turns: fused Changes (cache on: the new light alone is sampled)
+                cur[k] = S.rotate_z(cur[k], 3.0)
+                new = abi.DirLightParams(cur[k], 0.45)
+                res.change_dir_light(light, new, world)
+                orc.change_dir_light(light, new, world)
+                same(res, orc, f"dual={dual} change {k}")
+                lights[k] = new
+            res.add_dir_light(lights[0], False, world)
+            orc.add_dir_light(lights[0], False, world)
+            same(res, orc, f"dual={dual} removal")
+            c = res.path_counters()
+            two_pass_ops = sum(1 for d in dirs if abi.host_light_passes(abi.DirLightParams(d, 0.45), world, dims)[1] == 2)
+            if dual:
+                assert c["occlusion_dual"] >= two_pass_ops, c
+            else:
+                assert c["occlusion_dual"] == 0 and c["occlusion_single"] > 0, c
+            assert c["passes_chain"] == 0 and c["passes_slice"] == 0, c
+            results[dual] = res.download_light_volume()
+    assert np.array_equal(results[0], results[1])
+
+
+def test_dual_occlusion_with_clip_plane_half_resolution_and_float_data(gpu, oracle_mod, tunables):
+    """The dual launch under the conditions that change its sample loop: an active clip plane (per-voxel AlphaWeight), a
+    half-resolution light volume (data : light = 2 : 1, more staged bricks per unit), float and 8-bit data, the Add shader's
+    guard on samples outside the cube versus the Change shader's border colour (an opaque shell)."""
+    for dtype, half, tf, window in ((np.float32, False, S.TF_A_KEYS, (0.5, 0.9, True, False)), (np.uint8, True, S.TF_B_KEYS, (0.5, 0.8, True, True)),
+                                    (np.uint16, True, S.TF_A_KEYS, (0.3, 1.4, False, False))):
+        dims = (96, 64, 80)
+        vol = S.make_volume_numpy(dims, dtype, 0x5EED0A01)
+        lut = abi.color_curve_to_lut(tf)
+        win = abi.WindowingParams(*window)
+        tr = abi.identity_transform(scale=(100.0, 120.0, 80.0), translation=(10.0, -5.0, 3.0), rotation=(0.1305262, 0.0, 0.0, 0.9914449))
+        world = abi.make_world(tr, clip_center=(12.0, -2.0, 5.0), clip_direction=(0.3, -0.2, 0.93))
+        for dual in (1, 0):
+            tunables("occ_dual", dual)
+            orc = oracle_mod.OracleScene(vol, False, half)
+            orc.set_tf_lut(lut)
+            orc.set_windowing(win)
+            with abi.Resources(dims, abi.DTYPE_FMT[np.dtype(dtype)], False, half_res=half) as res:
+                res.upload_volume(vol)
+                res.set_tf_lut(lut)
+                res.set_windowing(win)
+                res.clear_light_volume(0.0)
+                a, b = abi.DirLightParams((1, .4, -.55), 0.6), abi.DirLightParams((.97, .45, -.5), 0.6)
+                res.add_dir_light(a, True, world)
+                orc.add_dir_light(a, True, world)
+                same(res, orc, f"{dtype} half={half} dual={dual} add")
+                res.change_dir_light(a, b, world)
+                orc.change_dir_light(a, b, world)
+                same(res, orc, f"{dtype} half={half} dual={dual} change")
+                if dual and res.path_counters()["passes_sweep"]:
+                    assert res.path_counters()["occlusion_dual"] > 0
+
+
+def test_a_failed_sweep_is_reported_by_every_join_until_the_light_volume_is_cleared(gpu, oracle_mod, tunables):
+    """sweep_timeout_ms < 0: a tile that finds a neighbour's hand-off word missing gives up at once instead of polling — the
+    failure a starved or reset device produces after its timeout. The handle must not hand out what that sweep left behind:
+    flush, the light-volume download, the host-buffer frame, the operator timing and the next light operator all report it,
+    until ClearResourceLightVolumes defines the light volume again — after which the sweeps run as before."""
+    dims = (96, 96, 64)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0A02)
+    cam, tile, rp = S.default_camera(64, 64), abi.Tile(0, 0, 64, 64), abi.RaymarchParams(48.0, -1, True)
+    with res:
+        tunables("sweep_timeout_ms", -1)
+        failed = False
+        for k in range(6):  # (nine tiles per pass: a downstream tile practically always polls at least once)
+            try:
+                res.add_dir_light(S.light(k % 4), True, world)
+                res.flush()
+            except abi.TbrmError as e:
+                assert "undefined" in str(e), e
+                failed = True
+                break
+        assert failed, "no tile ever had to wait for a neighbour: the hook did not fire"
+        for call in (res.flush, res.download_light_volume, lambda: res.raymarch_lit(cam, tile, rp, world), lambda: res.last_gpu_time_ms(0),
+                     lambda: res.add_dir_light(S.light(0), True, world)):
+            with pytest.raises(abi.TbrmError, match="undefined"):
+                call()
+        tunables("sweep_timeout_ms", 0)
+        res.clear_light_volume(0.0)
+        before = res.path_counters()
+        for i in (0, 1):
+            res.add_dir_light(S.light(i), True, world)
+            orc.add_dir_light(S.light(i), True, world)
+        same(res, orc, "after the clear")
+        after = res.path_counters()
+        assert after["passes_sweep"] > before["passes_sweep"] and after["passes_chain"] == before["passes_chain"], (before, after)
