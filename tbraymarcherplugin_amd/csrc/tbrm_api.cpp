@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"occ_dual", 1},
+    {"sweep_timeout_ms", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -445,7 +445,10 @@ int tbrm_resources_destroy(tbrm_resources* r)
         (void) hipStreamSynchronize(r->occ_stream);
         (void) hipStreamDestroy(r->occ_stream);
         for (int b = 0; b < 2; ++b) { (void) hipEventDestroy(r->occ_ev_fork[b]); (void) hipEventDestroy(r->occ_ev_ready[b]); }
+        for (hipEvent_t e : r->op_done)
+            if (e) (void) hipEventDestroy(e);
     }
+    if (r->frame_done) (void) hipEventDestroy(r->frame_done);
     for (uint16_t* o : r->d_octree) (void) hipFree(o);
     for (uint8_t* d : r->d_dist) (void) hipFree(d);
     (void) hipFree(r->d_alpha_prefix);
@@ -832,6 +835,11 @@ int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tb
     if (int e = begin_timed(r, 1)) return e;
     HIP_TRY(launch_raymarch(p, r->stream));
     ++r->launches[2];
+    if (tune(TUNE_OCC_AFTER_FRAME) && r->occ_stream) {
+        if (!r->frame_done) HIP_TRY(hipEventCreateWithFlags(&r->frame_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(r->frame_done, r->stream));
+        r->frame_pending = true;
+    }
     return end_timed(r, 1);
 }
 

@@ -18,6 +18,14 @@
 
 namespace tbrm_host {
 
+// flags of the events that order the two streams (experiment: TBRM_EVENT_FLAGS=0 creates them with timing, i.e. with a marker of
+// their own in the queue at record time)
+static unsigned event_flags()
+{
+    static const unsigned f = [] { const char* e = getenv("TBRM_EVENT_FLAGS"); return e && *e ? (unsigned) atoi(e) : (unsigned) hipEventDisableTiming; }();
+    return f;
+}
+
 // ---- chunked propagation (tbrm_light_kernels.hip) --------------------------------------------------------------
 
 bool force_slice_kernel() { return tune(TUNE_FORCE_SLICE_KERNEL) == 1; }
@@ -494,9 +502,10 @@ static int ensure_occ_stream(tbrm_resources* r)
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, tune(TUNE_OCC_PRIORITY) == 1 ? 0 : least));
     for (int k = 0; k < 2; ++k) {
-        HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], event_flags()));
+        HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], event_flags()));
     }
+    for (hipEvent_t& ev : r->op_done) HIP_TRY(hipEventCreateWithFlags(&ev, event_flags()));
     return TBRM_OK;
 }
 
@@ -511,8 +520,8 @@ static int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int st
         HIP_TRY(hipStreamSynchronize(r->stream)); // (read from the occlusion stream's sweeps' predecessors: simplest to have it done)
     }
     if (!f.ev_ready) {
-        HIP_TRY(hipEventCreateWithFlags(&f.ev_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&f.ev_idle, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&f.ev_ready, event_flags()));
+        HIP_TRY(hipEventCreateWithFlags(&f.ev_idle, event_flags()));
     }
     const bool grow_store = blocks > f.store_blocks, grow_meta = blocks > f.meta_blocks;
     bool need = grow_meta;
@@ -614,10 +623,27 @@ static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t wan
     const size_t bytes = want * 2048 * sizeof(float);
     FactorEntry* e = nullptr;
     auto fits = [&](const FactorEntry* c) { return !c->pinned && c->cap_blocks >= want && c->cap_blocks <= want + want / 2 + 64 && c->table_blocks >= table_blocks; };
+    auto reusable = [&](const FactorEntry* c) { return fits(c) && ((c->resolved && !c->valid) || c->spent || !c->enqueued); };
+    // An entry that the operator just before this one read (the removed side of its Change) is still being read by that
+    // operator's sweeps when this operator's occlusion could start — beside those very sweeps, which leave two thirds of a
+    // CU's issue slots idle. Reusing it would make the occlusion wait for them (measured: the whole 0.38 ms of it exposed
+    // in front of every operator of the benchmark's loop); an entry retired an operator earlier is free by then.
+    auto settled = [&](const FactorEntry* c) { return !(c->read_yet && c->last_read_op + 1 >= r->op_serial); };
     for (FactorEntry* c : r->kept) // dropped and spent entries first, oldest first
-        if (fits(c) && ((c->resolved && !c->valid) || c->spent || !c->enqueued) && (!e || c->last_use < e->last_use)) e = c;
+        if (reusable(c) && settled(c) && (!e || c->last_use < e->last_use)) e = c;
+    size_t budget = 0; // (asked for only when an allocation is on the cards: hipMemGetInfo takes milliseconds)
+    auto room_for_a_new_one = [&]() {
+        budget = kept_budget(r);
+        if (kept_bytes(r) + bytes > budget) return false;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return false; }
+        return free_b >= 2 * bytes + ((size_t) 1 << 30);
+    };
+    if (!e && !room_for_a_new_one()) // (no room to grow: the entry that is still being read, and the wait)
+        for (FactorEntry* c : r->kept)
+            if (reusable(c) && (!e || c->last_use < e->last_use)) e = c;
     if (!e) {
-        const size_t budget = kept_budget(r);
+        if (budget == 0) budget = kept_budget(r);
         // make room: entries that are of no use go first, then the least recently used
         auto victim = [&]() -> FactorEntry* {
             FactorEntry* v = nullptr;
@@ -643,7 +669,7 @@ static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t wan
         e = new FactorEntry{};
         bool ok = hipMalloc((void**) &e->base, bytes) == hipSuccess && hipMalloc((void**) &e->slot, table_blocks * sizeof(int32_t)) == hipSuccess &&
                   hipHostMalloc((void**) &e->count_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
-        for (hipEvent_t* ev : {&e->ev_count, &e->ev_filled, &e->ev_idle}) ok = ok && hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+        for (hipEvent_t* ev : {&e->ev_count, &e->ev_filled, &e->ev_idle}) ok = ok && hipEventCreateWithFlags(ev, event_flags()) == hipSuccess;
         if (!ok) { // out of memory: do without
             (void) hipGetLastError();
             free_entry(e);
@@ -782,6 +808,11 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
             plan.f_entry[0] = kept_new(r, key_a, want, blocks);
         }
     } else if (int e = ensure_factor_scratch(r, plan.f_buf, blocks, 0)) return e; // (its events order the buffers' reuse)
+    if (tune(TUNE_SWEEP_DEBUG) & 4)
+        fprintf(stderr, "[tbrm plan] op %llu axis %d mode %d occ_mode %d buf %d (used %d) entry a %p (hit %d, read_yet %d, last read op %llu) entry r %p; pool %zu\n",
+                (unsigned long long) r->op_serial, pa.axis, mode, plan.occ_mode, plan.f_buf, (int) r->f_scratch[plan.f_buf].used, (void*) plan.f_entry[0], (int) plan.f_hit[0],
+                plan.f_entry[0] ? (int) plan.f_entry[0]->read_yet : -1, plan.f_entry[0] ? (unsigned long long) plan.f_entry[0]->last_read_op : 0ull, (void*) plan.f_entry[1],
+                r->kept.size());
     if (cache_on && change) retire(*pr);
     if (cache_on && !change && b_added < 0.0f) retire(pa);
     r->f_buf = plan.f_buf;
@@ -983,6 +1014,44 @@ static int order_behind_inputs(tbrm_resources* r)
     return TBRM_OK;
 }
 
+// The occlusion stream is about to overwrite the scratch buffer / cache entry of `plan`, which earlier sweeps may still be
+// reading. Readers of an EARLIER operator are waited for through that operator's "sweeps done" event — one wait per occlusion
+// launch whatever the number of buffers (wait_for_readers; *op collects the latest such operator) —, readers of THIS operator
+// (a reset of many lights runs through all four buffers within one run_passes) through the buffer's own event.
+static int note_readers(tbrm_resources* r, const PassPlan& plan, uint64_t* op)
+{
+    FactorScratch& f = r->f_scratch[plan.f_buf];
+    FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
+    if (f.used && !(tune(TUNE_SWEEP_DEBUG) & 8)) {
+        if (f.last_read_op >= r->op_serial && f.idle_recorded) HIP_TRY(hipStreamWaitEvent(r->occ_stream, f.ev_idle, 0));
+        else if (f.last_read_op >= r->op_serial) *op = UINT64_MAX; // (no event of its own: everything enqueued so far)
+        else *op = std::max(*op, f.last_read_op);
+    }
+    if (e && e->read_yet && !(tune(TUNE_SWEEP_DEBUG) & 16)) {
+        if (e->last_read_op >= r->op_serial && e->idle_recorded) HIP_TRY(hipStreamWaitEvent(r->occ_stream, e->ev_idle, 0));
+        else if (e->last_read_op >= r->op_serial) *op = UINT64_MAX;
+        else *op = std::max(*op, e->last_read_op);
+    }
+    return TBRM_OK;
+}
+static int wait_for_readers(tbrm_resources* r, uint64_t op)
+{
+    if (r->frame_pending && tune(TUNE_OCC_AFTER_FRAME)) { // (tunable occ_after_frame: not beside the frame that is on its way)
+        HIP_TRY(hipStreamWaitEvent(r->occ_stream, r->frame_done, 0));
+        r->frame_pending = false;
+    }
+    if (op == 0) return TBRM_OK;
+    const int k = (int) (op % tbrm_resources::kOpEvents);
+    if (op != UINT64_MAX && r->op_done_serial[k] >= op) { // (what a later operator recorded in the same slot is later still)
+        HIP_TRY(hipStreamWaitEvent(r->occ_stream, r->op_done[k], 0));
+        return TBRM_OK;
+    }
+    // that operator never recorded its event (it failed half way): everything enqueued on the handle's stream so far
+    HIP_TRY(hipEventRecord(r->occ_ev_fork[1], r->stream));
+    HIP_TRY(hipStreamWaitEvent(r->occ_stream, r->occ_ev_fork[1], 0));
+    return TBRM_OK;
+}
+
 // The occlusion of a sweep pass (plan_pass_sweep): the whole pass's empty-block flags, work list and block ranks, then one
 // launch that leaves the factors of the live blocks block-compact in the cache entry being filled and / or the scratch
 // buffer — all on the occlusion stream, beside whatever the handle's stream is running (the sweep of the pass before, a
@@ -994,9 +1063,12 @@ int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
     FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
     hipStream_t s = r->occ_stream;
     if (int e2 = order_behind_inputs(r)) return e2;
-    // the buffers about to be overwritten may still be read by an earlier sweep
-    if (f.used && !(tune(TUNE_SWEEP_DEBUG) & 8)) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
-    if (e && e->read_yet && !(tune(TUNE_SWEEP_DEBUG) & 16)) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
+    // the buffers about to be overwritten may still be read by earlier sweeps
+    {
+        uint64_t op = 0;
+        if (int e2 = note_readers(r, plan, &op)) return e2;
+        if (int e2 = wait_for_readers(r, op)) return e2;
+    }
     ChunkParams p = plan.p;
     p.occ_flags_out = f.flags;
     p.occ_list_out = f.list;
@@ -1086,13 +1158,17 @@ int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& pa, const PassPlan
     }
     DualOcc d{};
     d.on = 1;
+    // the buffers about to be overwritten may still be read by earlier sweeps
+    {
+        uint64_t op = 0;
+        if (int e2 = note_readers(r, pa, &op)) return e2;
+        if (int e2 = note_readers(r, pb, &op)) return e2;
+        if (int e2 = wait_for_readers(r, op)) return e2;
+    }
     for (int k = 0; k < 2; ++k) {
         const PassPlan& plan = *plans[k];
         FactorScratch& f = r->f_scratch[plan.f_buf];
         FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
-        // the buffers about to be overwritten may still be read by an earlier sweep
-        if (f.used && !(tune(TUNE_SWEEP_DEBUG) & 8)) HIP_TRY(hipStreamWaitEvent(s, f.ev_idle, 0));
-        if (e && e->read_yet && !(tune(TUNE_SWEEP_DEBUG) & 16)) HIP_TRY(hipStreamWaitEvent(s, e->ev_idle, 0));
         ChunkParams p = plan.p;
         p.occ_flags_out = f.flags;
         p.occ_list_out = f.list;
@@ -1213,12 +1289,19 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
     HIP_TRY(launch_light_sweep(p, q, plan.mode, r->stream));
     ++r->launches[0];
     ++r->sweep_launches;
-    HIP_TRY(hipEventRecord(f.ev_idle, r->stream));
+    // who read what: later operators wait for this operator's "sweeps done" event (wait_for_readers); the buffers' own events
+    // are recorded only where a later pass of THIS operator could take the buffer again (an operator of more than two sweep
+    // passes: every marker between two dependent kernels costs the stream a few microseconds)
+    if (r->op_many_passes) HIP_TRY(hipEventRecord(f.ev_idle, r->stream));
     f.used = true;
+    f.last_read_op = r->op_serial;
+    f.idle_recorded = r->op_many_passes;
     for (int si = 0; si < ns; ++si)
         if (FactorEntry* const e = plan.f_entry[si]) {
-            HIP_TRY(hipEventRecord(e->ev_idle, r->stream));
+            if (r->op_many_passes) HIP_TRY(hipEventRecord(e->ev_idle, r->stream));
             e->read_yet = true;
+            e->last_read_op = r->op_serial;
+            e->idle_recorded = r->op_many_passes;
         }
     return TBRM_OK;
 }
@@ -1403,6 +1486,7 @@ struct HostProbe {
 int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs)
 {
     if (int e = sweep_failed(r)) return e; // (an earlier sweep left the light volume undefined: nothing to build on)
+    ++r->op_serial;
     if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)
         if (int e = ensure_skipping(r)) return e;
     struct Unpin { // planning pins cache entries (use_kept / kept_new): released on every way out
@@ -1432,6 +1516,7 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         chunked.push_back(e == TBRM_OK ? 1 : 0);
         probe.lap("plan");
     }
+    r->op_many_passes = specs.size() > 2;
     for (size_t i = 0; i < specs.size(); ++i) {
         const PassSpec& q = specs[i];
         if (!chunked[i]) {
@@ -1456,6 +1541,11 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         for (int c = 0; c < plans[i].n_chunks; ++c)
             if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e; // (enqueue_plan_chunk has drained the second stream)
         probe.lap("pass");
+    }
+    if (r->occ_stream) { // "this operator's sweeps are done" (wait_for_readers)
+        const int k = (int) (r->op_serial % tbrm_resources::kOpEvents);
+        HIP_TRY(hipEventRecord(r->op_done[k], r->stream));
+        r->op_done_serial[k] = r->op_serial;
     }
     return TBRM_OK;
 }

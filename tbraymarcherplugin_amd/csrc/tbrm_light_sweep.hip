@@ -248,6 +248,8 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         const unsigned long long until = wall_clock64() + (unsigned long long) hops * (unsigned long long) q.stagger_ns / 10ull; // (100 MHz)
         while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
+    if (q.give_up_ticks == 0 && ticket == 0 && threadIdx.x == 0) atomicOr(q.error, 1); // (tunable sweep_timeout_ms < 0, a test hook: "the
+                                                                                       // first tile gave up" — what a starved device reports after its timeout)
     const bool stamping = (q.debug & 2) != 0 && q.stamps != nullptr && threadIdx.x == 0;
     if (stamping) q.stamps[4 * tile_lin + 0] = wall_clock64();
 

@@ -70,6 +70,8 @@ struct FactorEntry {
     hipEvent_t ev_filled = nullptr; // the occlusion that fills the entry is done (occlusion stream)
     hipEvent_t ev_idle = nullptr;   // the last sweep that reads the entry is done (the handle's stream)
     bool read_yet = false;          // (ev_idle has been recorded)
+    uint64_t last_read_op = 0;      // tbrm_resources::op_serial of the operator whose sweep read it last
+    bool idle_recorded = false;     // ... and whether that sweep recorded ev_idle (else: the operator's op_done event)
     FactorKey key{};
     bool enqueued = false;          // the occlusion that fills it is on the occlusion stream
     bool resolved = false;          // the count has been read: valid / dropped
@@ -93,6 +95,8 @@ struct FactorScratch {
     hipEvent_t ev_ready = nullptr;  // the occlusion into this buffer is done (occlusion stream)
     hipEvent_t ev_idle = nullptr;   // the sweep that read this buffer is done (the handle's stream)
     bool used = false;              // (ev_idle has been recorded)
+    uint64_t last_read_op = 0;      // tbrm_resources::op_serial of the operator whose sweep read it
+    bool idle_recorded = false;     // ... and whether that sweep recorded ev_idle (else: the operator's op_done event)
 };
 
 struct tbrm_resources {
@@ -154,6 +158,16 @@ struct tbrm_resources {
     int sweep_stamp_tiles = 0, sweep_stamp_tx = 0, sweep_stamp_sx = 0, sweep_stamp_sy = 0;
     std::vector<FactorEntry*> kept; // the factor cache
     uint64_t kept_clock = 0;       // its LRU clock
+    uint64_t op_serial = 0;        // whole-volume light operators run so far (run_passes)
+    // "every sweep of operator k is done" (the handle's stream), k mod 8: what the occlusion stream waits for before it
+    // overwrites a scratch buffer or a cache entry that operator k's sweeps read — ONE wait per occlusion launch whatever the
+    // number of buffers involved
+    static constexpr int kOpEvents = 8;
+    hipEvent_t op_done[kOpEvents]{};
+    uint64_t op_done_serial[kOpEvents]{}; // which operator each was last recorded for (0: never)
+    bool op_many_passes = false;   // the operator being enqueued has more than two sweep passes: its buffers may come round again
+    hipEvent_t frame_done = nullptr; // the last lit frame is done (the handle's stream; tunable occ_after_frame)
+    bool frame_pending = false;      // ... recorded since the occlusion stream last waited for it
     uint64_t kept_hits = 0, kept_computed = 0; // stream-passes whose occlusion came from the cache / was computed (tbrm_light_cache_stats)
     size_t f_est_blocks = 0;       // live blocks per pass seen under f_est_key (what a new entry is sized for)
     uint64_t f_est_key[2] = {0, 0};
