@@ -189,6 +189,9 @@ struct SweepParams {
     int debug;              // diagnostics (sweep_debug tunable): bit 0 = tiles do not wait for each other (WRONG results: slice time alone);
                             // bit 1 = every tile leaves four time stamps (10 ns units) in `stamps`
     unsigned long long* stamps; // [tile][4]: start of slice 0, end of slice 63, end of the last slice, after the write-back
+    int reinit_slice;       // > 0: the launch's first reinit_slice slices lie in front of the volume (a pass that runs downwards from a
+                            // depth that is no multiple of 8, padded to whole brick layers): slice reinit_slice - 1 hands on the pass's
+                            // initial plane instead of what it computed
     int* error;             // set when a tile gave up waiting (bit 0) or found its taps outside the halo (bit 1)
     unsigned long long give_up_ticks; // how long a poll waits for a neighbour's word, in 10 ns ticks of wall_clock64 (tunable sweep_timeout_ms)
 };

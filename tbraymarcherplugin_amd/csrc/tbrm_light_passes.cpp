@@ -83,7 +83,9 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
 {
     if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident || r->sweep_failed_bits) return false;
     if (mode != PASS_ADD && mode != PASS_CHANGE) return false;
-    if (pa.td[2] % 8 != 0 || (pa.start & 7) != (pa.dir > 0 ? 0 : 7)) return false;
+    // (a depth that is no multiple of 8 is padded to whole brick layers: plan_pass_sweep; a downward pass then needs a second
+    // layer behind the ragged one)
+    if (pa.td[2] % 8 != 0 && pa.dir < 0 && pa.td[2] < 9) return false;
     fit = SweepFit{};
     TapSide side[2][2];
     bool opposite = false;
@@ -745,7 +747,12 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
 {
     SweepFit sfit;
     if (!sweep_fit(r, pa, pr, mode, sfit)) return TBRM_ERR_UNSUPPORTED;
-    const int D = pa.td[2];
+    // The pass over the light volume padded to whole brick layers along its axis (the bricked layout has the padding voxels):
+    // D slices from `start`, of which the `pad` slices beyond the volume come last when the pass runs upwards — garbage in,
+    // garbage out, into voxels nothing reads — and first when it runs downwards, where the last of them hands on the initial
+    // plane (SweepParams::reinit_slice).
+    const int D = ceil_div(pa.td[2], 8) * 8, pad = D - pa.td[2];
+    const int start = pa.dir > 0 ? 0 : D - 1;
     if (D > sweep_max_slices() || tune(TUNE_SPARSE_OCC) == 0 || tune(TUNE_OCC_LIST) == 0) return TBRM_ERR_UNSUPPORTED;
     if (int e = ensure_skipping(r)) return e; // (the work list needs the per-brick emptiness bits)
     if (int e = ensure_occ_stream(r)) return e;
@@ -755,6 +762,8 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     plan.sweep = true;
     fill_pass_params(r, base, pa, pr, b_added, 0.0f, plan);
     ChunkParams& p = plan.p;
+    plan.D = D;
+    plan.start = start;
     plan.M = plan.S = D;
     plan.n_chunks = plan.n_spans = plan.chunks_of_pass = 1;
     plan.sparse = plan.work_list = true;
@@ -831,6 +840,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 2;
     q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : 1500;
     q.debug = tune(TUNE_SWEEP_DEBUG);
+    q.reinit_slice = pa.dir < 0 ? pad : 0;
     {
         const int ms = tune(TUNE_SWEEP_TIMEOUT_MS);
         q.give_up_ticks = ms < 0 ? 0ull : (unsigned long long) (ms == 0 ? 2000 : ms) * 100000ull;
@@ -1612,7 +1622,7 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         // A pass that the pipelined sweep takes is not paired: a sweep of its own costs less than its half of a paired chain.
         auto kept = [&](const tbrm_light_pass& q) {
             SweepFit sf;
-            return sweep_fit(r, q, nullptr, PASS_ADD, sf) && q.td[2] <= sweep_max_slices() && tune(TUNE_SPARSE_OCC) != 0 && tune(TUNE_OCC_LIST) != 0;
+            return sweep_fit(r, q, nullptr, PASS_ADD, sf) && ceil_div(q.td[2], 8) * 8 <= sweep_max_slices() && tune(TUNE_SPARSE_OCC) != 0 && tune(TUNE_OCC_LIST) != 0;
         };
         Entry* partner = nullptr;
         ChunkFit fa;

@@ -35,8 +35,10 @@
 //    the upstream neighbours' cells of the current slice into the halo of the plane being built, and requests the words it
 //    will need PF slices from now. Nothing it waits for delays the compute waves unless the neighbours really are late.
 // No thread owns halo pixels, so a slice costs what its 1024 pixels cost. Arithmetic per voxel is the chain's and the
-// reference's, bit for bit. Spans start on a brick layer of the light volume and are whole layers long (the planner sends
-// anything else to the chain).
+// reference's, bit for bit. Spans start on a brick layer of the light volume and are whole layers long: a pass whose length is
+// no multiple of 8 is run over the volume padded to whole layers — the slices beyond the volume compute garbage into the light
+// volume's padding voxels (which nothing reads), behind the real slices when the pass runs upwards, and in front of them when it
+// runs downwards: then the last of them hands the pass's initial plane on (SweepParams::reinit_slice).
 #include "tbrm_device_sampling.h"
 #include "tbrm_light_chain.h"
 
@@ -343,11 +345,14 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
 
         lds_barrier(); // (the loader's first factor slice is in LDS)
         __builtin_amdgcn_s_setprio(3); // (its few instructions go first: what it publishes is what the neighbours wait for)
-        auto group = [&](int g, auto last_c) {
-            constexpr bool LAST = decltype(last_c)::value;
+        auto group = [&](int g, auto first_c, auto last_c) {
+            constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
             sweep_each_const([&](auto kc) {
                 constexpr int K8 = decltype(kc)::value, CUR = K8 & 1;
                 const int s = g * 8 + K8;
+                // (a pass that starts inside a brick layer: the slice before its first real one leaves the initial plane behind)
+                bool reinit = false;
+                if constexpr (FIRST) reinit = K8 + 1 == q.reinit_slice;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
                 if ((TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
                     uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RW));
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                         if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error, q.give_up_ticks);
                         if (hal_on[h]) {
 #pragma unroll
-                            for (int si = 0; si < (RREC ? 1 : NS); ++si) plane(CUR ^ 1, si)[hal_dst[h]] = decode_u8((w >> (8 * si)) & 255u);
+                            for (int si = 0; si < (RREC ? 1 : NS); ++si) plane(CUR ^ 1, si)[hal_dst[h]] = reinit ? stream(si).init_value : decode_u8((w >> (8 * si)) & 255u);
                         }
                     }
                     if constexpr (RREC) { // the removed light's cells: published long ago (a word that is not there is an error)
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                             const uint32_t w = rreg[K8][h];
                             if (rh_on[h]) {
                                 if ((w >> 16) != (q.r_epoch & 0xffffu)) atomicOr(q.error, 4);
-                                plane(CUR ^ 1, 1)[rh_dst[h]] = decode_u8(w & 255u);
+                                plane(CUR ^ 1, 1)[rh_dst[h]] = reinit ? stream(1).init_value : decode_u8(w & 255u);
                             }
                         }
                     }
@@ -386,8 +391,9 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
             }, std::make_integer_sequence<int, 8>{});
         };
-        for (int g = 0; g < G - 1; ++g) group(g, std::false_type{});
-        group(G - 1, std::true_type{});
+        if (q.reinit_slice > 0) group(0, std::true_type{}, std::false_type{}); // (G >= 2: the launcher's check)
+        for (int g = q.reinit_slice > 0 ? 1 : 0; g < G - 1; ++g) group(g, std::false_type{}, std::false_type{});
+        group(G - 1, std::false_type{}, std::true_type{});
     } else if (wave > NWC) {
         // ================================================= the factor loader =====================================================
         // Block-compact hand-over (ChunkStream::fs_*): per slice group each of the tile's 2 x 2 occlusion blocks of a stream
@@ -538,8 +544,8 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             lv_prev[lv_at[0]] = (uint8_t) (w0 ? (uint32_t) qn.x : code_old[0]);
             lv_prev[lv_at[1]] = (uint8_t) (w1 ? (uint32_t) qn.y : code_old[1]);
         };
-        auto group = [&](int g, auto last_c) {
-            constexpr bool LAST = decltype(last_c)::value;
+        auto group = [&](int g, auto first_c, auto last_c) {
+            constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
             uint8_t* const lv_layer = lvt + (g % 3) * kLvBuf;
             sweep_each_const([&](auto kc) {
                 constexpr int K8 = decltype(kc)::value, CUR = K8 & 1;
@@ -604,6 +610,13 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 for (int si = 0; si < NS; ++si) { qc[si].x = __builtin_floorf(qc[si].x); qc[si].y = __builtin_floorf(qc[si].y); }
 #pragma unroll
                 for (int si = 0; si < NS; ++si) pval[si] = decode2(qc[si]);
+                if constexpr (FIRST) { // the slice before the pass's first real one (a pass that starts inside a brick layer) hands on the
+                                       // initial plane, whatever the slices in front of the volume made of it (SweepParams::reinit_slice)
+                    if (K8 + 1 == q.reinit_slice) {
+#pragma unroll
+                        for (int si = 0; si < NS; ++si) pval[si] = (v2f) stream(si).init_value;
+                    }
+                }
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
                     const ChunkStream& st = stream(si);
@@ -622,11 +635,12 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             }, std::make_integer_sequence<int, 8>{});
         };
         __builtin_amdgcn_s_setprio(2); // (ahead of any occlusion workgroup that shares the CU: this loop is one dependent chain)
-        for (int g = 0; g < G - 1; ++g) {
-            group(g, std::false_type{});
+        if (q.reinit_slice > 0) group(0, std::true_type{}, std::false_type{});
+        for (int g = q.reinit_slice > 0 ? 1 : 0; g < G - 1; ++g) {
+            group(g, std::false_type{}, std::false_type{});
             if (g == 7 && stamping) q.stamps[4 * tile_lin + 1] = wall_clock64();
         }
-        group(G - 1, std::true_type{});
+        group(G - 1, std::false_type{}, std::true_type{});
         __builtin_amdgcn_s_setprio(0);
         if (stamping) q.stamps[4 * tile_lin + 2] = wall_clock64();
         if constexpr (LV) { // the last slice's voxels, then the last layer
@@ -700,6 +714,7 @@ hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mo
     const bool aligned = (p.n_steps & 7) == 0 && (p.j0 & 7) == (p.dir > 0 ? 0 : 7) && p.occ_phase == 0 && p.n_steps <= 8 * kSweepFlagGroups;
     if (!aligned || !p.compact || !p.ones || !p.a.fs_slot || (mode == PASS_CHANGE && !p.r.fs_slot)) return hipErrorInvalidConfiguration;
     if (q.r_from_records && (mode != PASS_CHANGE || !q.rec[1])) return hipErrorInvalidConfiguration;
+    if (q.reinit_slice < 0 || q.reinit_slice > 7 || (q.reinit_slice > 0 && p.n_steps < 16)) return hipErrorInvalidConfiguration;
     if (mode == PASS_ADD) return launch_sweep2<PASS_ADD>(p, q, s);
     if (mode == PASS_CHANGE) return launch_sweep2<PASS_CHANGE>(p, q, s);
     if (mode == PASS_PLANES) return launch_sweep2<PASS_PLANES>(p, q, s);

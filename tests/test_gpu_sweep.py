@@ -44,7 +44,7 @@ def test_sweep_runs_where_it_applies_and_declines_the_rest(gpu, oracle_mod):
         c = res.launch_counters()
         assert c["sweep"] == n and c["chunk"] == n and c["slice"] == 0, c
         same(res, orc, "sweeps")
-    # a depth that is not whole brick layers along one axis: passes along that axis take the chain, the others sweep
+    # a depth that is not whole brick layers along one axis: the sweep runs over the padded volume (round 4; the chain before)
     dims = (64, 48, 52)
     res, orc = scene(oracle_mod, dims)
     with res:
@@ -52,8 +52,19 @@ def test_sweep_runs_where_it_applies_and_declines_the_rest(gpu, oracle_mod):
             res.add_dir_light(S.light(i), True, world)
             orc.add_dir_light(S.light(i), True, world)
         c = res.launch_counters()
-        assert 0 < c["sweep"] < c["chunk"] and c["slice"] == 0, c
-        same(res, orc, "mixed sweep / chain")
+        assert c["sweep"] == c["chunk"] > 0 and c["slice"] == 0, c
+        same(res, orc, "ragged depth")
+    # what still declines: a downward pass over fewer than nine slices of a ragged depth (one padded layer: nothing behind it)
+    dims = (40, 40, 5)
+    res, orc = scene(oracle_mod, dims)
+    with res:
+        for dz in (1, -1):  # one of the two first passes runs downwards
+            light = abi.DirLightParams((.1, .2, dz), 0.4)
+            res.add_dir_light(light, True, world)
+            orc.add_dir_light(light, True, world)
+        p = res.path_counters()
+        assert p["passes_chain"] + p["passes_slice"] >= 1 and p["passes_sweep"] >= 1, p
+        same(res, orc, "five slices")
     # a float light volume: the chain alone
     vol = S.make_volume_numpy((48, 48, 48), np.uint16, 7)
     with abi.Resources((48, 48, 48), abi.FMT_G16, True) as res:
@@ -406,3 +417,70 @@ def test_a_failed_sweep_is_reported_by_every_join_until_the_light_volume_is_clea
         same(res, orc, "after the clear")
         after = res.path_counters()
         assert after["passes_sweep"] > before["passes_sweep"] and after["passes_chain"] == before["passes_chain"], (before, after)
+
+
+RAGGED = [  # light-volume dimensions that are no multiples of 8 (or of anything), lights through all six faces
+    (67, 45, 53), (41, 90, 33), (100, 100, 57), (9, 70, 70), (75, 12, 130),
+]
+
+
+@pytest.mark.parametrize("dims", RAGGED)
+@pytest.mark.parametrize("cache", [0, -1])
+def test_pass_lengths_that_are_no_multiple_of_eight_are_swept(gpu, oracle_mod, tunables, dims, cache):
+    """A scan's depth is whatever the scanner made it (512 x 512 x 373), and a half-resolution light volume rounds odd sizes
+    up (RaymarchVolume.cpp:850-855): the sweep runs such passes over the volume padded to whole brick layers — upwards the extra
+    slices come last, downwards they come first and the last of them hands the initial plane on. Adds through all six faces,
+    fused changes, lights that pull two ways, removals: the oracle's light volume after every operator, no chain, no slice loop."""
+    tunables("light_cache_mb", cache)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0B00 + dims[0])
+    dirs = [(1, .35, -.5), (-.4, 1, -.3), (.2, -.3, -1), (-1, -.6, .4), (.6, -1, -.2), (-.3, .2, 1)]
+    with res:
+        for k, d in enumerate(dirs):
+            light = abi.DirLightParams(d, 0.3)
+            res.add_dir_light(light, True, world)
+            orc.add_dir_light(light, True, world)
+            same(res, orc, f"{dims} add {d}")
+        for k, d in enumerate(dirs):
+            new_d = S.rotate_z(d, 4.0) if k % 2 == 0 else (d[0], d[1], -d[2] * 0.9) if abs(d[2]) < 0.45 else S.rotate_z(d, -3.0)
+            res.change_dir_light(abi.DirLightParams(d, 0.3), abi.DirLightParams(new_d, 0.3), world)
+            orc.change_dir_light(abi.DirLightParams(d, 0.3), abi.DirLightParams(new_d, 0.3), world)
+            same(res, orc, f"{dims} change {d} -> {new_d}")
+            dirs[k] = new_d
+        res.add_dir_light(abi.DirLightParams(dirs[0], 0.3), False, world)
+        orc.add_dir_light(abi.DirLightParams(dirs[0], 0.3), False, world)
+        same(res, orc, f"{dims} removal")
+        p = res.path_counters()
+        assert p["passes_sweep"] > 0, p
+        if max(dims) <= 3 * min(dims):  # (a flat volume's slanted passes reach further than the sweep's planes hold: those take the chain)
+            assert p["passes_chain"] == 0 and p["passes_slice"] == 0, p
+
+
+def test_half_resolution_light_volume_of_an_odd_scan_is_swept(gpu, oracle_mod):
+    """187 = (373 + 1) / 2 slices: the case the N3 loader produces (LoadMHDFileIntoVolumeNormalized + half-resolution light volume)."""
+    dims = (120, 96, 373)
+    vol = S.make_volume_numpy(dims, np.uint16, 0x5EED0B10)
+    lut = abi.color_curve_to_lut(S.TF_A_KEYS)
+    win = abi.WindowingParams(0.5, 0.9, True, False)
+    world = S.default_world()
+    orc = oracle_mod.OracleScene(vol, False, True)
+    orc.set_tf_lut(lut)
+    orc.set_windowing(win)
+    with abi.Resources(dims, abi.FMT_G16, False, half_res=True) as res:
+        assert res.light_dims == (60, 48, 187)
+        res.upload_volume(vol)
+        res.set_tf_lut(lut)
+        res.set_windowing(win)
+        res.clear_light_volume(0.0)
+        for i in (2, 5):  # the two lights whose first pass runs along z, down and up
+            res.add_dir_light(S.light(i), True, world)
+            orc.add_dir_light(S.light(i), True, world)
+            same(res, orc, f"light {i}")
+        new = abi.DirLightParams(S.rotate_z(S.LIGHTS[2][0], 6.0), S.LIGHTS[2][1])
+        res.change_dir_light(S.light(2), new, world)
+        orc.change_dir_light(S.light(2), new, world)
+        same(res, orc, "change")
+        p = res.path_counters()
+        # (the passes along z, 187 slices, are swept; the second passes of these lights run along y over a 60 x 187 plane 48 slices
+        # deep: their taps lie up to 14 texels from the pixel — beyond the sweep's planes — and take the chain)
+        assert p["passes_sweep"] >= 3, p
