@@ -71,6 +71,50 @@ def relaunch_under_torchrun(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+def kernel_source_hash():
+    """sha1 over the kernel sources: what the committed counter summaries under profiles/ were collected from (tools/pmc_traffic.py
+    and tools/issue_roofline.py record it; a summary collected from other sources is not quoted)."""
+    import hashlib
+
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "tbraymarcherplugin_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(kind, per_step):
+    """The newest profiles/rNN_<kind>.json — HBM traffic / instruction-issue counters of this very command, collected in separate
+    rocprofv3 --pmc passes (tools/measure_round.sh) — if it still describes the kernels this run launched: same kernel sources
+    (kernel_source_hash) and the same launches per step (per_step: this run's tbrm_path_counters over the timed loop). Returns
+    (data or None, where it came from or why it is not quoted)."""
+    import glob
+    import re
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{kind}.json")), key=lambda q: int(re.search(r"r(\d+)_", os.path.basename(q)).group(1)))
+    if not paths:
+        return None, f"no profiles/rNN_{kind}.json"
+    path = paths[-1]
+    rel = os.path.relpath(path, ROOT)
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return None, f"{rel} unreadable: {e}"
+    sig = data.get("_signature")
+    if not sig:
+        return None, f"{rel} carries no launch signature (collected before round 4): not quoted"
+    if sig.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{rel} was collected from other kernel sources (hash {sig.get('kernel_source_hash')}, now {kernel_source_hash()}): stale, not quoted"
+    for key, want in (sig.get("launches_per_step") or {}).items():
+        have = per_step.get(key)
+        if have is None or abs(have - want) > 0.15 * max(want, 1.0):
+            return None, f"{rel} was collected with {want:.2f} {key} launches per step, this run made {have}: not quoted"
+    return data, rel
+
+
 def gpu_ms(torch, stream, fn):
     """GPU time of whatever fn() enqueues on the library's stream, by HIP events recorded on that stream."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -320,6 +364,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    paths0 = res.path_counters()
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k, False)
@@ -330,6 +375,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    paths1 = res.path_counters()
+    # which kernels the timed steps launched (include/tbrm.h tbrm_path_counters), per step
+    light_paths = {k: round((paths1[k] - paths0[k]) / max(args.steps, 1), 3) for k in paths1}
     pending = [None, None]
     out, gathered = outs[last[0]], gathers[last[0]]
     if dist is not None:
@@ -492,32 +540,27 @@ def main():
     # one ChangeDirLight makes (tools/pmc_traffic.py "_per_operator_call")
     traffic = None
     traffic_source = None
-    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.config == 3 and n_gpus == 1:
-        try:
-            with open(pmc_path) as f:
-                pmc = json.load(f)
+    per_step = {"k_light_sweep": light_paths["launches_sweep"], "k_light_occlusion": light_paths["occlusion_single"] + light_paths["occlusion_dual"],
+                "k_raymarch_lit": light_paths["raymarch"]}
+    if args.config == 3 and n_gpus == 1 and not args.raymarch_only:
+        pmc, traffic_source = committed_counters("pmc_traffic", per_step)
+        if pmc is not None:
             per_call = pmc["_per_operator_call"]
-            traffic = per_call["raymarch_hbm_bytes"] if dom["kernel"].startswith("k_raymarch") else per_call["change_dir_light_hbm_bytes"]
-            traffic = int(traffic)
-            traffic_source = ("profiles/r03_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                              "(tools/measure_round.sh), NOT measured in this run")
-        except Exception:
-            traffic = None
+            traffic = int(per_call["raymarch_hbm_bytes"] if dom["kernel"].startswith("k_raymarch") else per_call["change_dir_light_hbm_bytes"])
+            traffic_source += (": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/measure_round.sh), NOT measured in "
+                               "this run; checked against this run's kernel sources and launches per step")
     # why the fraction is what it is: the instruction-issue view of the hot kernels (tools/issue_roofline.py over two more
-    # --pmc passes of this command; committed numbers, like the traffic)
+    # --pmc passes of this command; committed numbers, like the traffic, under the same check)
     issue = None
-    issue_path = os.path.join(ROOT, "profiles", "r03_issue.json")
-    if os.path.exists(issue_path) and args.config == 3 and n_gpus == 1:
-        try:
-            with open(issue_path) as f:
-                raw = json.load(f)
-            issue = {k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in raw.items()}
-            issue["source"] = ("profiles/r03_issue.json: rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / "
+    if args.config == 3 and n_gpus == 1 and not args.raymarch_only:
+        raw, where = committed_counters("issue", per_step)
+        if raw is not None:
+            issue = {k: {kk: vv for kk, vv in v.items() if kk != "per_launch"} for k, v in raw.items() if not k.startswith("_")}
+            issue["source"] = (where + ": rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / "
                                "SQ_ACTIVE_INST_LDS / GRBM_GUI_ACTIVE passes of this command (tools/measure_round.sh), NOT measured in this run; "
                                "valu_issue_frac = SQ_INSTS_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE)")
-        except Exception:
-            issue = None
+        else:
+            issue = {"source": where}
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4)}
@@ -561,6 +604,7 @@ def main():
             "gpu_ms": dict({"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4)},
                            **{k: round(v, 4) for k, v in ops_ms.items()},
                            first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
+            "light_paths_per_step": light_paths,  # tbrm_path_counters over the timed loop: sweep / chain / slice passes and launches, occlusion launches
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)
             "scaling_detail": scaling_note,

@@ -188,7 +188,9 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * bit 2 the host's time per operator phase, bit 5 leaves out the events behind tbrm_last_gpu_time_ms), occ_dual (1 = the two
  * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
  * 0 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
- * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook). Unknown name: TBRM_ERR_INVALID_ARG. */
+ * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook), sweep_epoch_preset (0; > 0: a
+ * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), occ_after_frame (0; 1 = an
+ * operator's occlusion waits for the lit frame in front of it: measured, loses). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
 

@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
+    {"sweep_timeout_ms", 0}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];

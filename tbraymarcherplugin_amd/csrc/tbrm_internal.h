@@ -307,6 +307,8 @@ enum Tunable : int {
                              // store / the cache entry to be idle (WRONG results: what gates its start?), 32: no timing events
     TUNE_SWEEP_TIMEOUT_MS,   // how long a sweep tile waits for a neighbour's hand-off word before it gives up and raises the handle's error
                              // word (0: 2 s; < 0: not at all — a test hook: every word that is not there yet fails the launch)
+    TUNE_SWEEP_EPOCH_PRESET, // > 0: a handle's first sweep launch continues from this launch tag (a test hook: the 16-bit tags of the
+                             // hand-off records start over after 65535 launches)
     TUNE_OCC_AFTER_FRAME,    // 1: an operator's occlusion does not start beside a lit frame that is still running (both are bound by
                              // the same thing, the vector ALUs) but beside the sweeps behind it (which leave two thirds of the issue slots idle)
     TUNE_OCC_DUAL,           // 1: the two axis passes of a light share ONE occlusion launch where their sampling positions are bit-equal

@@ -213,6 +213,10 @@ static int ensure_sweep(tbrm_resources* r, size_t words, size_t words1 = 0)
 // (launches: how many consecutive launches must not have the tags start over between them)
 static int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch, uint32_t launches = 1)
 {
+    if (!r->sweep_epoch_preset_done && tune(TUNE_SWEEP_EPOCH_PRESET) > 0) { // (a test hook: the 16-bit tags start over after 65535 launches)
+        r->sweep_epoch = (uint32_t) tune(TUNE_SWEEP_EPOCH_PRESET) & 0xffffu;
+        r->sweep_epoch_preset_done = true;
+    }
     if (++r->sweep_epoch + (launches - 1) >= (1u << 16)) { // 2^16 launches later: tags start over
         HIP_TRY(hipMemsetAsync(r->sweep_rec[0], 0, r->sweep_rec_words * sizeof(uint32_t), r->stream));
         if (r->sweep_rec[1]) HIP_TRY(hipMemsetAsync(r->sweep_rec[1], 0, r->sweep_rec1_words * sizeof(uint32_t), r->stream));
@@ -781,13 +785,15 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     estimate_scope(r, base);
     for (FactorEntry* e : r->kept) resolve_entry(r, e, false); // (counts that have arrived sharpen the estimate)
     const bool cache_on = cache_usable(r);
-    FactorEntry *have_a = nullptr, *have_r = nullptr;
+    FactorEntry *have_a = nullptr, *have_r = nullptr, *refill = nullptr;
     FactorKey key_a{};
     if (cache_on) {
         key_a = factor_key(r, base, pa, mode == PASS_ADD);
         have_a = kept_find(r, key_a);
         if (change) have_r = kept_find(r, factor_key(r, base, *pr, false));
-        if (change && have_a && !have_r) have_a = nullptr; // (the removed light alone is not computed: both are)
+        // (the removed light alone is not computed: both are — and the added light's factors go into the entry that already
+        // holds them, not into a second one with the same key)
+        if (change && have_a && !have_r) { refill = have_a; have_a = nullptr; }
     }
     // whatever is kept of a light that this pass takes out of the scene (the removed side of a Change, a removal) is of no
     // further use unless the light comes back: first in line when a buffer is needed (kept_new)
@@ -814,7 +820,13 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
             // the blocks of a large one (CT-like volumes are mostly air: 512^3 of the benchmark keeps 40 %)
             const size_t unknown = blocks * 2048 * sizeof(float) <= ((size_t) 256 << 20) ? blocks : blocks / 2;
             const size_t want = r->f_est_blocks ? std::min(blocks, r->f_est_blocks + r->f_est_blocks / 32 + 64) : std::max<size_t>(unknown, 1);
-            plan.f_entry[0] = kept_new(r, key_a, want, blocks);
+            if (refill && refill->cap_blocks >= want && refill->table_blocks >= blocks && !refill->pinned) {
+                refill->resolved = refill->valid = refill->enqueued = refill->spent = false;
+                refill->pinned = true;
+                refill->last_use = ++r->kept_clock;
+                *refill->count_host = 0;
+                plan.f_entry[0] = refill;
+            } else plan.f_entry[0] = kept_new(r, key_a, want, blocks);
         }
     } else if (int e = ensure_factor_scratch(r, plan.f_buf, blocks, 0)) return e; // (its events order the buffers' reuse)
     if (tune(TUNE_SWEEP_DEBUG) & 4)

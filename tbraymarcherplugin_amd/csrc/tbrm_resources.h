@@ -153,6 +153,7 @@ struct tbrm_resources {
     int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
     int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
     uint32_t sweep_epoch = 0;      // tag of the last sweep launch
+    bool sweep_epoch_preset_done = false; // (tunable sweep_epoch_preset has been applied to this handle)
     int sweep_failed_bits = 0;     // latched error word (sweep_failed): the light volume is undefined until it is cleared
     unsigned long long* sweep_stamps = nullptr; // diagnostics (sweep_debug & 2): the last launch's per-tile time stamps
     int sweep_stamp_tiles = 0, sweep_stamp_tx = 0, sweep_stamp_sx = 0, sweep_stamp_sy = 0;

@@ -1,6 +1,6 @@
 """BASELINE configs 3, 4 and 5 at their FULL sizes on one MI355X.
 
-Config 3 (the metric's config) is checked against the oracle itself: the whole operator sequence of SURVEY.md 8d at
+Config 3 (the metric's config) is checked against the oracle itself (and, round 4, so is config 4's illumination): the whole operator sequence of SURVEY.md 8d at
 512^3 — four Adds, a fused Change, a Change across cube faces (remove + add) — leaves the oracle's UNORM8 light volume
 bit for bit, and the 1024^2 / 512-step frame is the oracle's within 1e-4 (about half a minute of oracle time on the GPU
 box's host cores). Configs 4 and 5 are quoted for 8 GPUs; here the whole job runs on one, and the checks are the
@@ -118,6 +118,33 @@ def test_config4_chunks_equal_slices_and_slabs_equal_one_handle(gpu, tunables):
     finally:
         for h in handles:
             h.close()
+
+
+def test_config4_light_volume_against_the_oracle_at_1024(gpu, oracle_mod):
+    """Config 4's illumination at its full size against the ORACLE, not only kernel against kernel: an Add of L0 (a pass along x,
+    a pass along z, 1024 slices each, four 32 x 32 tiles per CU) and the fused Change of a second light leave the oracle's 2^30
+    UNORM8 voxels bit for bit (about a minute of oracle time on the GPU box's host cores)."""
+    cfg, vol = device_volume(4)
+    world = S.default_world()
+    vol_np = vol.cpu().numpy()
+    orc = oracle_mod.OracleScene(vol_np, cfg["light_32bit"])
+    orc.set_tf_lut(abi.color_curve_to_lut(S.tf_keys(cfg["tf"])))
+    orc.set_windowing(abi.WindowingParams(*cfg["window"]))
+    old, new = S.light(1), abi.DirLightParams(S.rotate_z(S.LIGHTS[1][0], 5.0), S.LIGHTS[1][1])
+    with handle_for(cfg, vol) as res:
+        res.clear_light_volume(0.0)
+        res.add_dir_light(S.light(0), True, world)
+        orc.add_dir_light(S.light(0), True, world)
+        got = res.download_light_volume()
+        assert np.array_equal(got, orc.light), f"after the Add: {np.count_nonzero(got != orc.light)} of {got.size} voxels differ"
+        res.add_dir_light(old, True, world)
+        orc.add_dir_light(old, True, world)
+        res.change_dir_light(old, new, world)
+        orc.change_dir_light(old, new, world)
+        got = res.download_light_volume()
+        assert np.array_equal(got, orc.light), f"after the Change: {np.count_nonzero(got != orc.light)} of {got.size} voxels differ"
+        p = res.path_counters()
+        assert p["passes_sweep"] == 6 and p["passes_chain"] == 0 and p["passes_slice"] == 0, p
 
 
 def test_config5_skipping_and_tiles_at_2048(gpu):

@@ -484,3 +484,27 @@ def test_half_resolution_light_volume_of_an_odd_scan_is_swept(gpu, oracle_mod):
         # (the passes along z, 187 slices, are swept; the second passes of these lights run along y over a 60 x 187 plane 48 slices
         # deep: their taps lie up to 14 texels from the pixel — beyond the sweep's planes — and take the chain)
         assert p["passes_sweep"] >= 3, p
+
+
+def test_launch_tags_start_over_after_65535_launches(gpu, oracle_mod, tunables):
+    """The hand-off words carry a 16-bit launch tag and are never cleared between launches; after 65535 launches both record
+    buffers are zeroed and the tags start over (a two-way Change reserves two consecutive tags). sweep_epoch_preset puts a
+    fresh handle a few launches in front of that point: ordinary sweeps, fused and two-way Changes across the wrap leave the
+    oracle's light volume — a stale word accepted as current would not."""
+    tunables("sweep_epoch_preset", 0xFFFF - 9)
+    dims = (96, 96, 64)
+    world = S.default_world()
+    res, orc = scene(oracle_mod, dims, seed=0x5EED0C00)
+    with res:
+        pairs = TWO_WAY[:3] * 3
+        for k, (d_old, d_new) in enumerate(pairs):  # add (2 launches), two-way change (>= 3), removal (2): ~7 launches per round
+            old, new = abi.DirLightParams(d_old, 0.5), abi.DirLightParams(d_new, 0.5)
+            res.add_dir_light(old, True, world)
+            orc.add_dir_light(old, True, world)
+            res.change_dir_light(old, new, world)
+            orc.change_dir_light(old, new, world)
+            same(res, orc, f"round {k} after the change")
+            res.add_dir_light(new, False, world)
+            orc.add_dir_light(new, False, world)
+            same(res, orc, f"round {k} after the removal")
+        assert res.launch_counters()["sweep"] > 40

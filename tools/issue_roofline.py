@@ -58,8 +58,20 @@ def main():
         if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c:
             entry["wait_share"] = round(c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], 4)
         out[fam] = entry
+    csvs = [a for a in sys.argv[2:] if a.endswith(".csv")]
+    if csvs:  # what it was collected from (bench.py quotes it only for the same kernel sources and launches per step)
+        import os
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from pmc_traffic import signature
+
+        first = next(csv.DictReader(open(csvs[0])))["Counter_Name"]
+        out["_signature"] = signature(csvs[0], first)
     json.dump(out, open(sys.argv[1], "w"), indent=1)
     for fam, e in out.items():
+        if fam.startswith("_"):
+            print(fam, e)
+            continue
         print(fam, {k: v for k, v in e.items() if k != "per_launch"})
         for k, v in e["per_launch"].items():
             print(f"    {k:28s} {v:18.1f}")

@@ -53,6 +53,33 @@ def operator_runs(path, counter, scale):
     return runs
 
 
+def signature(path, counter):
+    """What the summary was collected from, so that bench.py can refuse to quote it for other kernels: the kernel sources' hash
+    (bench.kernel_source_hash) and the launches per step of the hot kernel families AFTER the first frame (= the steps)."""
+    import os
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
+
+    rows = []
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] == counter:
+            rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"]))
+    rows.sort()
+    counts, frames = collections.Counter(), 0
+    for _, name in rows:
+        if "k_raymarch_lit" in name:
+            frames += 1
+        if frames == 0:
+            continue  # (the setup's ResetAllLights)
+        for fam in ("k_light_sweep", "k_light_occlusion", "k_raymarch_lit"):
+            if fam in name:
+                counts[fam] += 1
+    # (the light kernels behind the last frame belong to no step: none in bench.py --timed-only)
+    steps = max(frames, 1)
+    return {"kernel_source_hash": kernel_source_hash(), "steps": frames, "launches_per_step": {k: round(v / steps, 3) for k, v in sorted(counts.items())}}
+
+
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
@@ -79,6 +106,7 @@ def main():
             "change_dir_light_hbm_bytes": sum(b for b, _ in calls) / len(calls),
             "change_dir_light_hbm_bytes_by_kind": {k: {"calls": len(v), "hbm_bytes": sum(v) / len(v)} for k, v in sorted(by_kind.items())},
             "raymarch_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ray) / sum(v["launches"] for v in ray)}
+    out["_signature"] = signature(sys.argv[1], "FETCH_SIZE")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if k.startswith("_"):
