@@ -144,6 +144,10 @@ def main():
     ap.add_argument("--light-parallel-reset", action="store_true",
                     help="N>1: the untimed ResetAllLights deals the lights over the ranks and combines the light volumes with "
                          "reduce-scatter + all-gather (SURVEY.md §8e) instead of adding every light on every GPU")
+    ap.add_argument("--light-update", choices=["redundant", "broadcast"], default="redundant",
+                    help="N>1: how the step's ChangeDirLight reaches every GPU. redundant (default): every GPU computes it (no exchange). "
+                         "broadcast: rank 0 computes it and broadcasts the light volume (SURVEY.md 8e's other option; on the critical path "
+                         "Change + broadcast + frame / N cannot beat Change + frame / N: reported for comparison)")
     ap.add_argument("--slab-illumination", action="store_true",
                     help="N>1: the timed ChangeDirLight is partitioned over the ranks in light-volume z slabs (plane halo exchange "
                          "per chunk / z pipeline, slabs.py), followed by an all-gather of the light volume, instead of being "
@@ -330,6 +334,15 @@ def main():
                 with slab_member.stream_context():  # RCCL point-to-point operations ordered with the library's stream
                     slabs.change_dir_light([slab_member], slab_fabric, lights[li], new, world)
                     slabs.gather_light_volume([slab_member], slab_fabric, gather_light)
+            elif args.light_update == "broadcast" and dist is not None and not one_gpu_dry_run:
+                from tbraymarcherplugin_amd import sharding
+
+                def bcast(t, src):  # ordered behind the operator on the library's stream; the frame behind it waits for it there
+                    with torch.cuda.stream(lib_stream):
+                        dist.broadcast(t, src)
+
+                sharding.change_dir_light_on_owner(lambda: res.change_dir_light(lights[li], new, world), lambda: sharding.device_light_tensor(res),
+                                                   rank, 0, bcast)
             else:
                 res.change_dir_light(lights[li], new, world)
             lights[li] = new
@@ -380,7 +393,12 @@ def main():
     light_paths = {k: round((paths1[k] - paths0[k]) / max(args.steps, 1), 3) for k in paths1}
     pending = [None, None]
     out, gathered = outs[last[0]], gathers[last[0]]
+    per_rank_ms = None
     if dist is not None:
+        mine = torch.tensor([elapsed / max(args.steps, 1) * 1e3], dtype=torch.float64, device=red_device)
+        every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(float(x.item()), 4) for x in every]
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -604,6 +622,11 @@ def main():
             "gpu_ms": dict({"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4)},
                            **{k: round(v, 4) for k, v in ops_ms.items()},
                            first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
+            "distributed": None if dist is None else {
+                "backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ms_per_step_per_rank": per_rank_ms,
+                "light_update": args.light_update if slab_member is None else "slabs",
+                # what the tiles alone gain (the part of a step that shards), next to the whole step's figure in scaling_detail
+                "raymarch_ms_this_rank": round(ray_ms, 4)},
             "light_paths_per_step": light_paths,  # tbrm_path_counters over the timed loop: sweep / chain / slice passes and launches, occlusion launches
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)

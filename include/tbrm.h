@@ -189,7 +189,8 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
  * 0 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
  * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook), sweep_epoch_preset (0; > 0: a
- * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), occ_after_frame (0; 1 = an
+ * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), ray_tables (1 = the
+ * lit march reads the data taps' offsets out of LDS tables where a step is at most one texel; 0 = computes them per sample), occ_after_frame (0; 1 = an
  * operator's occlusion waits for the lit frame in front of it: measured, loses). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
@@ -399,7 +400,7 @@ TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);
  * per launch; out[3] sweep launches (a two-way Change takes two per pass), out[4] chain launches, out[5] slice launches;
  * out[6] occlusion launches that served one pass, out[7] occlusion launches that served both passes of a light
  * (tunable occ_dual); out[8] stream-passes whose occlusion came from the factor cache; out[9] lit-raymarch launches;
- * out[10..15] reserved (0). */
+ * out[10] sweep launches that propagated two lights' passes at once (tbrm_add_dir_lights); out[11..15] reserved (0). */
 #define TBRM_PATH_COUNTERS 16
 TBRM_API int tbrm_path_counters(const tbrm_resources* res, uint64_t out[TBRM_PATH_COUNTERS]);
 /* The factor cache of the light operators (no counterpart in the reference, invisible in the results). The expensive half

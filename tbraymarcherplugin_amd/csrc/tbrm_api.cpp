@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
+    {"sweep_timeout_ms", 0}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -215,6 +215,7 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     p.steps = rp->steps;
     p.jitter_frame = rp->jitter_frame;
     p.bnx = r->bn[0]; p.bny = r->bn[1]; p.bnz = r->bn[2];
+    p.tab = r->d_ray_tab;
     return TBRM_OK;
 }
 
@@ -415,6 +416,23 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     for (int k = 0; k < 2; ++k) CREATE_TRY(hipMalloc((void**) &r->d_dist[k], nb_pad));
     CREATE_TRY(hipMalloc((void**) &r->d_alpha_prefix, 258 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**) &r->d_counter, sizeof(unsigned long long)));
+    if (!r->resident) { // k_raymarch_lit's offset tables (RayParams::tab): per axis, for texel index i = -2 .. n + 1, where the data
+                        // sampler's address mode puts it in the bricked layout, and its brick's share of the linear brick index
+        const int dn[3] = {desc->dim_x, desc->dim_y, desc->dim_z};
+        std::vector<uint2> tab;
+        for (int c = 0; c < 3; ++c)
+            for (int i = -2; i < dn[c] + 2; ++i) {
+                int w = i;
+                if (desc->data_address_mode == TBRM_ADDRESS_CLAMP) w = clamp_int(i, 0, dn[c] - 1);
+                else { w %= dn[c]; if (w < 0) w += dn[c]; }
+                const uint32_t in_brick = (uint32_t) (w & 7) << (3 * c);
+                const uint32_t brick = (uint32_t) (w >> 3) * (c == 0 ? 1u : (c == 1 ? (uint32_t) r->dbn[0] : (uint32_t) (r->dbn[0] * r->dbn[1])));
+                tab.push_back(make_uint2((brick << 9) | in_brick, brick));
+            }
+        if (tab.size() & 1) tab.push_back(make_uint2(0, 0));
+        CREATE_TRY(hipMalloc((void**) &r->d_ray_tab, tab.size() * sizeof(uint2)));
+        CREATE_TRY(hipMemcpy(r->d_ray_tab, tab.data(), tab.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    }
     for (int k = 0; k < 2; ++k)
         for (int e = 0; e < 2; ++e) CREATE_TRY(hipEventCreate(&r->ev[k][e]));
     // the light volume render target starts cleared
@@ -453,6 +471,7 @@ int tbrm_resources_destroy(tbrm_resources* r)
     for (uint8_t* d : r->d_dist) (void) hipFree(d);
     (void) hipFree(r->d_alpha_prefix);
     (void) hipFree(r->d_counter);
+    (void) hipFree(r->d_ray_tab);
     (void) hipFree(r->d_out);
     for (auto& k : r->ev)
         for (hipEvent_t e : k)
@@ -1135,6 +1154,7 @@ int tbrm_path_counters(const tbrm_resources* r, uint64_t out[TBRM_PATH_COUNTERS]
     out[6] = r->occ_launches; out[7] = r->dual_launches;
     out[8] = r->kept_hits;
     out[9] = r->launches[2];
+    out[10] = r->pair_sweeps;
     return TBRM_OK;
 }
 

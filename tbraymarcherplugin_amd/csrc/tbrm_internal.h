@@ -219,6 +219,8 @@ struct RayParams {
     const float* depth; // may be null
     float* out;         // tile_w*tile_h*4
     const uint32_t* empty_bits; // one bit per brick; null when skipping is off
+    const uint2* tab;           // k_raymarch_lit TAB: per axis and texel index -2 .. n + 1 the {voxel offset, brick-index part} of the
+                                // addressed texel (x, then y, then z); null: none (slab-resident handles)
     const uint8_t* skip_dist;   // per brick: Chebyshev distance (bricks, capped) to the nearest non-empty brick; null when skipping is off
     int bnx, bny, bnz;  // brick grid
     unsigned long long* sample_counter; // count kernel only
@@ -307,6 +309,7 @@ enum Tunable : int {
                              // store / the cache entry to be idle (WRONG results: what gates its start?), 32: no timing events
     TUNE_SWEEP_TIMEOUT_MS,   // how long a sweep tile waits for a neighbour's hand-off word before it gives up and raises the handle's error
                              // word (0: 2 s; < 0: not at all — a test hook: every word that is not there yet fails the launch)
+    TUNE_RAY_TABLES,         // 0: k_raymarch_lit computes the data taps' offsets per sample even where its LDS offset tables apply
     TUNE_SWEEP_EPOCH_PRESET, // > 0: a handle's first sweep launch continues from this launch tag (a test hook: the 16-bit tags of the
                              // hand-off records start over after 65535 launches)
     TUNE_OCC_AFTER_FRAME,    // 1: an operator's occlusion does not start beside a lit frame that is still running (both are bound by

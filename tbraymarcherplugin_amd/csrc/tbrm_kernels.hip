@@ -10,6 +10,7 @@
 // Compiled with -ffp-contract=off; see tbrm_device_math.h for the arithmetic contract.
 #include "tbrm_device_sampling.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace tbrm {
@@ -153,7 +154,9 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // performing every addition of the ray, so every sample, and the early exit, are bit for bit those of the whole march.
 #ifndef TBRM_RAY_EXP
 #define TBRM_RAY_EXP 0 // timing experiments (WRONG frames; tools/ray_ablation.sh): 1 = no pow, 2 = no light-volume taps, 4 = no data taps
-#endif                 // (constant value), 8 = no in-order accumulation (every lane adds its own sample), 16 = no leap-distance look-up
+#endif                 // (constant value), 8 = no in-order accumulation (every lane adds its own sample), 16 = no leap-distance look-up;
+                       // A/B variants with RIGHT frames: 32 = the four lanes of a ray exchange their samples by DPP quad broadcasts instead
+                       // of through LDS, 64 = the same with selects instead of exec-mask regions (both measured, both lost)
 #ifdef TBRM_RAY_STATS // diagnostics build (tools/ray_stats.sh): how full the waves of the lit march are
 __device__ unsigned long long g_ray_stats[4]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples
 extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsigned long long* out, int reset)
@@ -179,17 +182,27 @@ __device__ __forceinline__ void sweep4(F&& f)
     f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
 }
 
-template <int DFMT, int LFMT, int DMODE, int kRayLanes, bool SLAB = false>
+// TAB: the data volume's texel -> voxel-offset arithmetic (address mode, +1 tap, bricked offset, brick index of the leap-distance
+// look-up: ~45 integer instructions per sample, more than the filter itself) comes out of three small tables the workgroup copies
+// into LDS, one {voxel offset, brick-index part} pair per texel index -2 .. n + 1 and axis (tbrm_api.cpp build_ray_tables); a
+// sample's base and +1 entries of an axis arrive with one 16-byte LDS read. The host picks it when no sample position can lie more than two texels outside the volume
+// (a step of at most one texel: positions stay within one step of the unit cube) and the tables are small.
+template <int DFMT, int LFMT, int DMODE, int kRayLanes, bool SLAB = false, bool TAB = false>
 __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6 waves per SIMD (80 VGPRs): measured 3-8 % faster than 5 or 8
 {
     static_assert(kRayLanes == 4 || kRayLanes == 8, "instantiated for 4 and 8 lanes per ray");
+    static_assert(!(TAB && SLAB), "slab stages keep the arithmetic path (relocated layers)");
+    extern __shared__ __attribute__((aligned(16))) uint2 s_tab[]; // TAB: [x | y | z], n + 4 entries each
+    const uint2* const tab_x = s_tab;
+    const uint2* const tab_y = tab_x + (TAB ? p.data.nx + 4 : 0);
+    const uint2* const tab_z = tab_y + (TAB ? p.data.ny + 4 : 0);
     constexpr int PW = 4, PH = kRayLanes == 4 ? 4 : 2; // rays of a wave: a PW x PH pixel patch
     constexpr int kRayBlockW = 2 * PW, kRayBlockH = 2 * PH;
     constexpr int LSH = kRayLanes == 4 ? 2 : 3;
     __shared__ float4 s_tf[256];
     __shared__ float4 s_x[256]; // per lane: (colour * alpha, alpha) of its sample; alpha < 0: nothing to accumulate
     s_tf[threadIdx.x] = p.tf[threadIdx.x];
-    __syncthreads();
+    if constexpr (!TAB) __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = lane & (kRayLanes - 1), r = lane >> LSH; // sample slot, ray within the wave
@@ -208,6 +221,13 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
     const int max_steps = valid ? (int) fl : 0;
     const float final_step = valid ? actual - fl : 0.0f;
     const int n_samples = max_steps + (final_step > 0.0f ? 1 : 0); // the full steps, then the fractional one (:84-93)
+    if constexpr (TAB) { // the tables (the handle built them once: tbrm_resources::d_ray_tab), unless no ray of the workgroup meets the volume
+        if (__syncthreads_or(n_samples > 0)) {
+            const int n16 = (p.data.nx + p.data.ny + p.data.nz + 12 + 1) >> 1;
+            for (int i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(s_tab)[i] = reinterpret_cast<const uint4*>(p.tab)[i];
+            __syncthreads();
+        }
+    }
     const float sv0 = ray.lcv[0] * step_size, sv1 = ray.lcv[1] * step_size, sv2 = ray.lcv[2] * step_size;
     const float step_world = 100.0f * step_size;
     float pos0 = ray.pos[0], pos1 = ray.pos[1], pos2 = ray.pos[2];
@@ -277,15 +297,27 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         // (after a trip in which no lane of the wave sampled, the lanes inside their proven-empty range look their brick up
         // again as well: all ranges then start from here, and the wave can take the trips they share in one go — below)
         const bool renew = eager && has && !live && idx <= safe_until;
+        TapOffsets tab_dt{}; // TAB: the data taps' offsets, out of the tables
         if (live || renew) {
             texel_split(q0, nx, ix, fx);
             texel_split(q1, ny, iy, fy);
             texel_split(q2, nz, iz, fz);
+            uint32_t tab_brick = 0;
+            if constexpr (TAB) { // (indices -2 .. n: the host's promise; the clamp only keeps a broken promise inside the tables)
+                const int tx = min(max(ix + 2, 0), p.data.nx + 2), ty = min(max(iy + 2, 0), p.data.ny + 2), tz = min(max(iz + 2, 0), p.data.nz + 2);
+                const uint2 ax = tab_x[tx], bx1 = tab_x[tx + 1], ay = tab_y[ty], by1 = tab_y[ty + 1], az = tab_z[tz], bz1 = tab_z[tz + 1];
+                tab_dt.x0 = ax.x; tab_dt.x1 = bx1.x; tab_dt.y0 = ay.x; tab_dt.y1 = by1.x; tab_dt.z0 = az.x; tab_dt.z1 = bz1.x;
+                tab_brick = ax.y + ay.y + az.y;
+            }
             if (p.skip_dist && !(TBRM_RAY_EXP & 16)) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
-                const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
-                const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
-                const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
-                const int dist = p.skip_dist[(bz * p.bny + by) * p.bnx + bx];
+                int dist;
+                if constexpr (TAB) dist = p.skip_dist[tab_brick];
+                else {
+                    const int bx = address<DMODE>(ix, p.data.nx) >> kBrickShift;
+                    const int by = address<DMODE>(iy, p.data.ny) >> kBrickShift;
+                    const int bz = address<DMODE>(iz, p.data.nz) >> kBrickShift;
+                    dist = p.skip_dist[(bz * p.bny + by) * p.bnx + bx];
+                }
                 live = live && dist == 0;
                 // Every brick within Chebyshev distance < dist is empty as well. From anywhere inside this brick a base
                 // tap has to move more than 8*(dist-1) texels along some axis to leave them, and a base tap moves at
@@ -304,7 +336,9 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
             RawTaps<DFMT> dtaps;
             RawTaps<LFMT> ltaps;
             float gx, gy, gz;
-            const TapOffsets dt = tap_offsets<DMODE, SLAB>(p.data, ix, iy, iz);
+            TapOffsets dt;
+            if constexpr (TAB) dt = tab_dt;
+            else dt = tap_offsets<DMODE, SLAB>(p.data, ix, iy, iz);
             dtaps.issue(p.data.data, dt);
             // LightVolume.SampleLevel(Wrap, saturate(CurPos)) (WindowedRaymarchMaterials.usf:30)
             const float sp0 = saturate_(q0), sp1 = saturate_(q1), sp2 = saturate_(q2);
@@ -342,10 +376,26 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 le0 = le0 + (x.x * om); le1 = le1 + (x.y * om); le2 = le2 + (x.z * om); le3 = le3 + (x.w * om);
                 if (le3 > 0.95f && base < max_steps) { le3 = 1.0f; done = true; }
             }
-        } else if (any_x && kRayLanes == 4) {
-            // the four lanes of a ray are one DPP quad: lane t's sample reaches the other three as a quad_perm:[t,t,t,t] operand —
-            // no LDS round trip and no wave barrier on the serial part (every lane of the wave is active here: the loop and this
-            // branch are wave-uniform)
+        } else if (any_x && kRayLanes == 4 && (TBRM_RAY_EXP & 64)) {
+            // (A/B variant, measured and lost like the next one: the DPP replay without exec-mask regions — selects instead)
+            sweep4([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const float cx = quad_bcast<t>(x.x), cy = quad_bcast<t>(x.y), cz = quad_bcast<t>(x.z), cw = quad_bcast<t>(x.w);
+                const bool use = !done && !(cw < 0.0f);
+                const float om = 1.0f - le3;
+                const float n0 = le0 + (cx * om), n1 = le1 + (cy * om), n2 = le2 + (cz * om), n3 = le3 + (cw * om);
+                const bool ex = use && n3 > 0.95f && base + t < max_steps;
+                le0 = use ? n0 : le0;
+                le1 = use ? n1 : le1;
+                le2 = use ? n2 : le2;
+                le3 = ex ? 1.0f : (use ? n3 : le3);
+                done = done || ex;
+            });
+        } else if (any_x && kRayLanes == 4 && (TBRM_RAY_EXP & 32)) {
+            // (A/B variant, round 4: the four lanes of a ray are one DPP quad, lane t's sample reaches the other three as
+            // quad_perm:[t,t,t,t] moves — no LDS round trip and no wave barrier on the serial part. Measured at config 3: 0.556 -
+            // 0.559 ms per frame against 0.539 - 0.551 for the LDS exchange below: sixteen v_mov_dpp issue slots per trip cost more
+            // than one ds_write_b128 + four ds_read_b128, whose latency the other five waves of the SIMD hide.)
             sweep4([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 const float4 c = make_float4(quad_bcast<t>(x.x), quad_bcast<t>(x.y), quad_bcast<t>(x.z), quad_bcast<t>(x.w));
@@ -416,6 +466,15 @@ static hipError_t launch_ray3(const RayParams& p, hipStream_t s)
     if (p.slab_on) {
         if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP, RL, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP, RL, true>), grid, block, 0, s, p);
+        return hipGetLastError();
+    }
+    // the offset tables (k_raymarch_lit TAB): a step of at most one texel along every axis — then no sample's base tap lies below
+    // -2 or above n — and tables of at most 16 KiB (six workgroups per CU keep their place)
+    const size_t tab_bytes = (size_t) ((p.data.nx + p.data.ny + p.data.nz + 12 + 1) & ~1) * sizeof(uint2);
+    const bool tab = p.tab != nullptr && tune(TUNE_RAY_TABLES) != 0 && (float) std::max(p.data.nx, std::max(p.data.ny, p.data.nz)) <= p.steps && tab_bytes <= 16 * 1024;
+    if (tab) {
+        if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP, RL, false, true>), grid, block, tab_bytes, s, p);
+        else hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_WRAP, RL, false, true>), grid, block, tab_bytes, s, p);
         return hipGetLastError();
     }
     if (p.data_addr_mode == ADDR_CLAMP) hipLaunchKernelGGL((k_raymarch_lit<DFMT, LFMT, ADDR_CLAMP, RL>), grid, block, 0, s, p);

@@ -1328,6 +1328,76 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
     return TBRM_OK;
 }
 
+// Two Add passes of DIFFERENT lights that leave the same cube face as ONE sweep (PASS_ADD2; SURVEY.md 8f N4, the multi-light
+// optimisation the reference lists as not done, Readme.md:186-187): both streams share the slice loop, its latency chain, the
+// hand-off words and the light volume's read-modify-write (light a's, then light b's on its result: exactly pass a followed by
+// pass b). Each stream keeps its own factors (the lights' own occlusion launches, the cache entries); `fit` is the two
+// streams' common tile order and reach (sweep_fit, not two_way).
+static int enqueue_sweep_pair(tbrm_resources* r, const PassPlan& pa, const PassPlan& pb, const SweepFit& fit)
+{
+    const PassPlan* const plans[2] = {&pa, &pb};
+    for (const PassPlan* plan : plans) {
+        if (int e = enqueue_sweep_occlusion(r, *plan)) return e;
+        if (plan->occ_mode >= 0) HIP_TRY(hipStreamWaitEvent(r->stream, r->f_scratch[plan->f_buf].ev_ready, 0));
+        if (plan->f_hit[0]) HIP_TRY(hipStreamWaitEvent(r->stream, plan->f_entry[0]->ev_filled, 0));
+    }
+    ChunkParams p = pa.p;
+    p.r = pb.p.a;
+    p.b_added2 = pb.p.b_added;
+    p.j0 = pa.start;
+    p.n_steps = pa.D;
+    p.first_chunk = 1;
+    p.occ_phase = 0;
+    p.a.plane_in = plan_plane(r, 0, 0); p.a.plane_out = plan_plane(r, 1, 0);
+    p.r.plane_in = plan_plane(r, 0, 1); p.r.plane_out = plan_plane(r, 1, 1);
+    p.ones = r->d_ones;
+    ChunkStream* const streams[2] = {&p.a, &p.r};
+    for (int si = 0; si < 2; ++si) { // each stream from its own pass's factors (enqueue_sweep, stream a)
+        const PassPlan& plan = *plans[si];
+        FactorScratch& f = r->f_scratch[plan.f_buf];
+        FactorEntry* const e = plan.f_entry[0];
+        ChunkStream& st = *streams[si];
+        if (plan.f_hit[0]) { st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->slot; }
+        else {
+            st.fs_keep = e ? e->base : nullptr;
+            st.fs_cap = e ? (uint32_t) e->cap_blocks : 0u;
+            st.fs_spill = f.store[0];
+            st.fs_slot = e ? e->slot : f.slot;
+        }
+    }
+    SweepParams q = pa.sq;
+    q.sx = fit.sx; q.sy = fit.sy; q.hx = fit.hx; q.hy = fit.hy;
+    q.r_from_records = 0;
+    const size_t words = (size_t) pa.D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (fit.hx + fit.hy));
+    if (words >= ((size_t) 1 << 32)) return fail(TBRM_ERR_UNSUPPORTED, "hand-off records too large");
+    if (int e = ensure_sweep(r, std::max<size_t>(words, 1), 0)) return e;
+    q.rec[0] = r->sweep_rec[0];
+    q.rec[1] = r->sweep_rec[1];
+    q.ticket = r->sweep_ticket;
+    q.error = r->sweep_error;
+    q.stamps = nullptr;
+    q.debug &= ~2;
+    if (int e = next_sweep_epoch(r, q.epoch)) return e;
+    HIP_TRY(launch_light_sweep(p, q, PASS_ADD2, r->stream));
+    ++r->launches[0];
+    ++r->sweep_launches;
+    ++r->pair_sweeps;
+    for (const PassPlan* plan : plans) {
+        FactorScratch& f = r->f_scratch[plan->f_buf];
+        if (r->op_many_passes) HIP_TRY(hipEventRecord(f.ev_idle, r->stream));
+        f.used = true;
+        f.last_read_op = r->op_serial;
+        f.idle_recorded = r->op_many_passes;
+        if (FactorEntry* const e = plan->f_entry[0]) {
+            if (r->op_many_passes) HIP_TRY(hipEventRecord(e->ev_idle, r->stream));
+            e->read_yet = true;
+            e->last_read_op = r->op_serial;
+            e->idle_recorded = r->op_many_passes;
+        }
+    }
+    return TBRM_OK;
+}
+
 static bool plan_has_occlusion(const PassPlan& plan) { return !plan.sliced && !plan.sweep && plan.n_chunks > 0; }
 
 static int enqueue_plan_chunk_impl(tbrm_resources* r, const PassPlan& plan, int c, const PassPlan* next);
@@ -1505,7 +1575,9 @@ struct HostProbe {
     ~HostProbe() { if (on) fprintf(stderr, "[tbrm host] %s:%s\n", what, line.c_str()); }
 };
 
-int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs)
+// partner (optional, one entry per spec): the spec that is swept TOGETHER with this one (enqueue_sweep_pair), -1: none. The
+// partner's own turn is skipped.
+int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs, std::vector<int> partner = {})
 {
     if (int e = sweep_failed(r)) return e; // (an earlier sweep left the light volume undefined: nothing to build on)
     ++r->op_serial;
@@ -1539,8 +1611,37 @@ int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> 
         probe.lap("plan");
     }
     r->op_many_passes = specs.size() > 2;
+    std::vector<char> is_second(specs.size(), 0);
+    if (partner.size() != specs.size()) partner.assign(specs.size(), -1); // (also after an ADD2 spec was split: chain batches carry none)
+    for (size_t i = 0; i < specs.size(); ++i) {
+        const int j = partner[i];
+        // a pair needs both passes on the sweep; anything else: each on its own
+        if (j < 0 || (size_t) j >= specs.size() || !chunked[i] || !chunked[(size_t) j] || !plans[i].sweep || !plans[(size_t) j].sweep) partner[i] = -1;
+        else is_second[(size_t) j] = 1;
+    }
+    bool any_pair = false;
+    for (int j : partner) any_pair = any_pair || j >= 0;
+    if (any_pair) // (a group of two lights: four passes, four scratch buffers — every occlusion can go first)
+        for (size_t k = 0; k < specs.size(); ++k) {
+            if (!chunked[k]) continue;
+            const int e = (k + 1 < specs.size() && chunked[k + 1] && dual_fit(plans[k], plans[k + 1])) ? enqueue_dual_occlusion(r, plans[k], plans[k + 1])
+                                                                                                       : enqueue_sweep_occlusion(r, plans[k]);
+            if (e) { quiesce_occ_stream(r); return e; }
+        }
     for (size_t i = 0; i < specs.size(); ++i) {
         const PassSpec& q = specs[i];
+        if (is_second[i]) continue; // (swept together with its partner)
+        if (partner[i] >= 0) {
+            const size_t j = (size_t) partner[i];
+            SweepFit fit;
+            if (sweep_fit(r, specs[i].a, &specs[j].a, PASS_CHANGE, fit) && !fit.two_way) {
+                if (int e = enqueue_sweep_pair(r, plans[i], plans[j], fit)) { quiesce_occ_stream(r); return e; }
+                r->passes[0] += 2;
+                probe.lap("pair");
+                continue;
+            }
+            is_second[j] = 0; // (does not fit after all: both on their own, in the order given)
+        }
         if (!chunked[i]) {
             PropParams p = base;
             p.b_added = q.b_added;
@@ -1619,6 +1720,79 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         if (int e = ensure_skipping(r)) return e;
     const float b = added ? 1.0f : -1.0f;
     const bool pairing = tune(TUNE_LIGHT_BATCHING) != 0;
+    // ---- every pass on the pipelined sweep (UNORM8 light volumes: the production path) --------------------------------------
+    // Lights are taken two at a time: a group's passes (four at most) each get their own occlusion — one launch per light
+    // (DualOcc) — into the four scratch buffers / their cache entries, and passes of the two lights that leave the same cube face
+    // and pull the same way are swept TOGETHER (enqueue_sweep_pair). A light's partner is the later light it shares most faces
+    // with. Groups of two keep every factor store of a pair resident without more scratch than single operators use.
+    auto sweepable = [&](const tbrm_light_pass& q) {
+        SweepFit sf;
+        return sweep_fit(r, q, nullptr, PASS_ADD, sf) && ceil_div(q.td[2], 8) * 8 <= sweep_max_slices() && tune(TUNE_SPARSE_OCC) != 0 && tune(TUNE_OCC_LIST) != 0;
+    };
+    bool all_sweep = pairing && !all.empty();
+    for (const Entry& e : all) all_sweep = all_sweep && sweepable(e.p);
+    if (all_sweep) {
+        auto pair_fits = [&](const tbrm_light_pass& x, const tbrm_light_pass& y) {
+            SweepFit sf;
+            return x.face == y.face && sweep_fit(r, x, &y, PASS_CHANGE, sf) && !sf.two_way;
+        };
+        std::vector<std::vector<size_t>> of_light((size_t) n_lights);
+        for (size_t k = 0; k < all.size(); ++k) of_light[(size_t) all[k].light].push_back(k);
+        std::vector<char> light_done((size_t) n_lights, 0);
+        int entries = 0;
+        for (int la = 0; la < n_lights; ++la) {
+            if (light_done[(size_t) la] || of_light[(size_t) la].empty()) continue;
+            light_done[(size_t) la] = 1;
+            // the partner light: most pairs (each pass in at most one)
+            int best = -1, best_n = 0;
+            std::vector<std::pair<size_t, size_t>> best_pairs;
+            for (int lb = la + 1; lb < n_lights; ++lb) {
+                if (light_done[(size_t) lb] || of_light[(size_t) lb].empty()) continue;
+                std::vector<std::pair<size_t, size_t>> pairs;
+                std::vector<char> used_b(of_light[(size_t) lb].size(), 0);
+                for (size_t ka : of_light[(size_t) la])
+                    for (size_t ib = 0; ib < of_light[(size_t) lb].size(); ++ib) {
+                        const size_t kb = of_light[(size_t) lb][ib];
+                        if (!used_b[ib] && pair_fits(all[ka].p, all[kb].p)) { used_b[ib] = 1; pairs.emplace_back(ka, kb); break; }
+                    }
+                if ((int) pairs.size() > best_n) { best_n = (int) pairs.size(); best = lb; best_pairs = pairs; }
+            }
+            std::vector<size_t> group = of_light[(size_t) la];
+            if (best >= 0) {
+                light_done[(size_t) best] = 1;
+                group.insert(group.end(), of_light[(size_t) best].begin(), of_light[(size_t) best].end());
+            }
+            std::vector<PassSpec> specs;
+            std::vector<int> partner(group.size(), -1);
+            for (size_t g = 0; g < group.size(); ++g) {
+                PassSpec q;
+                q.a = all[group[g]].p;
+                q.b_added = b;
+                specs.push_back(q);
+                for (const auto& pr : best_pairs)
+                    if (pr.first == group[g])
+                        for (size_t h = 0; h < group.size(); ++h)
+                            if (group[h] == pr.second) partner[g] = (int) h;
+            }
+            std::vector<char> second(group.size(), 0);
+            for (int j : partner)
+                if (j >= 0) second[(size_t) j] = 1;
+            for (size_t g = 0; g < group.size(); ++g) { // the order the sweeps run in (run_passes)
+                if (second[g]) continue;
+                if (schedule) {
+                    const Entry& ea = all[group[g]];
+                    schedule[4 * entries + 0] = ea.light; schedule[4 * entries + 1] = ea.pass;
+                    schedule[4 * entries + 2] = partner[g] >= 0 ? all[group[(size_t) partner[g]]].light : -1;
+                    schedule[4 * entries + 3] = partner[g] >= 0 ? all[group[(size_t) partner[g]]].pass : -1;
+                }
+                ++entries;
+            }
+            if (n_entries) *n_entries = entries;
+            if (int e = run_passes(r, base, specs, partner)) return e;
+        }
+        if (n_entries) *n_entries = entries;
+        return TBRM_OK;
+    }
     std::vector<PassSpec> specs;
     int entries = 0;
     for (size_t ia = 0; ia < all.size(); ++ia) {

@@ -65,18 +65,19 @@ constexpr int kSweepRing = 8;                          // register ring of reque
 constexpr int kSweepComputeWaves = 8;
 // + the hand-off wave + one factor loader per stream (an LDS-DMA costs its wave 60 - 180 cycles of issue: the eight of a
 // two-stream slice in one wave took longer than the slice)
-constexpr int sweep_threads(int mode) { return (kSweepComputeWaves + 1 + (mode == PASS_CHANGE ? 2 : 1)) * 64; }
+constexpr bool sweep_two_streams(int mode) { return mode == PASS_CHANGE || mode == PASS_ADD2; }
+constexpr int sweep_threads(int mode) { return (kSweepComputeWaves + 1 + (sweep_two_streams(mode) ? 2 : 1)) * 64; }
 constexpr int kSweepFlagGroups = 128;                  // slice groups of a span (1024 slices)
 constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x 16 block slice of occlusion factors: the four
                                                        // blocks under a tile start 16 banks apart (a lane pair's columns c, c + 16)
 
 // slots of the LDS ring of factor slices; the loader runs one less ahead. One-stream slices are short: 8; a two-stream pass
 // leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
-constexpr int sweep_factor_slots(int mode) { return mode == PASS_CHANGE ? 4 : 8; }
+constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? 4 : 8; }
 
 size_t sweep_lds_bytes(int mode, int slices)
 {
-    const int ns = mode == PASS_CHANGE ? 2 : 1;
+    const int ns = sweep_two_streams(mode) ? 2 : 1;
     const int groups = (slices + 7) / 8; // (the rank table is as long as the pass: every KiB not taken is the occlusion workgroups')
     // planes, three brick layers, block ranks, the ring of factor slices
     return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * groups * 4 +
@@ -139,7 +140,8 @@ __device__ __forceinline__ v2f quantize2(v2f x)                                 
     return c;
 }
 
-// MODE: PASS_ADD (stream a) or PASS_CHANGE (a added, r removed). PF: slices ahead of their use that the neighbours'
+// MODE: PASS_ADD (stream a), PASS_CHANGE (a added, r removed) or PASS_ADD2 (two lights that leave the same cube face added in one
+// sweep: per voxel light a's read-modify-write, then light r's on its result — exactly pass a followed by pass r). PF: slices ahead of their use that the neighbours'
 // hand-off words are requested (a tile settles PF + 1 slices and one memory round trip behind its upstream neighbours).
 // HC: 64-word chunks of hand-off words per slice. RREC (PASS_CHANGE): stream r's halo comes from the records of an earlier
 // PASS_PLANES launch (SweepParams::r_from_records). MODE PASS_PLANES: one stream, the light volume untouched.
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     __shared__ int s_ticket;
     constexpr int T = kSweepTile, CS = kSweepCS, PLANE = kSweepPlane, LVB = kSweepLvBrick;
     constexpr int R = 2, NWC = kSweepComputeWaves, NTC = NWC * 64, NT = sweep_threads(MODE);
-    constexpr int NS = MODE == PASS_CHANGE ? 2 : 1;
+    constexpr int NS = sweep_two_streams(MODE) ? 2 : 1;
     constexpr bool LV = MODE != PASS_PLANES; // the light volume is updated
     static_assert(!RREC || MODE == PASS_CHANGE, "only a fused Change takes a stream from records");
     constexpr int RING = kSweepRing;
@@ -537,6 +539,18 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             lv_old.x = (float) code_old[0]; lv_old.y = (float) code_old[1];
             lv_old = decode2(lv_old);
             v2f nv, d;
+            if constexpr (MODE == PASS_ADD2) {
+                // light a's update (AddDirLightShader.usf:123-126), the result through the volume's format, then light r's on it
+                const v2f qa = quantize2(fma2(lv_l[0], (v2f) p.b_added, lv_old));
+                v2f mid;
+                mid.x = fabsf(lv_l[0].x) > thresh ? qa.x : (float) code_old[0];
+                mid.y = fabsf(lv_l[0].y) > thresh ? qa.y : (float) code_old[1];
+                const v2f qb = quantize2(fma2(lv_l[1], (v2f) p.b_added2, decode2(mid)));
+                const bool w0 = fabsf(lv_l[1].x) > thresh, w1 = fabsf(lv_l[1].y) > thresh;
+                if (in_pl[0]) lv_prev[lv_at[0]] = (uint8_t) (uint32_t) (w0 ? qb.x : mid.x);
+                if (in_pl[1]) lv_prev[lv_at[1]] = (uint8_t) (uint32_t) (w1 ? qb.y : mid.y);
+                return;
+            }
             if constexpr (MODE != PASS_CHANGE) { nv = fma2(lv_l[0], (v2f) p.b_added, lv_old); d = lv_l[0]; } // (l * +-1 is exact: the fused form rounds once, like lv + l * b)
             else { d = lv_l[0] - lv_l[NS - 1]; nv = (lv_old + lv_l[0]) - lv_l[NS - 1]; }
             const v2f qn = quantize2(nv);
@@ -712,11 +726,12 @@ hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mo
 {
     if (p.n_steps <= 0 || p.tiles_x <= 0 || p.tiles_y <= 0) return hipSuccess;
     const bool aligned = (p.n_steps & 7) == 0 && (p.j0 & 7) == (p.dir > 0 ? 0 : 7) && p.occ_phase == 0 && p.n_steps <= 8 * kSweepFlagGroups;
-    if (!aligned || !p.compact || !p.ones || !p.a.fs_slot || (mode == PASS_CHANGE && !p.r.fs_slot)) return hipErrorInvalidConfiguration;
+    if (!aligned || !p.compact || !p.ones || !p.a.fs_slot || (sweep_two_streams(mode) && !p.r.fs_slot)) return hipErrorInvalidConfiguration;
     if (q.r_from_records && (mode != PASS_CHANGE || !q.rec[1])) return hipErrorInvalidConfiguration;
     if (q.reinit_slice < 0 || q.reinit_slice > 7 || (q.reinit_slice > 0 && p.n_steps < 16)) return hipErrorInvalidConfiguration;
     if (mode == PASS_ADD) return launch_sweep2<PASS_ADD>(p, q, s);
     if (mode == PASS_CHANGE) return launch_sweep2<PASS_CHANGE>(p, q, s);
+    if (mode == PASS_ADD2) return launch_sweep2<PASS_ADD2>(p, q, s);
     if (mode == PASS_PLANES) return launch_sweep2<PASS_PLANES>(p, q, s);
     return hipErrorInvalidConfiguration;
 }

@@ -202,6 +202,7 @@ struct tbrm_resources {
     int oct_dims[4][3]{};
     bool octree_valid = false;
 
+    uint2* d_ray_tab = nullptr;    // k_raymarch_lit's texel -> offset tables (RayParams::tab), built once per handle
     unsigned long long* d_counter = nullptr;
     float* d_out = nullptr; // staging for the host-pointer raymarch variant
     size_t out_bytes = 0;
@@ -214,6 +215,7 @@ struct tbrm_resources {
     uint64_t sweep_launches = 0; // (of the chunk launches: the pipelined sweep kernel's)
     uint64_t passes[3]{};        // axis passes run as a sweep / as the chunked chain / one slice per launch (tbrm_path_counters)
     uint64_t occ_launches = 0;   // occlusion launches that served one pass (dual_launches: both passes of a light)
+    uint64_t pair_sweeps = 0;    // sweep launches that propagated two lights' passes at once (PASS_ADD2)
 };
 
 

@@ -19,6 +19,14 @@ commutes); in fp32 it can differ from the sequential order at near-ties only, so
 reset is the oracle run with the SAME light->rank schedule and combine rule (tests/test_sharding.py), and the
 sequential single-GPU result is the reference it is compared to code by code. Float light volumes combine with a plain
 sum (tolerance 1e-4). The callbacks make the same code run over gloo on CPU tensors and over RCCL on device tensors.
+
+3. The selective update of ONE light on ONE GPU + a broadcast of the light volume (SURVEY.md §8e "Selective updates (Change) touch
+one light -> run on one GPU + broadcast delta, or redundantly on all"). A ChangeDirLight is two serial sweeps: it does not shard
+at 512^3, so at N > 1 every GPU either repeats it (no exchange: bench.py's default) or waits for the owner's
+copy of the result (one broadcast of the light volume: 128 MiB at 512^3). On the critical path of a step the second form is
+Change + broadcast + frame / N against Change + frame / N: it cannot be faster, it only leaves N - 1 GPUs free for other work
+(and their factor caches cold). change_dir_light_on_owner implements it behind a callback so that it runs over gloo in the
+tests and over RCCL in bench.py --light-update broadcast.
 """
 import numpy as np
 
@@ -126,3 +134,18 @@ def reset_all_lights_light_parallel(res, lights, world, rank, world_size, combin
     out = combine_u8(t) if t.dtype == torch.uint8 else combine_f32(t)
     t.copy_(out)
     torch.cuda.synchronize(t.device)
+
+
+# ---- selective update on one GPU + broadcast ---------------------------------------------------------------------------
+
+def change_dir_light_on_owner(change, light_tensor, rank, owner, broadcast):
+    """ChangeDirLight on rank `owner` only; every rank ends up with the owner's light volume.
+
+    change(): runs the operator on this rank's volume (called on the owner only). light_tensor(): this rank's light volume as a
+    tensor the collective can send / receive in place (sharding.device_light_tensor on GPUs). broadcast(t, src): the process
+    group's broadcast, issued where it is ordered behind the operator (the library's stream on GPUs)."""
+    if rank == owner:
+        change()
+    t = light_tensor()
+    broadcast(t, owner)
+    return t

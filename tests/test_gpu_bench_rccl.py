@@ -40,3 +40,12 @@ def test_slab_partitioned_light_update_over_rccl_equals_the_unpartitioned_operat
     r = run_bench(["--config", "3", "--slab-illumination"])
     assert r["slab_light_volume_equals_unpartitioned"] is True, r
     assert r["gathered_frame_equals_single_gpu_render"] is True, r
+
+
+def test_light_update_on_one_rank_and_broadcast_over_rccl(gpu):
+    """--light-update broadcast: the ChangeDirLight on rank 0 and ncclBroadcast of the light volume on the library's stream (one rank
+    here: the broadcast is RCCL's own no-op path, the stream ordering and the line's fields are what is exercised)."""
+    r = run_bench(["--config", "5", "--light-update", "broadcast"])
+    assert r["gathered_frame_equals_single_gpu_render"] is True, r
+    d = r["distributed"]
+    assert d["backend"] == "nccl" and d["world_size_seen"] == 1 and d["light_update"] == "broadcast" and len(d["ms_per_step_per_rank"]) == 1, d

@@ -472,11 +472,14 @@ def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, 
         sched = res.add_dir_lights(lights, True, world)
         n_passes = sum(2 if b >= 0 else 1 for _, _, b, _ in sched)
         assert n_passes == sum(abi.host_light_passes(l, world, res.light_dims)[1] for l in lights)
-        sweeps = kernel_variant == "sweep" and not light_32bit  # (these dimensions are whole brick layers)
-        if kernel_variant != "slice" and not sweeps:
+        sweeps = kernel_variant == "sweep" and not light_32bit
+        if kernel_variant != "slice":
             assert sum(b >= 0 for _, _, b, _ in sched) >= 2, f"fewer than two pairs: {sched}"
-        else:  # the slice-per-launch kernel has no two-light form, and a pass that sweeps is not worth pairing
+        else:  # the slice-per-launch kernel has no two-light form
             assert all(b < 0 for _, _, b, _ in sched)
+        if sweeps:  # round 4: pairs on the production path are ONE sweep launch each (PASS_ADD2 of k_light_sweep)
+            p = res.path_counters()
+            assert p["pair_sweeps"] == sum(b >= 0 for _, _, b, _ in sched) and p["passes_chain"] == 0 and p["passes_slice"] == 0, (p, sched)
         for la, pa, lb, pb in sched:
             assert orc.add_dir_light_pass(lights[la], True, world, pa) == 1
             if lb >= 0:

@@ -158,3 +158,53 @@ def test_two_rank_gloo_light_parallel_reset(tmp_path, oracle_mod):
     assert diff.max() <= 1
     assert (diff != 0).mean() < 1e-3
     assert int(seq.light.max()) > 100  # the scene is lit at all
+
+
+# ---- selective update on one rank + broadcast of the light volume ------------------------------------
+
+def _broadcast_worker(rank, world_size, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from oracle import oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world = S.default_world()
+    orc = _light_scene(oracle)
+    lights = [S.light(i) for i in range(3)]
+    for l in lights:
+        orc.add_dir_light(l, True, world)  # every rank holds the same volume to start with (replicated)
+    reference = _light_scene(oracle)
+    for l in lights:
+        reference.add_dir_light(l, True, world)
+    owner = 0
+    for k in range(4):  # four steps: one light turned per step, on the owner only; everybody receives the result
+        li = k % len(lights)
+        new = abi.DirLightParams(S.rotate_z(S.LIGHTS[li][0], 5.0 * (k + 1)), S.LIGHTS[li][1])
+        old = lights[li]
+        t = torch.from_numpy(orc.light.reshape(-1))
+        sharding.change_dir_light_on_owner(lambda: orc.change_dir_light(old, new, world), lambda: t, rank, owner,
+                                           lambda tensor, src: dist.broadcast(tensor, src))
+        reference.change_dir_light(old, new, world)
+        lights[li] = new
+        ok = np.array_equal(orc.light, reference.light)
+        if not ok:
+            break
+    open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_light_update_on_one_rank_and_broadcast(tmp_path, oracle_mod):
+    """bench.py --light-update broadcast: rank 0 runs every ChangeDirLight, the light volume is broadcast; after every step
+    both ranks hold what a single process computes."""
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_broadcast_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok"
