@@ -189,6 +189,7 @@ struct SweepParams {
     int debug;              // diagnostics (sweep_debug tunable): bit 0 = tiles do not wait for each other (WRONG results: slice time alone);
                             // bit 1 = every tile leaves four time stamps (10 ns units) in `stamps`
     unsigned long long* stamps; // [tile][4]: start of slice 0, end of slice 63, end of the last slice, after the write-back
+    int lv_f32;             // the light volume (and the planes) are floats: k_light_sweep<..., FMT_F32>, records pre-filled with 0xffffffff
     int reinit_slice;       // > 0: the launch's first reinit_slice slices lie in front of the volume (a pass that runs downwards from a
                             // depth that is no multiple of 8, padded to whole brick layers): slice reinit_slice - 1 hands on the pass's
                             // initial plane instead of what it computed
@@ -332,7 +333,7 @@ hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s,
 hipError_t launch_unit_flags(const ChunkParams& pc, const DualOcc& d, hipStream_t s); // + the units' work list (pc: the virtual pass along the third axis)
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s);
-size_t sweep_lds_bytes(int mode, int slices);
+size_t sweep_lds_bytes(int mode, int slices, int lv_fmt = FMT_U8);
 int sweep_halo_chunks(int hx, int hy);
 int sweep_max_slices();
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);

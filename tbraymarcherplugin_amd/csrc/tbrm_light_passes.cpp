@@ -81,7 +81,8 @@ static TapSide prev_tap_side(int size, float off)
 // fits the hand-off wave and both fit the planes side by side.
 bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit)
 {
-    if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->lv_fmt != FMT_U8 || r->resident || r->sweep_failed_bits) return false;
+    if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->resident || r->sweep_failed_bits) return false;
+    const bool f32 = r->lv_fmt != FMT_U8; // (float light volumes: k_light_sweep<..., FMT_F32> — one-way passes of up to three words per lane)
     if (mode != PASS_ADD && mode != PASS_CHANGE) return false;
     // (a depth that is no multiple of 8 is padded to whole brick layers: plan_pass_sweep; a downward pass then needs a second
     // layer behind the ragged one)
@@ -102,8 +103,8 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         fit.hx = std::max(fit.hx, tx.reach);
         fit.hy = std::max(fit.hy, ty.reach);
     }
-    if (!opposite) return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= 6;
-    if (tune(TUNE_LIGHT_SWEEP) == 2) return false; // (diagnostics: such passes take the chain, as before round 3's last week)
+    if (!opposite) return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= (f32 ? 3 : 6);
+    if (tune(TUNE_LIGHT_SWEEP) == 2 || f32) return false; // (diagnostics: such passes take the chain, as before round 3's last week)
     fit.two_way = true;
     fit.sx = side[0][0].side; fit.hx = side[0][0].reach; fit.sy = side[0][1].side; fit.hy = side[0][1].reach;
     fit.r_sx = side[1][0].side; fit.r_hx = side[1][0].reach; fit.r_sy = side[1][1].side; fit.r_hy = side[1][1].reach;
@@ -842,7 +843,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.sx = sfit.sx; q.sy = sfit.sy; q.hx = sfit.hx; q.hy = sfit.hy;
     q.r_from_records = sfit.two_way ? 1 : 0;
     q.r_sx = sfit.r_sx; q.r_sy = sfit.r_sy; q.r_hx = sfit.r_hx; q.r_hy = sfit.r_hy;
-    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy));
+    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy)) * (size_t) (r->lv_fmt != FMT_U8 && change ? 2 : 1);
     const size_t words1 = sfit.two_way ? (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.r_hx + sfit.r_hy)) : 0;
     if (words >= ((size_t) 1 << 32) || words1 >= ((size_t) 1 << 32)) return declined("hand-off records too large");
     if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words1)) return e;
@@ -853,6 +854,8 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : 1500;
     q.debug = tune(TUNE_SWEEP_DEBUG);
     q.reinit_slice = pa.dir < 0 ? pad : 0;
+    q.lv_f32 = r->lv_fmt != FMT_U8 ? 1 : 0;
+    plan.rec_words = words;
     {
         const int ms = tune(TUNE_SWEEP_TIMEOUT_MS);
         q.give_up_ticks = ms < 0 ? 0ull : (unsigned long long) (ms == 0 ? 2000 : ms) * 100000ull;
@@ -1293,6 +1296,8 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
         q.r_epoch = q1.epoch;
     }
     if (int e = next_sweep_epoch(r, q.epoch)) return e;
+    if (q.lv_f32) // float hand-off words carry no tag: "not published yet" is written over the launch's records first
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->sweep_rec[0], 0xffffffffu, plan.rec_words, r->stream));
     q.stamps = nullptr;
     if (q.debug & 2) { // diagnostics: per-tile time stamps of this launch (printed by tbrm_flush)
         const int tiles = p.tiles_x * p.tiles_y;
@@ -1729,7 +1734,7 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         SweepFit sf;
         return sweep_fit(r, q, nullptr, PASS_ADD, sf) && ceil_div(q.td[2], 8) * 8 <= sweep_max_slices() && tune(TUNE_SPARSE_OCC) != 0 && tune(TUNE_OCC_LIST) != 0;
     };
-    bool all_sweep = pairing && !all.empty();
+    bool all_sweep = pairing && !all.empty() && r->lv_fmt == FMT_U8; // (the two-light sweep is built for UNORM8 light volumes)
     for (const Entry& e : all) all_sweep = all_sweep && sweepable(e.p);
     if (all_sweep) {
         auto pair_fits = [&](const tbrm_light_pass& x, const tbrm_light_pass& y) {

@@ -75,12 +75,12 @@ constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x
 // leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
 constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? 4 : 8; }
 
-size_t sweep_lds_bytes(int mode, int slices)
+size_t sweep_lds_bytes(int mode, int slices, int lv_fmt)
 {
     const int ns = sweep_two_streams(mode) ? 2 : 1;
     const int groups = (slices + 7) / 8; // (the rank table is as long as the pass: every KiB not taken is the occlusion workgroups')
-    // planes, three brick layers, block ranks, the ring of factor slices
-    return (size_t) 2 * ns * kSweepPlane * 4 + 3 * 16 * kSweepLvBrick + (size_t) ns * 4 * groups * 4 +
+    // planes, three brick layers (UNORM8 light volumes: a float light volume is updated in place), block ranks, the ring of factor slices
+    return (size_t) 2 * ns * kSweepPlane * 4 + (lv_fmt == FMT_U8 ? 3 * 16 * kSweepLvBrick : 0) + (size_t) ns * 4 * groups * 4 +
            (size_t) sweep_factor_slots(mode) * ns * 4 * kSweepFBlock * 4;
 }
 
@@ -98,13 +98,14 @@ __device__ __forceinline__ void sweep_store_word(uint32_t* p, uint32_t w) { __hi
 // The slow path of a hand-off: the neighbour has not published the word yet. Its load is inline assembly so that the
 // compiler's wait-count bookkeeping of the caller never sees a loop with a memory operation in it (it would answer with
 // s_waitcnt vmcnt(0) at every later use of a request that is still in flight).
-__device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch, int* error, unsigned long long give_up_ticks)
+constexpr uint32_t kSweepNoWord = 0xffffffffu; // float light volumes: what a record word holds until it is published (a NaN no plane holds)
+__device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch, int* error, unsigned long long give_up_ticks, bool f32 = false)
 {
     uint32_t w = 0;
     const unsigned long long t0 = wall_clock64(); // (100 MHz, constant: a starved or shared device gets wall time, not a poll count)
     for (;;) {
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
-        if ((w >> 16) == epoch) return w;
+        if (f32 ? w != kSweepNoWord : (w >> 16) == epoch) return w;
         if (wall_clock64() - t0 >= give_up_ticks) break;
         __builtin_amdgcn_s_sleep(2);
     }
@@ -145,7 +146,13 @@ __device__ __forceinline__ v2f quantize2(v2f x)                                 
 // hand-off words are requested (a tile settles PF + 1 slices and one memory round trip behind its upstream neighbours).
 // HC: 64-word chunks of hand-off words per slice. RREC (PASS_CHANGE): stream r's halo comes from the records of an earlier
 // PASS_PLANES launch (SweepParams::r_from_records). MODE PASS_PLANES: one stream, the light volume untouched.
-template <int MODE, int AXIS, int PF, int HC, bool RREC = false>
+// LFMT: the light volume's (and the read / write buffers') format. FMT_U8: planes are UNORM8 codes re-quantised every slice, one
+// hand-off word carries a launch tag and both streams' codes, the tile's light-volume bricks are staged in LDS. FMT_F32
+// (bLightVolume32Bit, RaymarchVolume.cpp:857-866): planes are floats as they are, a hand-off word is the float itself (one per
+// stream; the records are filled with kSweepNoWord before the launch instead of being tagged), and the light volume is updated
+// in place — fire-and-forget fp32 atomic adds, the removed light's as a second add of -L: (LV + La) - Lr rounds twice, like the
+// reference's expression (ChangeDirLightShader.usf:152-154).
+template <int MODE, int AXIS, int PF, int HC, bool RREC = false, int LFMT = FMT_U8>
 __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const ChunkParams p, const SweepParams q)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -154,7 +161,11 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     constexpr int R = 2, NWC = kSweepComputeWaves, NTC = NWC * 64, NT = sweep_threads(MODE);
     constexpr int NS = sweep_two_streams(MODE) ? 2 : 1;
     constexpr bool LV = MODE != PASS_PLANES; // the light volume is updated
+    constexpr bool F32 = LFMT == FMT_F32;
+    constexpr bool LVS = LV && !F32;         // ... through brick layers staged in LDS
+    constexpr int NSW = F32 ? NS : 1;        // hand-off words per cell
     static_assert(!RREC || MODE == PASS_CHANGE, "only a fused Change takes a stream from records");
+    static_assert(!F32 || (!RREC && (MODE == PASS_ADD || MODE == PASS_CHANGE)), "float light volumes: Add and fused Change");
     constexpr int RING = kSweepRing;
     static_assert(PF >= 1 && PF < RING, "the request ring holds 8 slices");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     float* const lds = (float*) smem;
     auto plane = [&](int buf, int si) -> float* { return lds + (buf * NS + si) * PLANE; };
     uint8_t* const lvt = (uint8_t*) (lds + 2 * NS * PLANE);
-    int32_t* const sslot = (int32_t*) (lvt + 3 * 16 * LVB); // [si][2 x 2 blocks][slice group]: rank of the block, < 0: flagged empty
+    int32_t* const sslot = (int32_t*) (lvt + (F32 ? 0 : 3 * 16 * LVB)); // [si][2 x 2 blocks][slice group]: rank of the block, < 0: flagged empty
     // the ring of factor slices, [slot][si][2 x 2 blocks][kSweepFBlock]: filled FS - 1 slices ahead by the loader wave
     float* const fring = (float*) (sslot + NS * 4 * G);
     constexpr int FS = sweep_factor_slots(MODE); // (divides the loop's eight slices: a slice's slot is a constant)
@@ -237,14 +248,14 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         if (piece_exists) *(uint4*) ((uint8_t*) p.light + (piece_off + (uint32_t) layer_of(g) * layer_stride)) = *(const uint4*) ((const uint8_t*) piece_lds + (g % 3) * kLvBuf);
     };
     uint4 lv_next = make_uint4(0, 0, 0, 0);
-    if (LV && wave < NWC) {
+    if (LVS && wave < NWC) {
         *piece_lds = load_layer(0);
         lv_next = load_layer(1);
     }
 
     const uint32_t epoch = q.epoch & 0xffffu, tag = epoch << 16;
-    const int RW = T * (hx + hy);
-    const uint32_t rec_slice = (uint32_t) (n_tiles * RW); // words per slice
+    const int RW = T * (hx + hy), RWS = RW * NSW;
+    const uint32_t rec_slice = (uint32_t) (n_tiles * RWS); // words per slice
     __syncthreads(); // planes, flags and the first brick layer are in LDS
     // Staggered start (SweepParams::stagger_ns): the tile's lag behind its upstream neighbours, taken up front
     if (q.stagger_ns > 0 && !(q.debug & 1)) {
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             if (q.debug & 1) on = false;
             hal_on[h] = on;
             hal_dst[h] = (ox + cxh) * CS + oy + cyh;
-            hal_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * RW + word) : 0u;
+            hal_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * RWS + word) : 0u;
         }
         // RREC: stream r's halo cells, the same construction with stream r's geometry; their words were written by the launch
         // before this one (tag r_epoch), tile by tile in the same [slice][tile][word] layout
@@ -328,13 +339,15 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 rh_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * r_RW + word) : 0u;
             }
         }
-        uint32_t hreg[RING][HC], rreg[RING][RREC ? HC : 1];
+        uint32_t hreg[RING][HC][NSW], rreg[RING][RREC ? HC : 1];
         // (every lane loads: the ones without a halo word read word 0 of the slice — a branch around a load whose result is
         // consumed slices later would make the compiler drain every request in flight at the join)
         auto request_halo = [&](int s, auto slot_c) { // the neighbours' slice s
             constexpr int SLOT = decltype(slot_c)::value;
 #pragma unroll
-            for (int h = 0; h < HC; ++h) hreg[SLOT][h] = sweep_load_word((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]));
+            for (int h = 0; h < HC; ++h)
+#pragma unroll
+                for (int sw = 0; sw < NSW; ++sw) hreg[SLOT][h][sw] = sweep_load_word((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (sw * RW)));
             if constexpr (RREC) {
 #pragma unroll
                 for (int h = 0; h < HC; ++h) rreg[SLOT][h] = sweep_load_word((const uint32_t*) q.rec[1] + ((uint32_t) s * r_rec_slice + rh_src[h]));
@@ -357,25 +370,44 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 if constexpr (FIRST) reinit = K8 + 1 == q.reinit_slice;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
                 if ((TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
-                    uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RW));
+                    uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RWS));
 #pragma unroll
                     for (int h = 0; h < HC; ++h)
                         if (pub_cell[h] >= 0) {
-                            uint32_t w = tag;
+                            if constexpr (F32) {
 #pragma unroll
-                            for (int si = 0; si < NS; ++si) w |= ((uint32_t) (plane(CUR, si)[pub_cell[h]] * 255.0f + 0.5f) & 255u) << (8 * si); // (v = code / 255: back to the code)
-                            sweep_store_word(rec + (h * 64 + lane), w);
+                                for (int si = 0; si < NS; ++si) {
+                                    uint32_t w = __float_as_uint(plane(CUR, si)[pub_cell[h]]);
+                                    if (w == kSweepNoWord) w = 0x7fc00000u; // (that NaN of all NaNs means "not published yet")
+                                    sweep_store_word(rec + (si * RW + h * 64 + lane), w);
+                                }
+                            } else {
+                                uint32_t w = tag;
+#pragma unroll
+                                for (int si = 0; si < NS; ++si) w |= ((uint32_t) (plane(CUR, si)[pub_cell[h]] * 255.0f + 0.5f) & 255u) << (8 * si); // (v = code / 255: back to the code)
+                                sweep_store_word(rec + (h * 64 + lane), w);
+                            }
                         }
                 }
                 // the upstream neighbours' cells of THIS slice into the halo of the plane the compute waves are building
                 if constexpr (!(LAST && K8 == 7)) {
 #pragma unroll
                     for (int h = 0; h < HC; ++h) {
-                        uint32_t w = hreg[K8][h];
-                        if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error, q.give_up_ticks);
-                        if (hal_on[h]) {
+                        if constexpr (F32) {
 #pragma unroll
-                            for (int si = 0; si < (RREC ? 1 : NS); ++si) plane(CUR ^ 1, si)[hal_dst[h]] = reinit ? stream(si).init_value : decode_u8((w >> (8 * si)) & 255u);
+                            for (int si = 0; si < NS; ++si) {
+                                uint32_t w = hreg[K8][h][si];
+                                if (hal_on[h] && w == kSweepNoWord)
+                                    w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (si * RW)), epoch, q.error, q.give_up_ticks, true);
+                                if (hal_on[h]) plane(CUR ^ 1, si)[hal_dst[h]] = reinit ? stream(si).init_value : __uint_as_float(w);
+                            }
+                        } else {
+                            uint32_t w = hreg[K8][h][0];
+                            if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error, q.give_up_ticks);
+                            if (hal_on[h]) {
+#pragma unroll
+                                for (int si = 0; si < (RREC ? 1 : NS); ++si) plane(CUR ^ 1, si)[hal_dst[h]] = reinit ? stream(si).init_value : decode_u8((w >> (8 * si)) & 255u);
+                            }
                         }
                     }
                     if constexpr (RREC) { // the removed light's cells: published long ago (a word that is not there is an error)
@@ -480,6 +512,36 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             else lv_at[k] = lb + (uint32_t) (r & 7) * 8u + (uint32_t) (c & 7);
         }
         constexpr uint32_t kLvStep = AXIS == 0 ? 1u : (AXIS == 1 ? 8u : 64u);
+        uint32_t lv_voxel[R] = {0, 0}; // F32: the pixel's voxel in the bricked light volume, slice 0 of the volume (elements)
+        if constexpr (F32) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int py = base_y + r0 + k;
+                if (AXIS == 0) lv_voxel[k] = brick_off_y(px, p.lv_bnx) + brick_off_z(py, p.lv_bnxy);      // (u, v) = (y, z)
+                else if (AXIS == 1) lv_voxel[k] = brick_off_x(px) + brick_off_z(py, p.lv_bnxy);           // (x, z)
+                else lv_voxel[k] = brick_off_x(px) + brick_off_y(py, p.lv_bnx);                           // (x, y)
+            }
+        }
+        // F32: L of this slice straight into the light volume (:123-126 / ChangeDirLightShader.usf:152-154): returnless fp32 atomic
+        // adds — nothing waits for them, and a lane is its voxel's only writer; (LV + La) - Lr as two adds rounds like the expression
+        auto lv_update_f32 = [&](int s_idx, const v2f (&l)[NS]) {
+            const int j = p.j0 + s_idx * p.dir;
+            const uint32_t so = AXIS == 0 ? brick_off_x(j) : (AXIS == 1 ? brick_off_y(j, p.lv_bnx) : brick_off_z(j, p.lv_bnxy));
+            float* const lv = (float*) p.light;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const float la = k == 0 ? l[0].x : l[0].y;
+                if constexpr (MODE == PASS_CHANGE) {
+                    const float lr = k == 0 ? l[NS - 1].x : l[NS - 1].y;
+                    if (in_pl[k] && fabsf(la - lr) > 1e-3f) {
+                        unsafeAtomicAdd(lv + (lv_voxel[k] + so), la);
+                        unsafeAtomicAdd(lv + (lv_voxel[k] + so), -lr);
+                    }
+                } else {
+                    if (in_pl[k] && fabsf(la) > 1e-3f) unsafeAtomicAdd(lv + (lv_voxel[k] + so), la * p.b_added);
+                }
+            }
+        };
 #pragma unroll
         for (int si = 0; si < NS; ++si) {
             const ChunkStream& s = stream(si);
@@ -563,16 +625,16 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             uint8_t* const lv_layer = lvt + (g % 3) * kLvBuf;
             sweep_each_const([&](auto kc) {
                 constexpr int K8 = decltype(kc)::value, CUR = K8 & 1;
-                if constexpr (LV && K8 == 1) { // (the last voxels of the layer before were updated in slice 0 of this group)
+                if constexpr (LVS && K8 == 1) { // (the last voxels of the layer before were updated in slice 0 of this group)
                     if (g > 0) write_back_layer(g - 1);
                 }
-                if constexpr (LV && K8 == 3 && !LAST) { // the next layer: loaded eight slices ago, first used four barriers from now
+                if constexpr (LVS && K8 == 3 && !LAST) { // the next layer: loaded eight slices ago, first used four barriers from now
                     *(uint4*) ((uint8_t*) piece_lds + ((g + 1) % 3) * kLvBuf) = lv_next;
                     lv_next = load_layer(g + 2);
                 }
                 // LDS reads: the voxels of the slice before, this slice's taps
                 uint32_t code_old[R] = {0, 0};
-                if constexpr (LV) {
+                if constexpr (LVS) {
 #pragma unroll
                     for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
                 }
@@ -590,7 +652,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                         cb[si][k].x = pt[CS]; cb[si][k].y = pt[CS + 1];
                     }
                 }
-                if constexpr (LV && !(TBRM_SWEEP_EXP & 1))
+                if constexpr (LVS && !(TBRM_SWEEP_EXP & 1))
                     if (K8 > 0 || g > 0) light_volume_update(code_old);
                 // this slice, operation by operation over the streams: a slice is one dependent chain per stream, and the two
                 // chains of a Change are independent — side by side they fill each other's issue gaps
@@ -613,6 +675,15 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 }
 #pragma unroll
                 for (int si = 0; si < NS; ++si) lv_l[si] = xa[si] * fac[si];
+                if constexpr (F32) { // a float buffer returns what was written (:120); the light volume takes L at once
+                    if constexpr (LV && !(TBRM_SWEEP_EXP & 1)) {
+                        bool real = true; // (not the slices in front of a ragged downward pass: SweepParams::reinit_slice)
+                        if constexpr (FIRST) real = K8 >= q.reinit_slice;
+                        if (real) lv_update_f32(g * 8 + K8, lv_l);
+                    }
+#pragma unroll
+                    for (int si = 0; si < NS; ++si) pval[si] = lv_l[si];
+                } else {
                 // WriteBuffer[PixelLoc] = L (:120), as a read of it returns it: quantize_u8, decode_u8f
 #pragma unroll
                 for (int si = 0; si < NS; ++si) { qc[si].x = __builtin_amdgcn_fmed3f(lv_l[si].x, 0.0f, 1.0f); qc[si].y = __builtin_amdgcn_fmed3f(lv_l[si].y, 0.0f, 1.0f); }
@@ -624,6 +695,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 for (int si = 0; si < NS; ++si) { qc[si].x = __builtin_floorf(qc[si].x); qc[si].y = __builtin_floorf(qc[si].y); }
 #pragma unroll
                 for (int si = 0; si < NS; ++si) pval[si] = decode2(qc[si]);
+                }
                 if constexpr (FIRST) { // the slice before the pass's first real one (a pass that starts inside a brick layer) hands on the
                                        // initial plane, whatever the slices in front of the volume made of it (SweepParams::reinit_slice)
                     if (K8 + 1 == q.reinit_slice) {
@@ -657,7 +729,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         group(G - 1, std::false_type{}, std::true_type{});
         __builtin_amdgcn_s_setprio(0);
         if (stamping) q.stamps[4 * tile_lin + 2] = wall_clock64();
-        if constexpr (LV) { // the last slice's voxels, then the last layer
+        if constexpr (LVS) { // the last slice's voxels, then the last layer
             uint32_t code_old[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
@@ -666,7 +738,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     }
 
     __syncthreads(); // the last slice's voxels are in the layer buffers
-    if (LV && wave < NWC) write_back_layer(G - 1);
+    if (LVS && wave < NWC) write_back_layer(G - 1);
     if (stamping) q.stamps[4 * tile_lin + 3] = wall_clock64();
 
     // ---- the last tile to finish re-arms the tickets for the next launch -----------------------------------------------------
@@ -679,18 +751,26 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     }
 }
 
-template <int MODE, int AXIS, int PF, int HC, bool RREC = false>
+template <int MODE, int AXIS, int PF, int HC, bool RREC = false, int LFMT = FMT_U8>
 static hipError_t launch_sweep5(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC>, attr_done, 159 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE)), sweep_lds_bytes(MODE, p.n_steps), s, p, q);
+    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC, LFMT>, attr_done, 159 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC, LFMT>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE)), sweep_lds_bytes(MODE, p.n_steps, LFMT), s, p, q);
     return hipGetLastError();
 }
 template <int MODE, int AXIS, int PF>
 static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     const int hc = sweep_halo_chunks(q.hx, q.hy);
+    if (q.lv_f32) { // float light volumes: Add and fused Change, up to three words per lane and stream (sweep_fit)
+        if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE) {
+            if (q.r_from_records) return hipErrorInvalidConfiguration;
+            if (hc <= 2) return launch_sweep5<MODE, AXIS, PF, 2, false, FMT_F32>(p, q, s);
+            if (hc <= 3) return launch_sweep5<MODE, AXIS, PF, 3, false, FMT_F32>(p, q, s);
+        }
+        return hipErrorInvalidConfiguration;
+    }
 #if TBRM_SWEEP_EXP
     if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3>(p, q, s);
     return hipErrorInvalidConfiguration;

@@ -473,7 +473,9 @@ def test_batched_lights_match_oracle_replay(gpu, oracle_mod, light_32bit, dims, 
         n_passes = sum(2 if b >= 0 else 1 for _, _, b, _ in sched)
         assert n_passes == sum(abi.host_light_passes(l, world, res.light_dims)[1] for l in lights)
         sweeps = kernel_variant == "sweep" and not light_32bit
-        if kernel_variant != "slice":
+        if kernel_variant == "sweep" and light_32bit:
+            pass  # (float light volumes sweep pass by pass: the two-light sweep is built for UNORM8, and a pass that sweeps leaves the chain's pairing)
+        elif kernel_variant != "slice":
             assert sum(b >= 0 for _, _, b, _ in sched) >= 2, f"fewer than two pairs: {sched}"
         else:  # the slice-per-launch kernel has no two-light form
             assert all(b < 0 for _, _, b, _ in sched)
@@ -525,7 +527,7 @@ def test_reset_all_lights_from_kept_factors_is_bit_exact(gpu, oracle_mod, light_
     """ResetAllLights (RaymarchVolume.cpp:418-451: clear, then every light again) when every light's occlusion factors are
     kept (the factor cache, UNORM8 light volumes): the batched call samples the data volume not once — every pass is a sweep
     over kept factors, none is paired — and the light volume follows the oracle's replay of the reported order; so does the
-    removal of two of the lights. A float light volume takes the chunked chain, which caches nothing: same results."""
+    removal of two of the lights. A float light volume is swept from the same kept factors (round 4): same results within 2e-6."""
     dims = (72, 48, 56)
     res, orc = make_pair(gpu, oracle_mod, dims, np.uint16, light_32bit, seed=0x5EED0502)
     world = S.default_world()
@@ -545,8 +547,8 @@ def test_reset_all_lights_from_kept_factors_is_bit_exact(gpu, oracle_mod, light_
         if not light_32bit:
             assert all(b < 0 for _, _, b, _ in sched) and len(sched) == n_passes, sched
             assert after["hits"] - before["hits"] == n_passes and after["propagated"] == before["propagated"], (before, after)
-        else:
-            assert after["hits"] == before["hits"] == 0, (before, after)
+        else:  # (round 4: float light volumes sweep too, from the same kept factors; a pass the float sweep declines takes the chain)
+            assert after["hits"] - before["hits"] >= n_passes - 2, (before, after)
         for la, pa, lb, pb in sched:
             orc.add_dir_light_pass(lights[la], True, world, pa)
             if lb >= 0:
@@ -925,8 +927,8 @@ def test_contribution_cache_hits_misses_and_invalidation(gpu, oracle_mod, light_
     if not light_32bit:
         assert stats[0]["hits"] >= 10 and stats[0]["entries"] > 3, stats
         assert 0 < stats[2]["entries"] and stats[2]["bytes"] <= 4 << 20, stats
-    else:
-        assert stats[0]["hits"] == 0 and stats[0]["entries"] == 0, stats
+    else:  # (round 4: float light volumes sweep, and their passes' factors are kept like any other)
+        assert stats[0]["hits"] > 0 and stats[0]["entries"] > 0, stats
     assert stats[1]["hits"] == 0 and stats[1]["entries"] == 0, stats
     for other in finals[1:]:
         assert np.array_equal(finals[0], other) if not light_32bit else np.abs(finals[0] - other).max() == 0.0
