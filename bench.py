@@ -378,6 +378,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     paths0 = res.path_counters()
+    # the timed loop runs as a host that never asks for GPU times would: without the library's own event pairs around every
+    # operator (tbrm_last_gpu_time_ms; four markers per step between dependent kernels, ~1 % of the step). The gpu_ms passes below
+    # turn them on again. TBRM_BENCH_GPU_TIMING=1 keeps them on here too (A/B).
+    timing_in_loop = os.environ.get("TBRM_BENCH_GPU_TIMING") == "1"
+    if not timing_in_loop:
+        abi.set_tunable("gpu_timing", 0)
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(args.warmup + k, False)
@@ -388,6 +394,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    abi.set_tunable("gpu_timing", 1)
     paths1 = res.path_counters()
     # which kernels the timed steps launched (include/tbrm.h tbrm_path_counters), per step
     light_paths = {k: round((paths1[k] - paths0[k]) / max(args.steps, 1), 3) for k in paths1}
@@ -627,6 +634,7 @@ def main():
                 "light_update": args.light_update if slab_member is None else "slabs",
                 # what the tiles alone gain (the part of a step that shards), next to the whole step's figure in scaling_detail
                 "raymarch_ms_this_rank": round(ray_ms, 4)},
+            "timed_loop_records_gpu_timing_events": bool(timing_in_loop),
             "light_paths_per_step": light_paths,  # tbrm_path_counters over the timed loop: sweep / chain / slice passes and launches, occlusion launches
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)

@@ -189,7 +189,8 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
  * 0 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
  * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook), sweep_epoch_preset (0; > 0: a
- * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), ray_tables (1 = the
+ * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), gpu_timing (1 = operators record the HIP events behind
+ * tbrm_last_gpu_time_ms; 0 = they do not, and tbrm_last_gpu_time_ms fails until an operator has run with it on again), ray_tables (1 = the
  * lit march reads the data taps' offsets out of LDS tables where a step is at most one texel; 0 = computes them per sample), occ_after_frame (0; 1 = an
  * operator's occlusion waits for the lit frame in front of it: measured, loses). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);

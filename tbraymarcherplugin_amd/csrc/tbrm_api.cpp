@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
+    {"sweep_timeout_ms", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -154,13 +154,13 @@ PropParams base_prop_params(const tbrm_resources* r, const tbrm_world_params& wo
 
 int begin_timed(tbrm_resources* r, int kind)
 {
-    if (tune(TUNE_SWEEP_DEBUG) & 32) return TBRM_OK;
+    if ((tune(TUNE_SWEEP_DEBUG) & 32) || tune(TUNE_GPU_TIMING) == 0) { r->ev_valid[kind] = false; return TBRM_OK; }
     HIP_TRY(hipEventRecord(r->ev[kind][0], r->stream));
     return TBRM_OK;
 }
 int end_timed(tbrm_resources* r, int kind)
 {
-    if (tune(TUNE_SWEEP_DEBUG) & 32) return TBRM_OK;
+    if ((tune(TUNE_SWEEP_DEBUG) & 32) || tune(TUNE_GPU_TIMING) == 0) return TBRM_OK;
     HIP_TRY(hipEventRecord(r->ev[kind][1], r->stream));
     r->ev_valid[kind] = true;
     return TBRM_OK;
@@ -669,6 +669,11 @@ int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* remove
                         i, n, (int) op.a[i].axis, reach, g_plan_note);
         }
     }
+    // (a slab-partitioned operator is a light operator of its own for the sweep's buffer bookkeeping: its sweeps record their
+    // buffers' own idle events — no "operator done" event is recorded for it, a later operator's occlusion then waits for
+    // everything enqueued so far: wait_for_readers)
+    ++r->op_serial;
+    r->op_many_passes = true;
     *n_passes = op.n;
     return TBRM_OK;
 }

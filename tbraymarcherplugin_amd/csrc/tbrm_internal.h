@@ -310,6 +310,8 @@ enum Tunable : int {
                              // store / the cache entry to be idle (WRONG results: what gates its start?), 32: no timing events
     TUNE_SWEEP_TIMEOUT_MS,   // how long a sweep tile waits for a neighbour's hand-off word before it gives up and raises the handle's error
                              // word (0: 2 s; < 0: not at all — a test hook: every word that is not there yet fails the launch)
+    TUNE_GPU_TIMING,         // 0: operators do not record the HIP events behind tbrm_last_gpu_time_ms (four markers per step between
+                             // dependent kernels: a host that never asks for GPU times need not pay them)
     TUNE_RAY_TABLES,         // 0: k_raymarch_lit computes the data taps' offsets per sample even where its LDS offset tables apply
     TUNE_SWEEP_EPOCH_PRESET, // > 0: a handle's first sweep launch continues from this launch tag (a test hook: the 16-bit tags of the
                              // hand-off records start over after 65535 launches)

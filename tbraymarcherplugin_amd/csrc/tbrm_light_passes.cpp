@@ -556,7 +556,9 @@ static int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int st
     return TBRM_OK;
 }
 
-static FactorKey factor_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard)
+// start / D: the slices the planned sweep covers (a slab's share of a pass along z has the whole pass's geometry but its own
+// slices: its blocks and their ranks are not the whole pass's)
+static FactorKey factor_key(const tbrm_resources* r, const PropParams& base, const tbrm_light_pass& q, bool guard, int start, int D)
 {
     FactorKey k;
     memset(&k, 0, sizeof(k)); // compared bytewise
@@ -566,7 +568,7 @@ static FactorKey factor_key(const tbrm_resources* r, const PropParams& base, con
     for (int c = 0; c < 3; ++c) { k.cc[c] = base.cc[c]; k.cd[c] = base.cd[c]; k.uvw_off[c] = q.uvw_offset[c]; }
     k.data_border = base.data_border;
     k.clip_mode = base.clip_mode;
-    k.axis = q.axis; k.dir = q.dir; k.start = q.start; k.D = q.td[2]; k.W = q.td[0]; k.H = q.td[1];
+    k.axis = q.axis; k.dir = q.dir; k.start = start; k.D = D; k.W = q.td[0]; k.H = q.td[1];
     // the Add shader's uvw == saturate(uvw) guard only matters where a sample outside the cube could be opaque
     // (k_shell_transparent): else both shaders compute the same factors and one entry serves both
     k.guard = (guard && !r->shell_transparent) ? 1 : 0;
@@ -747,17 +749,25 @@ static void fill_pass_params(const tbrm_resources* r, const PropParams& base, co
 // A whole, unpartitioned pass over a UNORM8 light volume as ONE pipelined sweep (tbrm_light_sweep.hip): the occlusion of the
 // whole pass is computed block-compact on the occlusion stream — or comes from the factor cache — and one launch propagates.
 // TBRM_ERR_UNSUPPORTED (nothing changed): the pass takes the chunked chain.
+// slab (a pass along z of a slab-partitioned operator, round 4): the handle's own slices [z_begin, z_end) as one sweep that starts
+// from the planes the slab before handed on (or the pass's initial value) and leaves its last planes for the slab behind.
 static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& pa, const tbrm_light_pass* pr, float b_added,
-                           PassPlan& plan, int mode)
+                           PassPlan& plan, int mode, const tbrm_slab* slab = nullptr)
 {
     SweepFit sfit;
     if (!sweep_fit(r, pa, pr, mode, sfit)) return TBRM_ERR_UNSUPPORTED;
+    if (slab) {
+        const int nz = r->lv_dims[2];
+        if (pa.axis != 2 || sfit.two_way) return TBRM_ERR_UNSUPPORTED; // (lateral slab passes need a hand-off per slice across handles: the chain)
+        if (slab->z_begin < 0 || slab->z_end > nz || slab->z_begin >= slab->z_end || slab->z_begin % kChunkTile || slab->z_end % kChunkTile || nz % kChunkTile)
+            return TBRM_ERR_UNSUPPORTED; // (the chain's planner words the error)
+    }
     // The pass over the light volume padded to whole brick layers along its axis (the bricked layout has the padding voxels):
     // D slices from `start`, of which the `pad` slices beyond the volume come last when the pass runs upwards — garbage in,
     // garbage out, into voxels nothing reads — and first when it runs downwards, where the last of them hands on the initial
     // plane (SweepParams::reinit_slice).
-    const int D = ceil_div(pa.td[2], 8) * 8, pad = D - pa.td[2];
-    const int start = pa.dir > 0 ? 0 : D - 1;
+    const int D = slab ? slab->z_end - slab->z_begin : ceil_div(pa.td[2], 8) * 8, pad = slab ? 0 : D - pa.td[2];
+    const int start = slab ? (pa.dir > 0 ? slab->z_begin : slab->z_end - 1) : (pa.dir > 0 ? 0 : D - 1);
     if (D > sweep_max_slices() || tune(TUNE_SPARSE_OCC) == 0 || tune(TUNE_OCC_LIST) == 0) return TBRM_ERR_UNSUPPORTED;
     if (int e = ensure_skipping(r)) return e; // (the work list needs the per-brick emptiness bits)
     if (int e = ensure_occ_stream(r)) return e;
@@ -771,6 +781,12 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     plan.start = start;
     plan.M = plan.S = D;
     plan.n_chunks = plan.n_spans = plan.chunks_of_pass = 1;
+    if (slab) { // (the drivers order the slabs by first_chunk_of_pass; chunk = this slab's depth)
+        const int nz = r->lv_dims[2], before = pa.dir > 0 ? slab->z_begin : nz - slab->z_end;
+        plan.chunks_of_pass = ceil_div(nz, D);
+        plan.first_chunk_of_pass = before / D;
+        plan.pass_begins_here = before == 0;
+    }
     plan.sparse = plan.work_list = true;
     p.occ_groups = D / 8;
     plan.flags_per_group = (size_t) p.occ_blocks_y * p.occ_blocks_x;
@@ -789,9 +805,9 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     FactorEntry *have_a = nullptr, *have_r = nullptr, *refill = nullptr;
     FactorKey key_a{};
     if (cache_on) {
-        key_a = factor_key(r, base, pa, mode == PASS_ADD);
+        key_a = factor_key(r, base, pa, mode == PASS_ADD, start, D);
         have_a = kept_find(r, key_a);
-        if (change) have_r = kept_find(r, factor_key(r, base, *pr, false));
+        if (change) have_r = kept_find(r, factor_key(r, base, *pr, false, start, D));
         // (the removed light alone is not computed: both are — and the added light's factors go into the entry that already
         // holds them, not into a second one with the same key)
         if (change && have_a && !have_r) { refill = have_a; have_a = nullptr; }
@@ -800,7 +816,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     // further use unless the light comes back: first in line when a buffer is needed (kept_new)
     auto retire = [&](const tbrm_light_pass& q) {
         for (int guard = 0; guard < 2; ++guard) {
-            const FactorKey k = factor_key(r, base, q, guard != 0);
+            const FactorKey k = factor_key(r, base, q, guard != 0, start, D);
             for (FactorEntry* e : r->kept)
                 if (!memcmp(&e->key, &k, sizeof(k))) e->spent = true;
         }
@@ -872,8 +888,8 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     g_plan_note = "";
     const bool change = pr != nullptr;
     const int mode = change ? two_stream_mode : PASS_ADD;
-    if (!slab) {
-        const int e = plan_pass_sweep(r, base, pa, pr, b_added, plan, mode);
+    if (!slab || (pa.axis == 2 && !r->resident && mode != PASS_ADD2)) {
+        const int e = plan_pass_sweep(r, base, pa, pr, b_added, plan, mode, slab);
         if (e != TBRM_ERR_UNSUPPORTED) return e;
     }
     // the chunked chain: whatever the sweep declines (float light volumes, passes that are not whole brick layers, taps on
@@ -1252,7 +1268,7 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
     ChunkParams p = plan.p;
     p.j0 = plan.start;
     p.n_steps = plan.D;
-    p.first_chunk = 1;
+    p.first_chunk = plan.pass_begins_here ? 1 : 0; // (a slab behind the first continues from the planes it was handed)
     p.occ_phase = 0;
     p.a.plane_in = plan_plane(r, 0, 0); p.a.plane_out = plan_plane(r, 1, 0);
     p.r.plane_in = plan_plane(r, 0, 1); p.r.plane_out = plan_plane(r, 1, 1);

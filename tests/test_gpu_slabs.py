@@ -82,6 +82,11 @@ def test_slab_partitioned_lights_equal_single_handle(gpu, n_slabs, dims, half_re
         slabs.change_dir_light(members, fabric, old, new, world)
         assert_slabs_equal(full, members, "change across faces")
         assert fabric.bytes_moved > 0
+        # round 4: a slab's share of a pass ALONG z is one pipelined sweep (started from the planes the slab before handed on);
+        # lateral passes keep the chunked chain (their tiles would need a hand-off per slice across handles)
+        for m in members:
+            p = m.res.path_counters()
+            assert p["launches_sweep"] > 0 and p["launches_chain"] > 0 and p["launches_slice"] == 0, (m.slab_index, p)
         # the gathered volume is the whole unpartitioned one, on every handle
         slabs.gather_light_volume(members, fabric)
         ref = full.download_light_volume()
@@ -522,3 +527,33 @@ def test_dist_fabric_orders_rccl_transfers_with_the_handles_stream(gpu):
         res.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_repartitioned_handles_keep_their_partitions_factors_apart(gpu, tunables):
+    """The same handles partitioned in 2 slabs, then in 4 (what tests/test_gpu_full_size.py does at 1024^3, where this was found):
+    a slab's share of a pass along z is swept from kept occlusion factors, and the factor cache's key has to hold WHICH slices
+    the share covers — a downward pass of slab 0 starts at slice 63 in two slabs and at slice 31 in four; blocks and ranks of the
+    one are not the other's."""
+    tunables("light_cache_mb", -1)
+    dims = (64, 64, 128)
+    _, _, _, handles = make_handles(5, dims, np.uint16)
+    full, parts = handles[0], handles[1:]
+    world = S.default_world()
+    lights = [abi.DirLightParams(d, 0.35) for d in ((.2, -.3, -1), (.1, .45, 1), (-.25, .1, 1))]  # passes along z, both directions
+    try:
+        for n_slabs in (2, 4, 2):
+            members, fabric, _ = slab_setup(parts[:n_slabs], n_slabs)
+            for h in [full] + parts[:n_slabs]:
+                h.clear_light_volume(0.0)
+            for light in lights:
+                full.add_dir_light(light, True, world)
+                slabs.add_dir_light(members, fabric, light, True, world)
+            assert_slabs_equal(full, members, f"{n_slabs} slabs")
+            for light in lights[:2]:  # removals: from the factors the adds kept
+                full.add_dir_light(light, False, world)
+                slabs.add_dir_light(members, fabric, light, False, world)
+            assert_slabs_equal(full, members, f"{n_slabs} slabs, removals")
+        assert parts[0].path_counters()["launches_sweep"] > 0 and parts[0].light_cache_stats()["hits"] > 0
+    finally:
+        for h in handles:
+            h.close()
