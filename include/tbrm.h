@@ -189,7 +189,10 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
  * 0 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
  * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook), sweep_epoch_preset (0; > 0: a
- * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), gpu_timing (1 = operators record the HIP events behind
+ * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), fast_window_div (1 = where the host can vouch for the window — finite, moderate centre / width, UNORM data — the kernels
+ * compute the transfer-function position with three fmas instead of the IEEE division: the same bits, tbrm_selftest_window_division; 0 = always
+ * divide), slab_sweep (0; 1 = a slab's share of a pass along z
+ * runs as one sweep instead of the chunked chain: measured, a tie or a loss), gpu_timing (1 = operators record the HIP events behind
  * tbrm_last_gpu_time_ms; 0 = they do not, and tbrm_last_gpu_time_ms fails until an operator has run with it on again), ray_tables (1 = the
  * lit march reads the data taps' offsets out of LDS tables where a step is at most one texel; 0 = computes them per sample), occ_after_frame (0; 1 = an
  * operator's occlusion waits for the lit frame in front of it: measured, loses). Unknown name: TBRM_ERR_INVALID_ARG. */
@@ -393,6 +396,10 @@ TBRM_API int tbrm_upload_light_volume(tbrm_resources* res, const void* host_in, 
 TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, size_t* out_bytes);
 /* Kernel launches since creation: out[0] = chunked propagation launches, out[1] = slice-per-launch propagation
  * launches (fallback path), out[2] = raymarch launches. Lets tests assert which kernel actually ran. */
+/* Device self-test of the kernels' division-free window position (GetTransferFuncPosition, WindowedSampling.usf:14-17, for values
+ * filtered out of UNORM data): compares it with the IEEE quotient for EVERY float in [0, 1] and returns the number of
+ * mismatching bit patterns (0 expected); *out_fast_path = 0 when the library divides for this window anyway. */
+TBRM_API int tbrm_selftest_window_division(int device, float center, float width, uint64_t* out_mismatches, int* out_fast_path);
 TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
 /* Of out[0] above, the launches of the pipelined sweep kernel (one per axis pass; the rest are chunks of the chained kernel). */
 TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);

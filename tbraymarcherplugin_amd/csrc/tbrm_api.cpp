@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
+    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -99,10 +99,31 @@ VolumeDev data_view(const tbrm_resources* r)
     return VolumeDev{r->d_data, r->desc.dim_x, r->desc.dim_y, r->desc.dim_z, r->desc.data_format, r->dbn[0], r->dbn[0] * r->dbn[1],
                      q.wrap_src, (q.hi - q.wrap_src) * 8};
 }
-WindowDev window_dev(const tbrm_resources* r)
+// May the kernels divide by this window's width without the division sequence (tbrm_device_math.h tf_position_fast)? The width's
+// reciprocal correctly rounded (IEEE float division here), a significand that is not all ones, centre and width of moderate size
+// (no over- / underflow between a = value - centre + width / 2 in [-2^41, 2^41] and the quotient's correction term).
+static void window_division(float center, float width, float* inv_width, int* fast_div)
 {
-    return WindowDev{r->win.center, r->win.width, r->win.low_cutoff ? 1.0f : 0.0f, r->win.high_cutoff ? 1.0f : 0.0f};
+    *inv_width = 0.0f;
+    *fast_div = 0;
+    if (tune(TUNE_FAST_WINDOW_DIV) == 0 || !std::isfinite(center) || !std::isfinite(width)) return;
+    const float aw = std::fabs(width), ac = std::fabs(center);
+    if (!(aw >= 0x1p-40f && aw <= 0x1p40f) || ac > 0x1p40f) return;
+    uint32_t bits;
+    memcpy(&bits, &width, 4);
+    if ((bits & 0x007fffffu) == 0x007fffffu) return;
+    *inv_width = 1.0f / width;
+    *fast_div = 1;
 }
+
+WindowDev window_dev_of(float center, float width, int low_cutoff, int high_cutoff)
+{
+    WindowDev w{center, width, low_cutoff ? 1.0f : 0.0f, high_cutoff ? 1.0f : 0.0f, 0.0f, 0};
+    window_division(center, width, &w.inv_width, &w.fast_div);
+    return w;
+}
+
+WindowDev window_dev(const tbrm_resources* r) { return window_dev_of(r->win.center, r->win.width, r->win.low_cutoff, r->win.high_cutoff); }
 
 // The clip plane is inert for the propagation when every sample position (uvw + UVWOffset, inside
 // [-1/min(res), 1+1/min(res)]^3) sits >= 2 light-volume voxels on the kept side: AlphaWeight then clamps to
@@ -1133,6 +1154,26 @@ int tbrm_selftest_unorm8_roundtrip(int device, const float* in, size_t n, float*
     if (e == hipSuccess) e = hipMemcpy(out, d + n, n * sizeof(float), hipMemcpyDeviceToHost);
     (void) hipFree(d);
     HIP_TRY(e);
+    return TBRM_OK;
+}
+
+int tbrm_selftest_window_division(int device, float center, float width, uint64_t* out_mismatches, int* out_fast_path)
+{
+    if (!out_mismatches) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    WindowDev w = window_dev_of(center, width, 1, 1);
+    if (out_fast_path) *out_fast_path = w.fast_div;
+    *out_mismatches = 0;
+    if (!w.fast_div) return TBRM_OK; // (the kernels divide for this window: nothing to compare)
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**) &d, sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = launch_selftest_window_division(w, d, nullptr);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d, sizeof(bad), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    HIP_TRY(e);
+    *out_mismatches = bad;
     return TBRM_OK;
 }
 

@@ -121,6 +121,20 @@ __device__ __forceinline__ float tf_position(float value, float center, float wi
     return (value - center + (width / 2.0f)) / width;
 }
 
+// The same quotient, correctly rounded, in three instructions instead of the ~10 of the IEEE division sequence (two of them
+// quarter-rate): q = RN(a y) with y = RN(1 / width) from the host is within an ulp of a / width, the remainder a - q width is exact in
+// an fma, and one correction step rounds to the nearest (Markstein's theorem; it needs y correctly rounded — the host's division —,
+// a significand of `width` that is not all ones, and no over- / underflow on the way: the host checks all three and the operand range —
+// UNORM data, |center|, |width| within 2^+-40 — before it sets WindowDev::fast_div; tbrm_selftest_window_division compares the two
+// forms over every float in [0, 1] on the device).
+__device__ __forceinline__ float tf_position_fast(float value, float center, float width, float inv_width)
+{
+    const float a = value - center + (width / 2.0f);
+    const float q = a * inv_width;
+    const float r = fma_(-q, width, a);
+    return fma_(r, inv_width, q);
+}
+
 // IsCurPosClipped (RaymarcherCommon.usf:22-25)
 __device__ __forceinline__ bool is_clipped(float px, float py, float pz, const float* cc, const float* cd)
 {

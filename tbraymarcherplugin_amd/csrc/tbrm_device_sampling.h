@@ -210,10 +210,22 @@ __device__ __forceinline__ float sample_tf_alpha(const float* tf_alpha, float po
     return lerp_(tf_alpha[i0], tf_alpha[i1], f);
 }
 
+// GetTransferFuncPosition for a value filtered out of UNORM data (in [0, 1]: the range the host's fast_div vouches for); float data
+// always divides
+template <bool UNORM_DATA>
+__device__ __forceinline__ float window_position(float value, const WindowDev& w)
+{
+    if constexpr (UNORM_DATA) {
+        if (w.fast_div) return tf_position_fast(value, w.center, w.width, w.inv_width); // (wave-uniform)
+    }
+    return tf_position(value, w.center, w.width);
+}
+
 // SampleWindowedTransferFunction(...).a  (WindowedSampling.usf:20-37)
+template <bool UNORM_DATA = false>
 __device__ __forceinline__ float windowed_alpha(float value, float step, const float* tf_alpha, const WindowDev& w)
 {
-    const float pos = tf_position(value, w.center, w.width);
+    const float pos = window_position<UNORM_DATA>(value, w);
     if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return 0.0f;
     const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
     if (a == 0.0f) return 0.0f; // 1 - pow(1, s) == 0 exactly
@@ -222,10 +234,11 @@ __device__ __forceinline__ float windowed_alpha(float value, float step, const f
 
 // windowed_alpha(value, step0, ...) and windowed_alpha(value, step1, ...), bit for bit, sharing everything up to the opacity
 // correction's exponent (one sample position, two axis passes)
+template <bool UNORM_DATA = false>
 __device__ __forceinline__ void windowed_alpha2(float value, float step0, float step1, const float* tf_alpha, const WindowDev& w, float& a0, float& a1)
 {
     a0 = 0.0f; a1 = 0.0f;
-    const float pos = tf_position(value, w.center, w.width);
+    const float pos = window_position<UNORM_DATA>(value, w);
     if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return;
     const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
     if (a == 0.0f) return;

@@ -33,6 +33,10 @@ struct VolumeDev {
 
 struct WindowDev { // WindowingParameters float4 (VolumeInfo.h:49-52)
     float center, width, low_cutoff, high_cutoff;
+    // the host's licence to divide by `width` without the IEEE division sequence (tbrm_device_math.h tf_position_fast): RN(1 / width),
+    // and whether the window qualifies (else 0: the division). Not part of any cache key: the results are the same bits either way.
+    float inv_width;
+    int fast_div;
 };
 
 // One light stream of one axis pass (what LightingShaders.cpp:100-124 computes per axis).
@@ -310,6 +314,10 @@ enum Tunable : int {
                              // store / the cache entry to be idle (WRONG results: what gates its start?), 32: no timing events
     TUNE_SWEEP_TIMEOUT_MS,   // how long a sweep tile waits for a neighbour's hand-off word before it gives up and raises the handle's error
                              // word (0: 2 s; < 0: not at all — a test hook: every word that is not there yet fails the launch)
+    TUNE_FAST_WINDOW_DIV,    // 0: the kernels always divide by the window's width (IEEE sequence); 1: three fmas where the host vouches
+                             // for the window (WindowDev::fast_div) — the same bits
+    TUNE_SLAB_SWEEP,         // 1: a slab's share of a pass along z runs as one pipelined sweep instead of the chunked chain (measured at
+                             // 1024^3: a tie at 2 and 4 slabs, 6 % slower at 8 — a 128-slice sweep over 1024 tiles is mostly pipeline fill; off)
     TUNE_GPU_TIMING,         // 0: operators do not record the HIP events behind tbrm_last_gpu_time_ms (four markers per step between
                              // dependent kernels: a host that never asks for GPU times need not pay them)
     TUNE_RAY_TABLES,         // 0: k_raymarch_lit computes the data taps' offsets per sample even where its LDS offset tables apply
@@ -326,6 +334,7 @@ int tune(Tunable t);
 // launchers (tbrm_kernels.hip, tbrm_light_kernels.hip)
 hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s);
+hipError_t launch_selftest_window_division(const WindowDev& w, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt);
 size_t occlusion_lds_bytes(const ChunkParams& p); // dynamic LDS of an occlusion workgroup (the bricks it stages)

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
             }
             const float v = (TBRM_RAY_EXP & 4) ? 0.6f + fx * 0.01f : dtaps.filter(fx, fy, fz);
             // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
-            const float tpos = tf_position(v, p.win.center, p.win.width);
+            const float tpos = (TBRM_RAY_EXP & 4) ? tf_position(v, p.win.center, p.win.width) : window_position<DFMT != FMT_F32>(v, p.win);
             if (!((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f))) {
                 const float4 cs = sample_tf(s_tf, tpos);
                 const float a_sat = saturate_(cs.w);
@@ -509,6 +509,24 @@ hipError_t launch_raymarch(const RayParams& p, hipStream_t s)
         case FMT_U16: return launch_ray1<FMT_U16>(p, s);
         default: return launch_ray1<FMT_F32>(p, s);
     }
+}
+
+// ---- self-test of the division-free window position (tf_position_fast against the IEEE quotient, every float in [0, 1]) --------------
+__global__ __launch_bounds__(256) void k_selftest_window_division(WindowDev w, unsigned long long* mismatches)
+{
+    const uint32_t last = 0x3f800000u; // 1.0f
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= last; i += (uint64_t) gridDim.x * blockDim.x) {
+        const float v = __uint_as_float((uint32_t) i);
+        const float a = tf_position(v, w.center, w.width), b = tf_position_fast(v, w.center, w.width, w.inv_width);
+        if (__float_as_uint(a) != __float_as_uint(b)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+hipError_t launch_selftest_window_division(const WindowDev& w, unsigned long long* d_mismatches, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_window_division, dim3(256 * 64), dim3(256), 0, s, w, d_mismatches);
+    return hipGetLastError();
 }
 
 // ---- k_raymarch_intensity: PerformWindowedIntensityRaymarch (WindowedRaymarchMaterials.usf:187-242) ----------------

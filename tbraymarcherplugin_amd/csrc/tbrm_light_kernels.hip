@@ -70,7 +70,7 @@ __device__ __forceinline__ float propagate_stream(const PropParams& p, const Pro
     if constexpr (GUARD) inside = (u == saturate_(u)) && (v == saturate_(v)) && (w == saturate_(w));
     if (aw > 0.0f && inside) {
         const float val = sample_trilinear_border_uvw<DFMT>(p.data, u, v, w, p.data_border);
-        cur = windowed_alpha(val, s.step100, tf_alpha, p.win) * aw;
+        cur = windowed_alpha<DFMT != FMT_F32>(val, s.step100, tf_alpha, p.win) * aw;
     }
     return prev * (1 - cur);
 }
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                 if constexpr (DUAL) {
                     float occ0 = 0.0f, occ1 = 0.0f;
                     if (aw > 0.0f && inside) {
-                        windowed_alpha2(combine(lo, hi, fs), d.pass[0].step100[si], d.pass[1].step100[si], s_alpha, p.win, occ0, occ1);
+                        windowed_alpha2<DFMT != FMT_F32>(combine(lo, hi, fs), d.pass[0].step100[si], d.pass[1].step100[si], s_alpha, p.win, occ0, occ1);
                         occ0 = occ0 * aw;
                         occ1 = occ1 * aw;
                     }
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                     continue;
                 }
                 float occ = 0.0f;
-                if (aw > 0.0f && inside) occ = windowed_alpha(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
+                if (aw > 0.0f && inside) occ = windowed_alpha<DFMT != FMT_F32>(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
                 if constexpr (TBRM_OCC_EXP & 4) __hip_atomic_store(out + q * out_step, 1 - occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (write-through: what a finer hand-over to the sweep would need)
                 else out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }

@@ -888,7 +888,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
     g_plan_note = "";
     const bool change = pr != nullptr;
     const int mode = change ? two_stream_mode : PASS_ADD;
-    if (!slab || (pa.axis == 2 && !r->resident && mode != PASS_ADD2)) {
+    if (!slab || (pa.axis == 2 && !r->resident && mode != PASS_ADD2 && tune(TUNE_SLAB_SWEEP) != 0)) {
         const int e = plan_pass_sweep(r, base, pa, pr, b_added, plan, mode, slab);
         if (e != TBRM_ERR_UNSUPPORTED) return e;
     }

@@ -103,6 +103,7 @@ def test_config4_chunks_equal_slices_and_slabs_equal_one_handle(gpu, tunables):
         # z slabs: 2 and 8 (the same handles, re-partitioned)
         depth = whole.light_dims[2]
         for n_slabs in (2, 8):
+            tunables("slab_sweep", 1 if n_slabs == 2 else 0)  # (a slab's pass along z as one sweep / as the chunked chain)
             bounds = slabs.slab_bounds(depth, n_slabs)
             members = [slabs.DeviceSlab(res, k, *bounds[k]) for k, res in enumerate(parts[:n_slabs])]
             fabric = slabs.make_fabric([b[0] for b in bounds] + [depth])

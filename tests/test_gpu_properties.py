@@ -274,3 +274,32 @@ def test_error_behaviour_through_the_c_abi(gpu):
         assert res.add_dir_light(light, True, world)
         frame = res.raymarch_lit(cam, tile, rp, world)
         assert np.isfinite(frame).all() and frame[..., 3].max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("center,width", [(0.5, 0.9), (0.5, 0.8), (0.5, 1.0), (0.3, 1.4), (0.123456, 0.0371), (0.75, 3.0000002), (-2.5, 7.25), (0.5, 1e-3),
+                                          (0.5000001, 0.9), (0.5, -0.9)])
+def test_division_free_window_position_is_the_ieee_quotient(gpu, center, width):
+    """GetTransferFuncPosition (WindowedSampling.usf:14-17) divides by the window's width. For values filtered out of UNORM data the
+    kernels compute the quotient with three fmas (q = RN(a / w) from y = RN(1 / w): Markstein's correction step) where the host
+    vouches for the window; the device compares it with the IEEE division for EVERY float in [0, 1]: the same bits. Windows the
+    host does not vouch for (a width whose significand is all ones, non-finite or extreme parameters) keep the division."""
+    import ctypes as C
+
+    lib = abi.load()
+    bad, fast = C.c_uint64(123), C.c_int(-1)
+    abi.check(lib.tbrm_selftest_window_division(0, center, width, C.byref(bad), C.byref(fast)))
+    assert fast.value == 1 and bad.value == 0, (center, width, fast.value, bad.value)
+
+
+@pytest.mark.gpu
+def test_windows_the_host_does_not_vouch_for_keep_the_division(gpu):
+    import ctypes as C
+    import struct
+
+    lib = abi.load()
+    all_ones = struct.unpack("<f", struct.pack("<I", 0x3f7fffff))[0]  # 0.99999994: significand all ones
+    for center, width in ((0.5, all_ones), (0.5, float("inf")), (float("nan"), 0.9), (0.5, 1e-20), (1e20, 0.9)):
+        bad, fast = C.c_uint64(0), C.c_int(-1)
+        abi.check(lib.tbrm_selftest_window_division(0, center, width, C.byref(bad), C.byref(fast)))
+        assert fast.value == 0, (center, width)
