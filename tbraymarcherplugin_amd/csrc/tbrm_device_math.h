@@ -61,6 +61,40 @@ __device__ __forceinline__ float exp2_poly(float p)
     return v * __uint_as_float((uint32_t) (ni + 127) << 23);
 }
 
+// exp2_poly(p) for p <= 0 (or NaN), bit for bit: the results' exponent is never positive, so the overflow branch and the
+// 2^128 rescue drop out (the opacity correction raises 1 - a in [0, 1] to a step size >= 0: its exponent p = y log2 x is never positive)
+__device__ __forceinline__ float exp2_poly_nonpos(float p)
+{
+    if (!(p >= -150.0f)) return (p != p) ? p : 0.0f;
+    const float n = floorf(p + 0.5f);
+    const float g = p - n;
+    float r = 0x1.444004p-13f;
+    r = fma_(r, g, 0x1.5f0896p-10f);
+    r = fma_(r, g, 0x1.3b2a1cp-7f);
+    r = fma_(r, g, 0x1.c6af6cp-5f);
+    r = fma_(r, g, 0x1.ebfbep-3f);
+    r = fma_(r, g, 0x1.62e43p-1f);
+    float v = fma_(g, r, 1.0f);
+    int ni = (int) n;
+    if (ni < -126) { v = v * 0x1p-64f; ni += 64; }
+    return v * __uint_as_float((uint32_t) (ni + 127) << 23);
+}
+
+// pow_(x, y) for x in [0, 1] and y >= 0 (both NaN-free by construction: x = 1 - saturate(a), y = a step size the host checked), bit
+// for bit
+__device__ __forceinline__ float pow01_(float x, float y)
+{
+    if (!(x >= 0x1p-126f)) return (y > 0.0f) ? 0.0f : 1.0f; // (x == 0: pow_'s first branch with y >= 0)
+    return exp2_poly_nonpos(y * log2_poly(x));
+}
+__device__ __forceinline__ void pow01_2_(float x, float y0, float y1, float& r0, float& r1)
+{
+    if (!(x >= 0x1p-126f)) { r0 = (y0 > 0.0f) ? 0.0f : 1.0f; r1 = (y1 > 0.0f) ? 0.0f : 1.0f; return; }
+    const float l = log2_poly(x);
+    r0 = exp2_poly_nonpos(y0 * l);
+    r1 = exp2_poly_nonpos(y1 * l);
+}
+
 __device__ __forceinline__ float pow_(float x, float y)
 {
     if (!(x >= 0x1p-126f)) {

@@ -229,7 +229,7 @@ __device__ __forceinline__ float windowed_alpha(float value, float step, const f
     if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return 0.0f;
     const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
     if (a == 0.0f) return 0.0f; // 1 - pow(1, s) == 0 exactly
-    return 1.0f - pow_(1.0f - a, step);
+    return 1.0f - (step >= 0.0f ? pow01_(1.0f - a, step) : pow_(1.0f - a, step)); // (a in (0, 1]; step >= 0: wave-uniform)
 }
 
 // windowed_alpha(value, step0, ...) and windowed_alpha(value, step1, ...), bit for bit, sharing everything up to the opacity
@@ -243,7 +243,8 @@ __device__ __forceinline__ void windowed_alpha2(float value, float step0, float 
     const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
     if (a == 0.0f) return;
     float p0, p1;
-    pow2_(1.0f - a, step0, step1, p0, p1);
+    if (step0 >= 0.0f && step1 >= 0.0f) pow01_2_(1.0f - a, step0, step1, p0, p1); // (wave-uniform)
+    else pow2_(1.0f - a, step0, step1, p0, p1);
     a0 = 1.0f - p0;
     a1 = 1.0f - p1;
 }

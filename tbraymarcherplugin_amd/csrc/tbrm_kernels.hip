@@ -359,7 +359,9 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 const float4 cs = sample_tf(s_tf, tpos);
                 const float a_sat = saturate_(cs.w);
                 if (a_sat != 0.0f) { // else 1 - pow(1, s) = 0: the sample contributes exactly nothing
-                    const float a = (TBRM_RAY_EXP & 1) ? a_sat * step * 0.01f : 1.0f - pow_(1.0f - a_sat, step);
+                    // (a_sat in (0, 1]; the step is 100 / steps or 100 x a fraction in (0, 1): >= 0 unless the host passed a negative
+                    // step count, which build_ray_params rejects — pow01_ is pow_ on that domain, bit for bit)
+                    const float a = (TBRM_RAY_EXP & 1) ? a_sat * step * 0.01f : 1.0f - pow01_(1.0f - a_sat, step);
                     const float l = (TBRM_RAY_EXP & 2) ? gx : ltaps.filter(gx, gy, gz);
                     x = make_float4((cs.x * l) * a, (cs.y * l) * a, (cs.z * l) * a, a);
                 }
