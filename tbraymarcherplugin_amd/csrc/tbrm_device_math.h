@@ -142,6 +142,16 @@ __device__ __forceinline__ void texel_split(float u, float n, int& i0, float& f)
     f = x - fl;
 }
 
+// texel_split for a coordinate the caller knows to be finite and within +-2^30 texels (a sample position within a step of the unit
+// cube, a saturated coordinate): the clamp is dead there — the same bits without it
+__device__ __forceinline__ void texel_split_bounded(float u, float n, int& i0, float& f)
+{
+    const float x = u * n - 0.5f;
+    const float fl = floorf(x);
+    i0 = (int) fl;
+    f = x - fl;
+}
+
 __device__ __forceinline__ int wrap_index(int i, int n)
 {
     i %= n;

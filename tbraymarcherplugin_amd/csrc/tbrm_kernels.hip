@@ -156,7 +156,9 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 #define TBRM_RAY_EXP 0 // timing experiments (WRONG frames; tools/ray_ablation.sh): 1 = no pow, 2 = no light-volume taps, 4 = no data taps
 #endif                 // (constant value), 8 = no in-order accumulation (every lane adds its own sample), 16 = no leap-distance look-up;
                        // A/B variants with RIGHT frames: 32 = the four lanes of a ray exchange their samples by DPP quad broadcasts instead
-                       // of through LDS, 64 = the same with selects instead of exec-mask regions (both measured, both lost)
+                       // of through LDS, 64 = the same with selects instead of exec-mask regions (both measured, both lost), 128 = the light
+                       // volume's UNORM8 taps decoded through a 256-entry LDS table instead of convert + multiply + fma (a tie: 0.515 - 0.527
+                       // against 0.515 - 0.522 ms)
 #ifdef TBRM_RAY_STATS // diagnostics build (tools/ray_stats.sh): how full the waves of the lit march are
 __device__ unsigned long long g_ray_stats[4]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples
 extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsigned long long* out, int reset)
@@ -201,6 +203,8 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
     constexpr int LSH = kRayLanes == 4 ? 2 : 3;
     __shared__ float4 s_tf[256];
     __shared__ float4 s_x[256]; // per lane: (colour * alpha, alpha) of its sample; alpha < 0: nothing to accumulate
+    __shared__ float s_u8[(TBRM_RAY_EXP & 128) ? 256 : 1]; // (A/B variant 128: decode_u8 of every code, for the light volume's taps)
+    if constexpr (TBRM_RAY_EXP & 128) s_u8[threadIdx.x] = decode_u8(threadIdx.x);
     s_tf[threadIdx.x] = p.tf[threadIdx.x];
     if constexpr (!TAB) __syncthreads();
 
@@ -299,9 +303,15 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         const bool renew = eager && has && !live && idx <= safe_until;
         TapOffsets tab_dt{}; // TAB: the data taps' offsets, out of the tables
         if (live || renew) {
-            texel_split(q0, nx, ix, fx);
-            texel_split(q1, ny, iy, fy);
-            texel_split(q2, nz, iz, fz);
+            if constexpr (TAB) { // (the host's promise behind the tables: positions within a step of the unit cube)
+                texel_split_bounded(q0, nx, ix, fx);
+                texel_split_bounded(q1, ny, iy, fy);
+                texel_split_bounded(q2, nz, iz, fz);
+            } else {
+                texel_split(q0, nx, ix, fx);
+                texel_split(q1, ny, iy, fy);
+                texel_split(q2, nz, iz, fz);
+            }
             uint32_t tab_brick = 0;
             if constexpr (TAB) { // (indices -2 .. n: the host's promise; the clamp only keeps a broken promise inside the tables)
                 const int tx = min(max(ix + 2, 0), p.data.nx + 2), ty = min(max(iy + 2, 0), p.data.ny + 2), tz = min(max(iz + 2, 0), p.data.nz + 2);
@@ -346,10 +356,10 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 gx = fx; gy = fy; gz = fz;
                 ltaps.issue(p.light, dt);
             } else {
-                int lx, ly, lz;
-                texel_split(sp0, lnx, lx, gx);
-                texel_split(sp1, lny, ly, gy);
-                texel_split(sp2, lnz, lz, gz);
+                int lx, ly, lz; // (saturated coordinates: in [0, 1], or NaN -> 0)
+                texel_split_bounded(sp0, lnx, lx, gx);
+                texel_split_bounded(sp1, lny, ly, gy);
+                texel_split_bounded(sp2, lnz, lz, gz);
                 ltaps.issue(p.light, tap_offsets<ADDR_WRAP, SLAB>(lightv, lx, ly, lz));
             }
             const float v = (TBRM_RAY_EXP & 4) ? 0.6f + fx * 0.01f : dtaps.filter(fx, fy, fz);
@@ -362,7 +372,10 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                     // (a_sat in (0, 1]; the step is 100 / steps or 100 x a fraction in (0, 1): >= 0 unless the host passed a negative
                     // step count, which build_ray_params rejects — pow01_ is pow_ on that domain, bit for bit)
                     const float a = (TBRM_RAY_EXP & 1) ? a_sat * step * 0.01f : 1.0f - pow01_(1.0f - a_sat, step);
-                    const float l = (TBRM_RAY_EXP & 2) ? gx : ltaps.filter(gx, gy, gz);
+                    float l;
+                    if constexpr (TBRM_RAY_EXP & 2) l = gx;
+                    else if constexpr (LFMT == FMT_U8 && (TBRM_RAY_EXP & 128)) l = ltaps.filter_lut(s_u8, gx, gy, gz);
+                    else l = ltaps.filter(gx, gy, gz);
                     x = make_float4((cs.x * l) * a, (cs.y * l) * a, (cs.z * l) * a, a);
                 }
             }
