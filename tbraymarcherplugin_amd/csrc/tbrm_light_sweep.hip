@@ -66,7 +66,13 @@ constexpr int kSweepComputeWaves = 8;
 // + the hand-off wave + one factor loader per stream (an LDS-DMA costs its wave 60 - 180 cycles of issue: the eight of a
 // two-stream slice in one wave took longer than the slice)
 constexpr bool sweep_two_streams(int mode) { return mode == PASS_CHANGE || mode == PASS_ADD2; }
-constexpr int sweep_threads(int mode) { return (kSweepComputeWaves + 1 + (sweep_two_streams(mode) ? 2 : 1)) * 64; }
+#ifndef TBRM_SWEEP_HANDOFF_WAVES
+#define TBRM_SWEEP_HANDOFF_WAVES 2
+#endif
+// Hand-off waves per tile: 1 = one wave publishes, consumes and requests; 2 = a publisher and a consumer (each slice's
+// chain of LDS read -> convert -> store and of load -> decode -> LDS write then run side by side instead of one after the other)
+constexpr int kSweepHandoffWaves = TBRM_SWEEP_HANDOFF_WAVES;
+constexpr int sweep_threads(int mode) { return (kSweepComputeWaves + kSweepHandoffWaves + (sweep_two_streams(mode) ? 2 : 1)) * 64; }
 constexpr int kSweepFlagGroups = 128;                  // slice groups of a span (1024 slices)
 constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x 16 block slice of occlusion factors: the four
                                                        // blocks under a tile start 16 banks apart (a lane pair's columns c, c + 16)
@@ -268,8 +274,9 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     const bool stamping = (q.debug & 2) != 0 && q.stamps != nullptr && threadIdx.x == 0;
     if (stamping) q.stamps[4 * tile_lin + 0] = wall_clock64();
 
-    if (wave == NWC) {
-        // =================================================== the hand-off wave ===================================================
+    constexpr int HW = kSweepHandoffWaves;
+    if (wave >= NWC && wave < NWC + HW) {
+        // =================================================== the hand-off wave(s) ================================================
         // A tile publishes E_x = its hx columns and E_y = its hy rows on the side AWAY from the light, words [row][column of
         // E_x] then [row of E_y][column]; its halo is the same cells of the three upstream neighbours.
         const int e0x = q.sx > 0 ? 0 : T - hx, e0y = q.sy > 0 ? 0 : T - hy;
@@ -339,6 +346,8 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 rh_src[h] = on ? (uint32_t) ((nty * p.tiles_x + ntx) * r_RW + word) : 0u;
             }
         }
+        auto handoff = [&](auto pub_c, auto con_c) {
+        constexpr bool PUB = decltype(pub_c)::value, CON = decltype(con_c)::value;
         uint32_t hreg[RING][HC][NSW], rreg[RING][RREC ? HC : 1];
         // (every lane loads: the ones without a halo word read word 0 of the slice — a branch around a load whose result is
         // consumed slices later would make the compiler drain every request in flight at the join)
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         };
         sweep_each_const([&](auto sl) {
             constexpr int SL = decltype(sl)::value;
-            if constexpr (SL < PF) request_halo(SL, sl); // (n >= 8 > PF)
+            if constexpr (SL < PF && CON) request_halo(SL, sl); // (n >= 8 > PF)
         }, std::make_integer_sequence<int, RING>{});
 
         lds_barrier(); // (the loader's first factor slice is in LDS)
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 bool reinit = false;
                 if constexpr (FIRST) reinit = K8 + 1 == q.reinit_slice;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
-                if ((TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
+                if (PUB && (TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
                     uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RWS));
 #pragma unroll
                     for (int h = 0; h < HC; ++h)
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                         }
                 }
                 // the upstream neighbours' cells of THIS slice into the halo of the plane the compute waves are building
-                if constexpr (!(LAST && K8 == 7)) {
+                if constexpr (CON && !(LAST && K8 == 7)) {
 #pragma unroll
                     for (int h = 0; h < HC; ++h) {
                         if constexpr (F32) {
@@ -421,14 +430,18 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                         }
                     }
                 }
-                if constexpr ((!LAST || K8 + PF <= 6) && !(TBRM_SWEEP_EXP & 4)) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
+                if constexpr (CON && (!LAST || K8 + PF <= 6) && !(TBRM_SWEEP_EXP & 4)) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
                 if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
             }, std::make_integer_sequence<int, 8>{});
         };
         if (q.reinit_slice > 0) group(0, std::true_type{}, std::false_type{}); // (G >= 2: the launcher's check)
         for (int g = q.reinit_slice > 0 ? 1 : 0; g < G - 1; ++g) group(g, std::false_type{}, std::false_type{});
         group(G - 1, std::false_type{}, std::true_type{});
-    } else if (wave > NWC) {
+        };
+        if constexpr (HW == 1) handoff(std::true_type{}, std::true_type{});
+        else if (wave == NWC) handoff(std::true_type{}, std::false_type{});
+        else handoff(std::false_type{}, std::true_type{});
+    } else if (wave >= NWC + HW) {
         // ================================================= the factor loader =====================================================
         // Block-compact hand-over (ChunkStream::fs_*): per slice group each of the tile's 2 x 2 occlusion blocks of a stream
         // is 8 slices x 1 KiB, found through the block's rank among the pass's live blocks — in the cache entry being filled
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         // consumed: the count of loads in flight stays what the waits assume.)
         constexpr int L = 4; // loads per slice
         constexpr int A = FS - 1;
-        const int lsi = NS > 1 ? wave - (NWC + 1) : 0;
+        const int lsi = NS > 1 ? wave - (NWC + HW) : 0;
         const ChunkStream& st = stream(lsi);
         const int32_t* const ranks = sslot + lsi * 4 * G;
         const uint8_t* src[4]; // of the slice requested next
