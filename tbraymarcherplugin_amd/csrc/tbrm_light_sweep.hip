@@ -146,6 +146,13 @@ __device__ __forceinline__ v2f quantize2(v2f x)                                 
     c.y = __builtin_floorf(c.y);
     return c;
 }
+__device__ __forceinline__ v2f quantize2_unfloored(v2f x) // (>= 0.5: the conversion to an integer code IS the floor)
+{
+    v2f c;
+    c.x = __builtin_amdgcn_fmed3f(x.x, 0.0f, 1.0f);
+    c.y = __builtin_amdgcn_fmed3f(x.y, 0.0f, 1.0f);
+    return c * (v2f) 255.0f + (v2f) 0.5f;
+}
 
 // MODE: PASS_ADD (stream a), PASS_CHANGE (a added, r removed) or PASS_ADD2 (two lights that leave the same cube face added in one
 // sweep: per voxel light a's read-modify-write, then light r's on its result — exactly pass a followed by pass r). PF: slices ahead of their use that the neighbours'
@@ -524,6 +531,8 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             else if (AXIS == 1) lv_at[k] = lb + (uint32_t) (r & 7) * 64u + (uint32_t) (c & 7);
             else lv_at[k] = lb + (uint32_t) (r & 7) * 8u + (uint32_t) (c & 7);
         }
+        static_assert(R == 2, "a lane's two rows share a brick (r0 is even)");
+        lv_at[1] = lv_at[0] + (AXIS == 2 ? 8u : 64u); // (said so that the second voxel's address is the first one's plus an immediate)
         constexpr uint32_t kLvStep = AXIS == 0 ? 1u : (AXIS == 1 ? 8u : 64u);
         uint32_t lv_voxel[R] = {0, 0}; // F32: the pixel's voxel in the bricked light volume, slice 0 of the volume (elements)
         if constexpr (F32) {
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             }
             if constexpr (MODE != PASS_CHANGE) { nv = fma2(lv_l[0], (v2f) p.b_added, lv_old); d = lv_l[0]; } // (l * +-1 is exact: the fused form rounds once, like lv + l * b)
             else { d = lv_l[0] - lv_l[NS - 1]; nv = (lv_old + lv_l[0]) - lv_l[NS - 1]; }
-            const v2f qn = quantize2(nv);
+            const v2f qn = quantize2_unfloored(nv);
             const bool w0 = fabsf(d.x) > thresh && in_pl[0], w1 = fabsf(d.y) > thresh && in_pl[1];
             lv_prev[lv_at[0]] = (uint8_t) (w0 ? (uint32_t) qn.x : code_old[0]);
             lv_prev[lv_at[1]] = (uint8_t) (w1 ? (uint32_t) qn.y : code_old[1]);
