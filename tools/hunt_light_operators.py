@@ -18,4 +18,6 @@ for seed in range(lo, hi):
     except Exception as e:
         bad += 1
         print("SEED", seed, "FAILED:", str(e)[:300], flush=True)
+    if (seed - lo) % 50 == 49:
+        print("... through seed", seed, "failures", bad, flush=True)
 print("light-operator sweep seeds", lo, hi, "failures", bad, flush=True)
