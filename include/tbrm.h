@@ -195,7 +195,9 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * runs as one sweep instead of the chunked chain: measured, a tie or a loss), gpu_timing (1 = operators record the HIP events behind
  * tbrm_last_gpu_time_ms; 0 = they do not, and tbrm_last_gpu_time_ms fails until an operator has run with it on again), ray_tables (1 = the
  * lit march reads the data taps' offsets out of LDS tables where a step is at most one texel; 0 = computes them per sample), occ_after_frame (0; 1 = an
- * operator's occlusion waits for the lit frame in front of it: measured, loses). Unknown name: TBRM_ERR_INVALID_ARG. */
+ * operator's occlusion waits for the lit frame in front of it: measured, loses), ray_xcd_rows (1 = the lit march deals its 8 x 8
+ * pixel blocks to the GPU's eight XCDs row by row — horizontal neighbours, which march through the same bricks, share an L2 —; n = in
+ * bands of n rows; 0 = in launch order, i.e. round-robin block by block: 10 % slower at 512^3). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);
 TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
 

@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1},
+    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1}, {"ray_xcd_rows", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -206,6 +206,7 @@ int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile*
     p.data_addr_mode = r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP;
     p.tf = r->d_tf;
     p.win = window_dev(r);
+    p.xcd_rows = tune(TUNE_RAY_XCD_ROWS);
     p.light = r->d_light;
     for (int c = 0; c < 3; ++c) p.lv_dims[c] = r->lv_dims[c];
     p.lv_bnx = r->lbn[0];

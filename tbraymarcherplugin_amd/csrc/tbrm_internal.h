@@ -224,6 +224,7 @@ struct RayParams {
     const float* depth; // may be null
     float* out;         // tile_w*tile_h*4
     const uint32_t* empty_bits; // one bit per brick; null when skipping is off
+    int xcd_rows;               // k_raymarch_lit: rows of pixel blocks per band dealt to one XCD (tunable ray_xcd_rows; 0: launch order)
     const uint2* tab;           // k_raymarch_lit TAB: per axis and texel index -2 .. n + 1 the {voxel offset, brick-index part} of the
                                 // addressed texel (x, then y, then z); null: none (slab-resident handles)
     const uint8_t* skip_dist;   // per brick: Chebyshev distance (bricks, capped) to the nearest non-empty brick; null when skipping is off
@@ -327,6 +328,7 @@ enum Tunable : int {
                              // the same thing, the vector ALUs) but beside the sweeps behind it (which leave two thirds of the issue slots idle)
     TUNE_OCC_DUAL,           // 1: the two axis passes of a light share ONE occlusion launch where their sampling positions are bit-equal
                              // (DualOcc); 0: one launch per pass
+    TUNE_RAY_XCD_ROWS,       // k_raymarch_lit: rows of pixel blocks per band dealt to one XCD (0: blocks in launch order, i.e. round-robin)
     TUNE_COUNT
 };
 int tune(Tunable t);
