@@ -85,6 +85,25 @@ def test_skipping_and_tiling_do_not_change_the_image_at_config2_size(gpu):
             assert n == n_parts and n > 10_000_000
 
 
+def test_the_order_pixel_blocks_go_to_the_xcds_in_does_not_change_the_image(gpu, tunables):
+    """ray_xcd_rows (k_raymarch_lit): launch order, rows, bands of 2 and 4 rows; a frame whose rows of blocks do not divide by
+    8 x rows takes the launch order whatever the tunable says."""
+    world = S.default_world()
+    with make(gpu, 128, tf="B", window=(0.5, 0.8, True, True)) as res:
+        for i in range(2):
+            res.add_dir_light(S.light(i), True, world)
+        for w, h in ((512, 512), (256, 192), (136, 72)):  # 64, 24 and 9 rows of 8 x 8 blocks
+            cam = S.default_camera(w, h)
+            tile = abi.Tile(0, 0, w, h)
+            rp = abi.RaymarchParams(128.0, -1, True)
+            tunables("ray_xcd_rows", 0)
+            want = res.raymarch_lit(cam, tile, rp, world)
+            assert want[..., 3].max() > 0.5
+            for rows in (1, 2, 4):
+                tunables("ray_xcd_rows", rows)
+                assert np.array_equal(res.raymarch_lit(cam, tile, rp, world), want), (w, h, rows)
+
+
 def test_unorm_decode_is_exact_division(gpu):
     """The 2-instruction UNORM decode of the kernels (fma(c, r, c*r2), reciprocal split in two floats) equals IEEE
     c/255 and c/65535 for every code."""
