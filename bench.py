@@ -11,13 +11,14 @@ rank's share of the framebuffer, and (N>1) the RCCL all-gather of the tiles. Inp
 the timed region; the initial ResetAllLights (clear + 4 adds) is untimed setup and reported separately.
 
 N>1 (one process per GPU, torch.distributed/RCCL; `python bench.py --gpus N` from a bare shell re-launches itself under
-torch.distributed.run): BASELINE config 5 as north_star words it — 512^3 volume, ONE 2048^2 frame tile-partitioned over
-the GPUs, empty-space skipping on, 8 lights, TF-B — i.e. STRONG scaling of a fixed frame: rank r renders every N-th
-group of 8 rows (load-balanced interleave), volumes are replicated, the selective light update is computed redundantly
-on every GPU (no data-path collective: the update of ONE light is one serial slice sweep per axis) and the
-only exchange is the all_gather of the tiles. The line reports the full step, the raymarch-only rate, the same workload
-timed on one GPU in the same run, and the Amdahl ceiling the redundant update puts on the step. `--weak` keeps round
-1's mode (the framebuffer grows to ~N x fb^2 pixels); `--config K` picks another workload.
+torch.distributed.run): THE SAME WORKLOAD as N=1 — config 3 — at every N, so that value(N) / value(1) is a speed-up: STRONG
+scaling of one fixed frame, rank r renders every N-th group of 8 rows (load-balanced interleave), volumes are replicated,
+the selective light update is computed redundantly on every GPU (no data-path collective: the update of ONE light is one
+serial slice sweep per axis) and the only exchange is the all_gather of the tiles. The line reports the full
+step, the raymarch-only rate, the same workload timed on one GPU in the same run (top-level `speedup_vs_one_gpu`,
+`frame_speedup_vs_one_gpu`) and the Amdahl ceiling the redundant update puts on the step. `--config 5` runs north_star's
+scaling workload instead (512^3, ONE 2048^2 frame, 8 lights, TF-B, skipping on); `--weak` keeps round 1's mode (the
+framebuffer grows to ~N x fb^2 pixels).
 
 value = nominal samples of all ranks per step / step time, in Msamples/s (nominal sample = one loop iteration of
 PerformWindowedLitRaymarch that geometry prescribes, independent of early termination and skipping).
@@ -131,7 +132,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=None,
-                    help="SURVEY.md §8d config number; default: 3 (the metric's config) at N=1, 5 (north_star's scaling config) at N>1")
+                    help="SURVEY.md §8d config number; default: 3 (the metric's config) at EVERY N — value(N) / value(1) is then a speed-up; "
+                         "5 = north_star's tile-scaling workload (one 2048^2 frame)")
     ap.add_argument("--weak", action="store_true", help="N>1: grow the framebuffer with N (~N x fb^2 pixels) instead of splitting one frame")
     ap.add_argument("--fixed-frame", action="store_true", help="N>1: split ONE frame of the config's size over the GPUs (the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +160,7 @@ def main():
                          "exchange + the frame marched slab by slab (strong scaling: one frame of the config's size)")
     args = ap.parse_args()
     if args.config is None:
-        args.config = 3 if (args.gpus == 1 or args.slab_resident or args.slab_illumination) else 5
+        args.config = 3
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_torchrun(args.gpus))
     if os.environ.get("TBRM_BENCH_LAUNCH_CHECK") == "1":  # tests/test_bench_launcher.py: what did the launcher start?
@@ -384,17 +386,19 @@ def main():
     timing_in_loop = os.environ.get("TBRM_BENCH_GPU_TIMING") == "1"
     if not timing_in_loop:
         abi.set_tunable("gpu_timing", 0)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k, False)
-    for h in pending:
-        if h is not None:
-            h.wait()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    abi.set_tunable("gpu_timing", 1)
+    try:
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(args.warmup + k, False)
+        for h in pending:
+            if h is not None:
+                h.wait()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    finally:  # (process-global: whatever happens in the loop, later handles record their timing events again)
+        abi.set_tunable("gpu_timing", 1)
     paths1 = res.path_counters()
     # which kernels the timed steps launched (include/tbrm.h tbrm_path_counters), per step
     light_paths = {k: round((paths1[k] - paths0[k]) / max(args.steps, 1), 3) for k in paths1}
@@ -505,11 +509,14 @@ def main():
         ops_ms["window_sweep_step"] = timed(lambda: (stale_window(), reset_all_lights(), res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())))
         abi.set_tunable("light_cache_mb", 0)
         ops_ms["reset_all_lights_uncached"] = timed(reset_all_lights)
+        # every Change from an idle handle, timed on torch's view of the library's stream: the operator's occlusion runs on the
+        # handle's second stream, and between back-to-back calls the NEXT call's occlusion starts beside this call's sweeps and
+        # falls outside the library's own event pair (round 4 reported 0.79 ms that way — less than the cached figure)
         unc = []
         for li in range(len(lights)):
             new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li] + 5.0), lights[li].light_intensity)
-            res.change_dir_light(lights[li], new, world)
-            unc.append(res.last_gpu_time_ms(0))
+            res.flush()
+            unc.append(gpu_ms(torch, lib_stream, lambda: res.change_dir_light(lights[li], new, world)))
             res.change_dir_light(new, lights[li], world)
         ops_ms["change_dir_light_uncached"] = float(np.mean(unc))
         abi.set_tunable("light_cache_mb", cache_default)
@@ -638,6 +645,9 @@ def main():
             "light_paths_per_step": light_paths,  # tbrm_path_counters over the timed loop: sweep / chain / slice passes and launches, occlusion launches
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)
+            # N > 1: this line's step against the SAME workload on one GPU in the same run (whole step; the frame alone)
+            "speedup_vs_one_gpu": None if scaling_note is None else scaling_note["speedup_vs_one_gpu"],
+            "frame_speedup_vs_one_gpu": None if scaling_note is None else scaling_note["raymarch_only_speedup_vs_one_gpu"],
             "scaling_detail": scaling_note,
             "roofline": roofline,
             "roofline_issue": issue,

@@ -410,7 +410,9 @@ TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);
  * per launch; out[3] sweep launches (a two-way Change takes two per pass), out[4] chain launches, out[5] slice launches;
  * out[6] occlusion launches that served one pass, out[7] occlusion launches that served both passes of a light
  * (tunable occ_dual); out[8] stream-passes whose occlusion came from the factor cache; out[9] lit-raymarch launches;
- * out[10] sweep launches that propagated two lights' passes at once (tbrm_add_dir_lights); out[11..15] reserved (0). */
+ * out[10] sweep launches that propagated two lights' passes at once (tbrm_add_dir_lights); out[11] passes / dual launches whose
+ * block lists (empty-block flags, work list, ranks) had to be computed — the others found them with the handle;
+ * out[12..15] reserved (0). */
 #define TBRM_PATH_COUNTERS 16
 TBRM_API int tbrm_path_counters(const tbrm_resources* res, uint64_t out[TBRM_PATH_COUNTERS]);
 /* The factor cache of the light operators (no counterpart in the reference, invisible in the results). The expensive half

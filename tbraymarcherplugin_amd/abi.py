@@ -524,7 +524,7 @@ class Resources:
         return {"chunk": int(out[0]), "slice": int(out[1]), "raymarch": int(out[2]), "sweep": int(sweeps.value)}
 
     PATH_COUNTERS = ("passes_sweep", "passes_chain", "passes_slice", "launches_sweep", "launches_chain", "launches_slice",
-                     "occlusion_single", "occlusion_dual", "occlusion_cached", "raymarch", "pair_sweeps")
+                     "occlusion_single", "occlusion_dual", "occlusion_cached", "raymarch", "pair_sweeps", "block_lists_built")
 
     def path_counters(self):
         """tbrm_path_counters: which kernels the light operators took (per axis pass and per launch)."""

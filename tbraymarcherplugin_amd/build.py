@@ -12,13 +12,17 @@ LIB_PATH = os.path.join(LIB_DIR, "libtbrm.so")
 # (source, object name, extra flags): tbrm_light_chain.hip is compiled once per light-volume format so that the two halves
 # of the chain kernel's instantiations build in parallel
 UNITS = [
-    ("tbrm_api.cpp", "tbrm_api", []), ("tbrm_light_passes.cpp", "tbrm_light_passes", []), ("tbrm_host_math.cpp", "tbrm_host_math", []),
+    ("tbrm_api.cpp", "tbrm_api", []), ("tbrm_light_passes.cpp", "tbrm_light_passes", []), ("tbrm_block_lists.cpp", "tbrm_block_lists", []), ("tbrm_host_math.cpp", "tbrm_host_math", []),
     ("tbrm_kernels.hip", "tbrm_kernels", []), ("tbrm_light_kernels.hip", "tbrm_light_kernels", []),
     ("tbrm_light_chain.hip", "tbrm_light_chain_u8", ["-DTBRM_CHAIN_LFMT=0"]), ("tbrm_light_chain.hip", "tbrm_light_chain_f32", ["-DTBRM_CHAIN_LFMT=2"]),
-    ("tbrm_light_sweep.hip", "tbrm_light_sweep", []),
+    ("tbrm_light_sweep_dispatch.cpp", "tbrm_light_sweep_dispatch", []),
+] + [
+    # k_light_sweep: one unit per mode (PASS_ADD 0, PASS_CHANGE 1, PASS_ADD2 2, PASS_PLANES 5) and tile height
+    ("tbrm_light_sweep.hip", f"tbrm_light_sweep_m{m}_t{t}", [f"-DTBRM_SWEEP_UNIT_MODE={m}", f"-DTBRM_SWEEP_UNIT_TH={t}"])
+    for t in (16, 32) for m in (1, 0, 2, 5)
 ]
 SOURCES = sorted({u[0] for u in UNITS})
-HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h",
+HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h", "tbrm_light_sweep.h",
            "../../include/tbrm.h"]
 
 # -ffp-contract=off + explicit fma is the arithmetic contract with the oracle (DESIGN.md "Arithmetic spec").
@@ -80,7 +84,7 @@ def _build_locked(verbose, ThreadPoolExecutor):
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), max(os.cpu_count() or 4, 4))) as pool:
         objs = list(pool.map(compile_one, UNITS))
     tmp_lib = LIB_PATH + f".{os.getpid()}.tmp"
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden"] + objs + ["-o", tmp_lib]

@@ -291,6 +291,7 @@ int ensure_skipping(tbrm_resources* r)
             HIP_TRY(launch_brick_dist(dp, mode, r->stream));
         }
         r->empty_valid = true;
+        ++r->empty_gen;
         r->occ_inputs_changed = true; // (the occlusion stream orders itself behind this: order_behind_inputs)
     }
     return TBRM_OK;
@@ -1202,6 +1203,7 @@ int tbrm_path_counters(const tbrm_resources* r, uint64_t out[TBRM_PATH_COUNTERS]
     out[8] = r->kept_hits;
     out[9] = r->launches[2];
     out[10] = r->pair_sweeps;
+    out[11] = r->lists_launches;
     return TBRM_OK;
 }
 

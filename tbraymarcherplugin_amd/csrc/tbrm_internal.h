@@ -193,6 +193,7 @@ struct SweepParams {
     int debug;              // diagnostics (sweep_debug tunable): bit 0 = tiles do not wait for each other (WRONG results: slice time alone);
                             // bit 1 = every tile leaves four time stamps (10 ns units) in `stamps`
     unsigned long long* stamps; // [tile][4]: start of slice 0, end of slice 63, end of the last slice, after the write-back
+    int tile_rows;          // height of a tile: 32, or 16 (two workgroups per CU; tbrm_light_sweep.h sweep_tile_rows); a tile is 32 wide
     int lv_f32;             // the light volume (and the planes) are floats: k_light_sweep<..., FMT_F32>, records pre-filled with 0xffffffff
     int reinit_slice;       // > 0: the launch's first reinit_slice slices lie in front of the volume (a pass that runs downwards from a
                             // depth that is no multiple of 8, padded to whole brick layers): slice reinit_slice - 1 hands on the pass's
@@ -304,7 +305,7 @@ enum Tunable : int {
     TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)
     TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
     TUNE_LIGHT_SWEEP,        // 0: axis passes never take the pipelined sweep kernel (k_light_sweep); 1: where it applies
-    TUNE_SWEEP_ROWS,         // (unused: a sweep lane owns two rows)
+    TUNE_SWEEP_ROWS,         // height of a sweep tile: 16 (two workgroups per CU; default) or 32 (one)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
     TUNE_SWEEP_STAGGER_NS,   // start delay of a sweep tile per tile of distance from the upstream corner, ns (0: default; < 0: none)
     TUNE_STREAM_PRIORITY,    // priority of a handle's own stream, read when the handle is created: 0 = default, 1 = the highest the
@@ -346,9 +347,6 @@ hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s,
 hipError_t launch_unit_flags(const ChunkParams& pc, const DualOcc& d, hipStream_t s); // + the units' work list (pc: the virtual pass along the third axis)
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s);
-size_t sweep_lds_bytes(int mode, int slices, int lv_fmt = FMT_U8);
-int sweep_halo_chunks(int hx, int hy);
-int sweep_max_slices();
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);

@@ -5,6 +5,7 @@
 // slab-partitioned ones.
 #include "tbrm_resources.h"
 #include "tbrm_light_chain.h"
+#include "tbrm_light_sweep.h"
 
 #include <algorithm>
 #include <climits>
@@ -103,7 +104,8 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         fit.hx = std::max(fit.hx, tx.reach);
         fit.hy = std::max(fit.hy, ty.reach);
     }
-    if (!opposite) return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= (f32 ? 3 : 6);
+    const int th = sweep_tile_rows();
+    if (!opposite) return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy, th) <= (f32 ? 3 : 6);
     if (tune(TUNE_LIGHT_SWEEP) == 2 || f32) return false; // (diagnostics: such passes take the chain, as before round 3's last week)
     fit.two_way = true;
     fit.sx = side[0][0].side; fit.hx = side[0][0].reach; fit.sy = side[0][1].side; fit.hy = side[0][1].reach;
@@ -115,7 +117,7 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         for (int si = 0; si < 2; ++si) (side[si][ax].side < 0 ? lo : hi) = std::max(side[si][ax].side < 0 ? lo : hi, side[si][ax].reach);
         room[ax] = lo + hi;
     }
-    return room[0] <= 14 && room[1] <= 14 && sweep_halo_chunks(fit.hx, fit.hy) <= 6 && sweep_halo_chunks(fit.r_hx, fit.r_hy) <= 6;
+    return room[0] <= 14 && room[1] <= 14 && sweep_halo_chunks(fit.hx, fit.hy, th) <= 6 && sweep_halo_chunks(fit.r_hx, fit.r_hy, th) <= 6;
 }
 
 void release_sweep(tbrm_resources* r)
@@ -421,9 +423,8 @@ void drain_streams_public(tbrm_resources* r) { drain_streams(r); }
 static void free_entry(FactorEntry* e)
 {
     (void) hipFree(e->base);
-    (void) hipFree(e->slot);
-    if (e->count_host) (void) hipHostFree(e->count_host);
-    for (hipEvent_t ev : {e->ev_count, e->ev_filled, e->ev_idle})
+    if (e->lists) --e->lists->users;
+    for (hipEvent_t ev : {e->ev_filled, e->ev_idle})
         if (ev) (void) hipEventDestroy(ev);
     delete e;
 }
@@ -455,22 +456,14 @@ void release_occ_stores(tbrm_resources* r)
     for (auto& slot : r->occ_slot) slot = tbrm_resources::OccSlot{};
     for (FactorScratch& f : r->f_scratch) {
         for (float*& st : f.store) { (void) hipFree(st); st = nullptr; }
-        (void) hipFree(f.flags);
-        (void) hipFree(f.list);
-        (void) hipFree(f.slot);
-        (void) hipFree(f.count);
         for (hipEvent_t ev : {f.ev_ready, f.ev_idle})
             if (ev) (void) hipEventDestroy(ev);
         f = FactorScratch{};
     }
     (void) hipFree(r->d_ones);
     r->d_ones = nullptr;
-    (void) hipFree(r->dual_flags);
-    (void) hipFree(r->dual_list);
-    (void) hipFree(r->dual_count);
-    r->dual_flags = nullptr; r->dual_list = nullptr; r->dual_count = nullptr;
-    r->dual_units = 0;
     release_kept(r);
+    release_block_lists(r);
 }
 
 // room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass
@@ -517,7 +510,7 @@ static int ensure_occ_stream(tbrm_resources* r)
 }
 
 // the scratch of a sweep pass with `blocks` occlusion blocks: stores of `streams` streams (every block could be live), the
-// pass's metadata, the page of ones
+// page of ones
 static int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int streams)
 {
     FactorScratch& f = r->f_scratch[b];
@@ -530,21 +523,11 @@ static int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int st
         HIP_TRY(hipEventCreateWithFlags(&f.ev_ready, event_flags()));
         HIP_TRY(hipEventCreateWithFlags(&f.ev_idle, event_flags()));
     }
-    const bool grow_store = blocks > f.store_blocks, grow_meta = blocks > f.meta_blocks;
-    bool need = grow_meta;
+    const bool grow_store = blocks > f.store_blocks;
+    bool need = false;
     for (int si = 0; si < streams; ++si) need = need || grow_store || !f.store[si];
     if (!need) return TBRM_OK;
     drain_streams(r);
-    if (grow_meta) {
-        (void) hipFree(f.flags); (void) hipFree(f.list); (void) hipFree(f.slot); (void) hipFree(f.count);
-        f.flags = nullptr; f.list = nullptr; f.slot = nullptr; f.count = nullptr;
-        f.meta_blocks = 0;
-        HIP_TRY(hipMalloc((void**) &f.flags, blocks));
-        HIP_TRY(hipMalloc((void**) &f.list, blocks * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**) &f.slot, blocks * sizeof(int32_t)));
-        HIP_TRY(hipMalloc((void**) &f.count, 16 * sizeof(int)));
-        f.meta_blocks = blocks;
-    }
     if (grow_store) {
         for (float*& st : f.store) { (void) hipFree(st); st = nullptr; }
         f.store_blocks = 0;
@@ -595,10 +578,9 @@ static void estimate_scope(tbrm_resources* r, const PropParams& base)
 static void resolve_entry(tbrm_resources* r, FactorEntry* e, bool wait)
 {
     if (e->resolved || !e->enqueued) return;
-    if (wait) (void) hipEventSynchronize(e->ev_count);
-    else if (hipEventQuery(e->ev_count) != hipSuccess) { (void) hipGetLastError(); return; }
+    size_t count = 0;
+    if (!block_lists_count(e->lists, wait, &count)) return;
     e->resolved = true;
-    const size_t count = (size_t) std::max(*e->count_host, 0);
     e->valid = count <= e->cap_blocks;
     if (e->key.data_gen == r->f_est_key[0] && e->key.tf_gen == r->f_est_key[1] && !memcmp(e->key.win, r->f_est_win, sizeof(e->key.win)))
         r->f_est_blocks = std::max(r->f_est_blocks, count);
@@ -627,11 +609,11 @@ static size_t kept_budget(const tbrm_resources* r)
 // An entry for a pass about to be computed, sized for `want` blocks: the buffer of an entry whose light has left the scene
 // if one is large enough (no allocation while lights merely move), else a fresh allocation while the budget lasts and the
 // device has room to spare, else the least recently used entry's. null: the cache is off, or nothing can be had.
-static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t want, size_t table_blocks)
+static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t want, BlockLists* lists)
 {
     const size_t bytes = want * 2048 * sizeof(float);
     FactorEntry* e = nullptr;
-    auto fits = [&](const FactorEntry* c) { return !c->pinned && c->cap_blocks >= want && c->cap_blocks <= want + want / 2 + 64 && c->table_blocks >= table_blocks; };
+    auto fits = [&](const FactorEntry* c) { return !c->pinned && c->cap_blocks >= want && c->cap_blocks <= want + want / 2 + 64; };
     auto reusable = [&](const FactorEntry* c) { return fits(c) && ((c->resolved && !c->valid) || c->spent || !c->enqueued); };
     // An entry that the operator just before this one read (the removed side of its Change) is still being read by that
     // operator's sweeps when this operator's occlusion could start — beside those very sweeps, which leave two thirds of a
@@ -676,16 +658,14 @@ static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t wan
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + ((size_t) 1 << 30)) { (void) hipGetLastError(); return nullptr; }
         e = new FactorEntry{};
-        bool ok = hipMalloc((void**) &e->base, bytes) == hipSuccess && hipMalloc((void**) &e->slot, table_blocks * sizeof(int32_t)) == hipSuccess &&
-                  hipHostMalloc((void**) &e->count_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
-        for (hipEvent_t* ev : {&e->ev_count, &e->ev_filled, &e->ev_idle}) ok = ok && hipEventCreateWithFlags(ev, event_flags()) == hipSuccess;
+        bool ok = hipMalloc((void**) &e->base, bytes) == hipSuccess;
+        for (hipEvent_t* ev : {&e->ev_filled, &e->ev_idle}) ok = ok && hipEventCreateWithFlags(ev, event_flags()) == hipSuccess;
         if (!ok) { // out of memory: do without
             (void) hipGetLastError();
             free_entry(e);
             return nullptr;
         }
         e->cap_blocks = want;
-        e->table_blocks = table_blocks;
         r->kept.push_back(e);
     }
     e->key = key;
@@ -695,7 +675,9 @@ static FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t wan
     e->spent = false;
     e->pinned = true;
     e->last_use = ++r->kept_clock;
-    *e->count_host = 0;
+    if (e->lists) --e->lists->users;
+    e->lists = lists; // (its blocks will be stored under these ranks)
+    ++lists->users;
     return e;
 }
 
@@ -830,20 +812,30 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
         plan.occ_mode = !change ? PASS_ADD : (have_r ? PASS_CHANGE_ONE : PASS_CHANGE);
         r->kept_computed += plan.occ_mode == PASS_CHANGE ? 2 : 1;
         if (int e = ensure_factor_scratch(r, plan.f_buf, blocks, plan.occ_mode == PASS_CHANGE ? 2 : 1)) return e;
+        // the pass's block lists: the handle's, if a pass with the same signature has been here under this volume / transfer
+        // function / window (tbrm_block_lists.cpp) — then nothing is launched for them, and the live-block count may be known
+        plan.lists = block_lists_for_pass(r, p, plan.occ_mode);
+        if (!plan.lists) return TBRM_ERR_OUT_OF_MEMORY;
+        size_t live = 0;
+        const bool live_known = block_lists_count(plan.lists, false, &live);
+        if (live_known) r->f_est_blocks = std::max(r->f_est_blocks, live); // (estimate_scope: the estimate is this state's)
         // what is added stays in the scene: its factors are worth keeping (null: no room). What is removed does not.
         if (cache_on && !(mode == PASS_ADD && b_added < 0.0f)) {
             // sized for what passes under this volume / transfer function / window have needed so far; before the first count
             // has arrived: every block of a small pass (an entry that overflows is dropped and its pass sampled again), half
             // the blocks of a large one (CT-like volumes are mostly air: 512^3 of the benchmark keeps 40 %)
             const size_t unknown = blocks * 2048 * sizeof(float) <= ((size_t) 256 << 20) ? blocks : blocks / 2;
-            const size_t want = r->f_est_blocks ? std::min(blocks, r->f_est_blocks + r->f_est_blocks / 32 + 64) : std::max<size_t>(unknown, 1);
-            if (refill && refill->cap_blocks >= want && refill->table_blocks >= blocks && !refill->pinned) {
+            const size_t want = live_known ? std::max<size_t>(live, 1)
+                                           : (r->f_est_blocks ? std::min(blocks, r->f_est_blocks + r->f_est_blocks / 32 + 64) : std::max<size_t>(unknown, 1));
+            if (refill && refill->cap_blocks >= want && !refill->pinned) {
                 refill->resolved = refill->valid = refill->enqueued = refill->spent = false;
                 refill->pinned = true;
                 refill->last_use = ++r->kept_clock;
-                *refill->count_host = 0;
+                if (refill->lists) --refill->lists->users;
+                refill->lists = plan.lists;
+                ++plan.lists->users;
                 plan.f_entry[0] = refill;
-            } else plan.f_entry[0] = kept_new(r, key_a, want, blocks);
+            } else plan.f_entry[0] = kept_new(r, key_a, want, plan.lists);
         }
     } else if (int e = ensure_factor_scratch(r, plan.f_buf, blocks, 0)) return e; // (its events order the buffers' reuse)
     if (tune(TUNE_SWEEP_DEBUG) & 4)
@@ -859,8 +851,10 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.sx = sfit.sx; q.sy = sfit.sy; q.hx = sfit.hx; q.hy = sfit.hy;
     q.r_from_records = sfit.two_way ? 1 : 0;
     q.r_sx = sfit.r_sx; q.r_sy = sfit.r_sy; q.r_hx = sfit.r_hx; q.r_hy = sfit.r_hy;
-    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.hx + sfit.hy)) * (size_t) (r->lv_fmt != FMT_U8 && change ? 2 : 1);
-    const size_t words1 = sfit.two_way ? (size_t) D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (sfit.r_hx + sfit.r_hy)) : 0;
+    q.tile_rows = sweep_tile_rows(); // (the sweep's tiles: 32 wide, 16 or 32 high)
+    p.tiles_y = ceil_div(p.H, q.tile_rows);
+    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.hx, sfit.hy, q.tile_rows) * (size_t) (r->lv_fmt != FMT_U8 && change ? 2 : 1);
+    const size_t words1 = sfit.two_way ? (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.r_hx, sfit.r_hy, q.tile_rows) : 0;
     if (words >= ((size_t) 1 << 32) || words1 >= ((size_t) 1 << 32)) return declined("hand-off records too large");
     if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words1)) return e;
     // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
@@ -1093,6 +1087,28 @@ static int wait_for_readers(tbrm_resources* r, uint64_t op)
     return TBRM_OK;
 }
 
+// The block lists of a sweep pass that computes occlusion, unless the handle has them (BlockLists::enqueued): empty-block flags,
+// work list, block ranks, count — on the occlusion stream, in front of the occlusion launch that walks the list. How many
+// blocks a cache entry has to hold is known on the device only: the compaction leaves the count in pinned host memory too
+// (block_lists_count, resolve_entry).
+static int enqueue_block_lists(tbrm_resources* r, const PassPlan& plan)
+{
+    BlockLists* const l = plan.lists;
+    if (!l) return fail(TBRM_ERR_INVALID_ARG, "a pass that computes occlusion has no block lists");
+    if (l->enqueued) return TBRM_OK;
+    ChunkParams p = plan.p;
+    p.occ_flags_out = l->flags;
+    p.occ_list_out = l->list;
+    p.occ_count_out = l->count;
+    p.occ_slot_out = l->slot;
+    p.occ_count_host = l->count_host;
+    HIP_TRY(launch_occ_flags(p, plan.occ_mode, 1, r->occ_stream));
+    HIP_TRY(hipEventRecord(l->ev_done, r->occ_stream));
+    l->enqueued = true;
+    ++r->lists_launches;
+    return TBRM_OK;
+}
+
 // The occlusion of a sweep pass (plan_pass_sweep): the whole pass's empty-block flags, work list and block ranks, then one
 // launch that leaves the factors of the live blocks block-compact in the cache entry being filled and / or the scratch
 // buffer — all on the occlusion stream, beside whatever the handle's stream is running (the sweep of the pass before, a
@@ -1111,20 +1127,12 @@ int enqueue_sweep_occlusion(tbrm_resources* r, const PassPlan& plan)
         if (int e2 = wait_for_readers(r, op)) return e2;
     }
     ChunkParams p = plan.p;
-    p.occ_flags_out = f.flags;
-    p.occ_list_out = f.list;
-    p.occ_count_out = f.count;
-    p.occ_slot_out = e ? e->slot : f.slot;
-    // how many blocks the entry has to hold is known on the device only (resolve_entry): the compaction leaves the count in the
-    // entry's pinned host word too
-    p.occ_count_host = e ? e->count_host : nullptr;
-    HIP_TRY(launch_occ_flags(p, plan.occ_mode, 1, s));
-    if (e) HIP_TRY(hipEventRecord(e->ev_count, s));
+    if (int e2 = enqueue_block_lists(r, plan)) return e2;
     p.j0 = plan.start;
     p.n_steps = plan.D;
     p.occ_flags = nullptr;
-    p.occ_list = f.list;
-    p.occ_count = f.count;
+    p.occ_list = plan.lists->list;
+    p.occ_count = plan.lists->count;
     // an ordinary grid, one workgroup per live block: beside a sweep (nine waves and a third of the LDS per CU) the dispatcher
     // fills what is free; the resident grids that pay beside the chunked chain (occ_overlap) only slow this pair down
     // (measured: cached Change 1.48 ms, 1.58 - 1.68 with 4 - 8 resident workgroups per CU)
@@ -1187,16 +1195,10 @@ int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& pa, const PassPlan
     pc.roi_by1 = pc.occ_blocks_y;
     pc.compact = 1;
     const size_t units = (size_t) pc.occ_groups * pc.occ_blocks_y * pc.occ_blocks_x;
-    if (units > r->dual_units) {
-        drain_streams(r);
-        (void) hipFree(r->dual_flags); (void) hipFree(r->dual_list); (void) hipFree(r->dual_count);
-        r->dual_flags = nullptr; r->dual_list = nullptr; r->dual_count = nullptr;
-        r->dual_units = 0;
-        HIP_TRY(hipMalloc((void**) &r->dual_flags, units));
-        HIP_TRY(hipMalloc((void**) &r->dual_list, units * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**) &r->dual_count, 16 * sizeof(int)));
-        r->dual_units = units;
-    }
+    if (!pa.lists || !pb.lists) return fail(TBRM_ERR_INVALID_ARG, "a pass that computes occlusion has no block lists");
+    // the work units' flags and list: a function of the two passes' lists — the handle's, if this pair has been here
+    BlockLists* const ul = block_lists_for_dual(r, pa.lists, pb.lists, units);
+    if (!ul) return TBRM_ERR_OUT_OF_MEMORY;
     DualOcc d{};
     d.on = 1;
     // the buffers about to be overwritten may still be read by earlier sweeps
@@ -1210,14 +1212,7 @@ int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& pa, const PassPlan
         const PassPlan& plan = *plans[k];
         FactorScratch& f = r->f_scratch[plan.f_buf];
         FactorEntry* const e = plan.f_hit[0] ? nullptr : plan.f_entry[0];
-        ChunkParams p = plan.p;
-        p.occ_flags_out = f.flags;
-        p.occ_list_out = f.list;
-        p.occ_count_out = f.count;
-        p.occ_slot_out = e ? e->slot : f.slot;
-        p.occ_count_host = e ? e->count_host : nullptr;
-        HIP_TRY(launch_occ_flags(p, plan.occ_mode, 1, s));
-        if (e) HIP_TRY(hipEventRecord(e->ev_count, s));
+        if (int e2 = enqueue_block_lists(r, plan)) return e2;
         DualPass& P = d.pass[k];
         P.axis = plan.p.axis; P.start = plan.start; P.dir = plan.dir;
         P.blocks_x = plan.p.occ_blocks_x; P.blocks_y = plan.p.occ_blocks_y;
@@ -1228,18 +1223,22 @@ int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& pa, const PassPlan
         P.fs_keep[1] = nullptr;
         P.fs_cap[1] = 0;
         P.fs_spill[1] = f.store[1];
-        P.fs_slot = p.occ_slot_out;
-        P.flags = f.flags;
+        P.fs_slot = plan.lists->slot;
+        P.flags = plan.lists->flags;
     }
-    pc.occ_flags_out = r->dual_flags;
-    pc.occ_list_out = r->dual_list;
-    pc.occ_count_out = r->dual_count;
-    pc.occ_slot_out = nullptr;
-    pc.occ_count_host = nullptr;
-    HIP_TRY(launch_unit_flags(pc, d, s));
+    if (!ul->enqueued) {
+        pc.occ_flags_out = ul->flags;
+        pc.occ_list_out = ul->list;
+        pc.occ_count_out = ul->count;
+        pc.occ_slot_out = nullptr;
+        pc.occ_count_host = nullptr;
+        HIP_TRY(launch_unit_flags(pc, d, s));
+        ul->enqueued = true;
+        ++r->lists_launches;
+    }
     pc.occ_flags = nullptr;
-    pc.occ_list = r->dual_list;
-    pc.occ_count = r->dual_count;
+    pc.occ_list = ul->list;
+    pc.occ_count = ul->count;
     pc.occ_grid_cap = 0;
     HIP_TRY(launch_light_occlusion(pc, pa.occ_mode, s, &d));
     ++r->dual_launches;
@@ -1278,14 +1277,14 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
         FactorEntry* const e = plan.f_entry[si];
         ChunkStream& st = *streams[si];
         if (plan.f_hit[si]) { // every live block is in the entry
-            st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->slot;
+            st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->lists->slot;
         } else { // computed by this pass: stream a into its entry (if it has one) and the scratch, stream r into the scratch,
                  // both under the ranks of the jointly computed work list
             FactorEntry* const filled = plan.f_entry[0];
             st.fs_keep = (si == 0 && filled) ? filled->base : nullptr;
             st.fs_cap = (si == 0 && filled) ? (uint32_t) filled->cap_blocks : 0u;
             st.fs_spill = f.store[si];
-            st.fs_slot = filled ? filled->slot : f.slot;
+            st.fs_slot = plan.lists->slot;
         }
     }
     SweepParams q = plan.sq;
@@ -1378,18 +1377,18 @@ static int enqueue_sweep_pair(tbrm_resources* r, const PassPlan& pa, const PassP
         FactorScratch& f = r->f_scratch[plan.f_buf];
         FactorEntry* const e = plan.f_entry[0];
         ChunkStream& st = *streams[si];
-        if (plan.f_hit[0]) { st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->slot; }
+        if (plan.f_hit[0]) { st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->lists->slot; }
         else {
             st.fs_keep = e ? e->base : nullptr;
             st.fs_cap = e ? (uint32_t) e->cap_blocks : 0u;
             st.fs_spill = f.store[0];
-            st.fs_slot = e ? e->slot : f.slot;
+            st.fs_slot = plan.lists->slot;
         }
     }
     SweepParams q = pa.sq;
     q.sx = fit.sx; q.sy = fit.sy; q.hx = fit.hx; q.hy = fit.hy;
     q.r_from_records = 0;
-    const size_t words = (size_t) pa.D * p.tiles_x * p.tiles_y * (size_t) (kChunkTile * (fit.hx + fit.hy));
+    const size_t words = (size_t) pa.D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(fit.hx, fit.hy, q.tile_rows);
     if (words >= ((size_t) 1 << 32)) return fail(TBRM_ERR_UNSUPPORTED, "hand-off records too large");
     if (int e = ensure_sweep(r, std::max<size_t>(words, 1), 0)) return e;
     q.rec[0] = r->sweep_rec[0];

@@ -41,6 +41,7 @@
 // runs downwards: then the last of them hands the pass's initial plane on (SweepParams::reinit_slice).
 #include "tbrm_device_sampling.h"
 #include "tbrm_light_chain.h"
+#include "tbrm_light_sweep.h"
 
 #include <type_traits>
 #include <utility>
@@ -52,48 +53,6 @@
 #endif
 
 namespace tbrm {
-
-constexpr int kSweepTile = 32;
-// LDS plane: 48 x 48 cells (tile + halo <= 14 + guard ring), COLUMN-major — a pixel's two taps of one column (rows iy, iy + 1)
-// are neighbours in memory and arrive as one register pair, ready for a packed lerp along x over (top, bottom) — with a
-// column stride of 49 floats: the 32 columns of a wave's lanes fall into 32 different banks
-constexpr int kSweepCols = 48, kSweepCS = 49;
-constexpr int kSweepPlane = kSweepCols * kSweepCS;
-constexpr int kSweepLvBrick = 528;                     // bytes per staged light-volume brick: 512 + 16, so that the four bricks
-                                                       // under a tile row start 4 banks apart
-constexpr int kSweepRing = 8;                          // register ring of requested hand-off words (slices)
-constexpr int kSweepComputeWaves = 8;
-// + the hand-off wave + one factor loader per stream (an LDS-DMA costs its wave 60 - 180 cycles of issue: the eight of a
-// two-stream slice in one wave took longer than the slice)
-constexpr bool sweep_two_streams(int mode) { return mode == PASS_CHANGE || mode == PASS_ADD2; }
-#ifndef TBRM_SWEEP_HANDOFF_WAVES
-#define TBRM_SWEEP_HANDOFF_WAVES 2
-#endif
-// Hand-off waves per tile: 1 = one wave publishes, consumes and requests; 2 = a publisher and a consumer (each slice's
-// chain of LDS read -> convert -> store and of load -> decode -> LDS write then run side by side instead of one after the other)
-constexpr int kSweepHandoffWaves = TBRM_SWEEP_HANDOFF_WAVES;
-constexpr int sweep_threads(int mode) { return (kSweepComputeWaves + kSweepHandoffWaves + (sweep_two_streams(mode) ? 2 : 1)) * 64; }
-constexpr int kSweepFlagGroups = 128;                  // slice groups of a span (1024 slices)
-constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x 16 block slice of occlusion factors: the four
-                                                       // blocks under a tile start 16 banks apart (a lane pair's columns c, c + 16)
-
-// slots of the LDS ring of factor slices; the loader runs one less ahead. One-stream slices are short: 8; a two-stream pass
-// leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
-constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? 4 : 8; }
-
-size_t sweep_lds_bytes(int mode, int slices, int lv_fmt)
-{
-    const int ns = sweep_two_streams(mode) ? 2 : 1;
-    const int groups = (slices + 7) / 8; // (the rank table is as long as the pass: every KiB not taken is the occlusion workgroups')
-    // planes, three brick layers (UNORM8 light volumes: a float light volume is updated in place), block ranks, the ring of factor slices
-    return (size_t) 2 * ns * kSweepPlane * 4 + (lv_fmt == FMT_U8 ? 3 * 16 * kSweepLvBrick : 0) + (size_t) ns * 4 * groups * 4 +
-           (size_t) sweep_factor_slots(mode) * ns * 4 * kSweepFBlock * 4;
-}
-
-int sweep_max_slices() { return 8 * kSweepFlagGroups; }
-
-// hand-off words a tile reads per slice and stream, in chunks of 64 (one per lane of the hand-off wave)
-int sweep_halo_chunks(int hx, int hy) { return (32 * hx + 32 * hy + hx * hy + 63) / 64; }
 
 template <class F, int... S>
 __device__ __forceinline__ void sweep_each_const(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
@@ -119,6 +78,14 @@ __device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch,
     return w;
 }
 
+#ifndef TBRM_SWEEP_DMA_NT
+#define TBRM_SWEEP_DMA_NT 0
+#endif
+#if TBRM_SWEEP_DMA_NT
+#define TBRM_SWEEP_DMA_POLICY " nt"
+#else
+#define TBRM_SWEEP_DMA_POLICY ""
+#endif
 // One block slice of occlusion factors (64 lanes x 16 bytes = the 256 floats of a 16 x 16 block) from global memory straight
 // into LDS at `lds_dst` (wave-uniform byte address) + lane * 16: no registers, counted by vmcnt like any load — but invisible
 // to the compiler's own wait-count bookkeeping, which is the point: the loader waits with sweep_wait_loads<N>() for exactly
@@ -126,7 +93,7 @@ __device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch,
 __device__ __forceinline__ void sweep_dma_block(const void* src, uint32_t lds_dst)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" TBRM_SWEEP_DMA_POLICY "\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void sweep_wait_loads() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -165,13 +132,15 @@ __device__ __forceinline__ v2f quantize2_unfloored(v2f x) // (>= 0.5: the conver
 // stream; the records are filled with kSweepNoWord before the launch instead of being tagged), and the light volume is updated
 // in place — fire-and-forget fp32 atomic adds, the removed light's as a second add of -L: (LV + La) - Lr rounds twice, like the
 // reference's expression (ChangeDirLightShader.usf:152-154).
-template <int MODE, int AXIS, int PF, int HC, bool RREC = false, int LFMT = FMT_U8>
-__global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const ChunkParams p, const SweepParams q)
+template <int MODE, int AXIS, int PF, int HC, bool RREC, int LFMT, int TH>
+__global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 : 1) void k_light_sweep(const ChunkParams p, const SweepParams q)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_ticket;
-    constexpr int T = kSweepTile, CS = kSweepCS, PLANE = kSweepPlane, LVB = kSweepLvBrick;
-    constexpr int R = 2, NWC = kSweepComputeWaves, NTC = NWC * 64, NT = sweep_threads(MODE);
+    static_assert(TH == 32 || TH == 16, "a tile is 32 x 32 or 32 x 16 pixels");
+    constexpr int T = kSweepTile, CS = sweep_col_stride(TH), PLANE = sweep_plane(TH), LVB = kSweepLvBrick;
+    constexpr int R = 2, NWC = sweep_compute_waves(TH), NTC = NWC * 64, NT = sweep_threads(MODE, TH);
+    constexpr int NB = sweep_blocks(TH), NBR = sweep_bricks(TH);
     constexpr int NS = sweep_two_streams(MODE) ? 2 : 1;
     constexpr bool LV = MODE != PASS_PLANES; // the light volume is updated
     constexpr bool F32 = LFMT == FMT_F32;
@@ -191,7 +160,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     const int ui = ticket % p.tiles_x, uj = ticket / p.tiles_x;
     const int tile_x = q.sx > 0 ? p.tiles_x - 1 - ui : ui, tile_y = q.sy > 0 ? p.tiles_y - 1 - uj : uj;
     const int tile_lin = tile_y * p.tiles_x + tile_x;
-    const int base_x = tile_x * T, base_y = tile_y * T;
+    const int base_x = tile_x * T, base_y = tile_y * TH;
     const int n = p.n_steps, G = n >> 3; // whole brick layers (the launcher's check)
     const int hx = q.hx, hy = q.hy;
     // LDS plane coordinates of tile pixel (0, 0): behind the guard ring and whatever halo lies on the low side
@@ -204,11 +173,11 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     float* const lds = (float*) smem;
     auto plane = [&](int buf, int si) -> float* { return lds + (buf * NS + si) * PLANE; };
     uint8_t* const lvt = (uint8_t*) (lds + 2 * NS * PLANE);
-    int32_t* const sslot = (int32_t*) (lvt + (F32 ? 0 : 3 * 16 * LVB)); // [si][2 x 2 blocks][slice group]: rank of the block, < 0: flagged empty
+    int32_t* const sslot = (int32_t*) (lvt + (F32 ? 0 : 3 * NBR * LVB)); // [si][2 x TH / 16 blocks][slice group]: rank of the block, < 0: flagged empty
     // the ring of factor slices, [slot][si][2 x 2 blocks][kSweepFBlock]: filled FS - 1 slices ahead by the loader wave
-    float* const fring = (float*) (sslot + NS * 4 * G);
+    float* const fring = (float*) (sslot + NS * NB * G);
     constexpr int FS = sweep_factor_slots(MODE); // (divides the loop's eight slices: a slice's slot is a constant)
-    constexpr int kFSlot = NS * 4 * kSweepFBlock; // floats per slot
+    constexpr int kFSlot = NS * NB * kSweepFBlock; // floats per slot
     auto stream = [&](int si) -> const ChunkStream& { return si == 0 ? p.a : p.r; };
 
     // ---- the planes before the span's first slice ------------------------------------------------------------------------
@@ -227,15 +196,15 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         }
     }
     // the tile's 2 x 2 occlusion blocks in every slice group of the span: their ranks among the pass's live blocks
-    for (int i = threadIdx.x; i < NS * 4 * G; i += NT) {
-        const int si = i / (4 * G), blk = (i / G) & 3, zg = i % G;
+    for (int i = threadIdx.x; i < NS * NB * G; i += NT) {
+        const int si = i / (NB * G), blk = (i / G) % NB, zg = i % G;
         const int bx = (base_x >> 4) + (blk & 1), by = (base_y >> 4) + (blk >> 1);
         int32_t slot = -1;
         if (zg < G && bx < p.occ_blocks_x && by < p.occ_blocks_y) slot = stream(si).fs_slot[((size_t) zg * p.occ_blocks_y + by) * p.occ_blocks_x + bx];
         sslot[i] = slot;
     }
 
-    // ---- light-volume bricks: a layer = the 4 x 4 bricks under the tile, 512 pieces of 16 bytes, one per compute thread ----
+    // ---- light-volume bricks: a layer = the 4 x TH / 8 bricks under the tile, in pieces of 16 bytes, one per compute thread ----
     constexpr int dim_u = AXIS == 0 ? 1 : 0, dim_v = AXIS == 2 ? 1 : 2, dim_s = AXIS; // plane axes -> volume axes
     const int lbn[3] = {p.lv_bnx, p.lv_bnxy / p.lv_bnx, (p.lv_dims[2] + 7) >> 3};
     const int piece = (int) threadIdx.x & (NTC - 1);
@@ -253,7 +222,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         layer_stride = (uint32_t) ((l3[2] * lbn[1] + l3[1]) * lbn[0] + l3[0]) * 512u;
     }
     uint4* const piece_lds = (uint4*) (lvt + (piece >> 5) * LVB + (piece & 31) * 16); // in buffer 0
-    constexpr int kLvBuf = 16 * LVB;
+    constexpr int kLvBuf = NBR * LVB;
     auto layer_of = [&](int g) -> int { return down ? layer0 - g : layer0 + g; };
     // (a layer past the span's end is loaded from the span's last layer instead and never used: no branch around the load)
     auto load_layer = [&](int g) -> uint4 { return *(const uint4*) ((const uint8_t*) p.light + (piece_off + (uint32_t) layer_of(min(g, G - 1)) * layer_stride)); };
@@ -267,7 +236,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     }
 
     const uint32_t epoch = q.epoch & 0xffffu, tag = epoch << 16;
-    const int RW = T * (hx + hy), RWS = RW * NSW;
+    const int RW = TH * hx + T * hy, RWS = RW * NSW;
     const uint32_t rec_slice = (uint32_t) (n_tiles * RWS); // words per slice
     __syncthreads(); // planes, flags and the first brick layer are in LDS
     // Staggered start (SweepParams::stagger_ns): the tile's lag behind its upstream neighbours, taken up front
@@ -286,7 +255,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         // =================================================== the hand-off wave(s) ================================================
         // A tile publishes E_x = its hx columns and E_y = its hy rows on the side AWAY from the light, words [row][column of
         // E_x] then [row of E_y][column]; its halo is the same cells of the three upstream neighbours.
-        const int e0x = q.sx > 0 ? 0 : T - hx, e0y = q.sy > 0 ? 0 : T - hy;
+        const int e0x = q.sx > 0 ? 0 : T - hx, e0y = q.sy > 0 ? 0 : TH - hy;
         int pub_cell[HC];      // LDS cell of the word this lane publishes (chunk h: word 64 h + lane), < 0: none
         bool hal_on[HC];       // this lane fetches halo word 64 h + lane
         int hal_dst[HC];
@@ -297,20 +266,20 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
             {
                 int cx = 0, cy = 0;
                 const bool on = w < RW;
-                if (w < T * hx) { cy = w / max(hx, 1); cx = e0x + (w - cy * hx); }
-                else { const int m = w - T * hx; cy = e0y + m / T; cx = m % T; }
+                if (w < TH * hx) { cy = w / max(hx, 1); cx = e0x + (w - cy * hx); }
+                else { const int m = w - TH * hx; cy = e0y + m / T; cx = m % T; }
                 pub_cell[h] = on ? (ox + cx) * CS + oy + cy : -1;
             }
-            const int nx = T * hx, ny = T * hy, nc = hx * hy;
+            const int nx = TH * hx, ny = T * hy, nc = hx * hy;
             int ntx = tile_x, nty = tile_y, word = 0, cxh = 0, cyh = 0; // neighbour tile, its word, the halo cell in tile coordinates
             bool on = false;
             if (w < nx) { const int row = w / max(hx, 1), kx = w - row * hx; ntx += q.sx; word = row * hx + kx; cxh = (q.sx > 0 ? T : -hx) + kx; cyh = row; on = true; }
-            else if (w < nx + ny) { const int m = w - nx, ky = m / T, col = m - ky * T; nty += q.sy; word = nx + ky * T + col; cxh = col; cyh = (q.sy > 0 ? T : -hy) + ky; on = true; }
+            else if (w < nx + ny) { const int m = w - nx, ky = m / T, col = m - ky * T; nty += q.sy; word = nx + ky * T + col; cxh = col; cyh = (q.sy > 0 ? TH : -hy) + ky; on = true; }
             else if (w < nx + ny + nc) {
                 const int m = w - nx - ny, ky = m / max(hx, 1), kx = m - ky * hx;
                 ntx += q.sx; nty += q.sy;
                 word = (e0y + ky) * hx + kx;
-                cxh = (q.sx > 0 ? T : -hx) + kx; cyh = (q.sy > 0 ? T : -hy) + ky;
+                cxh = (q.sx > 0 ? T : -hx) + kx; cyh = (q.sy > 0 ? TH : -hy) + ky;
                 on = true;
             }
             // (a neighbour's pixels beyond the buffer are not handed over: their cells hold the border colour from the start)
@@ -326,24 +295,24 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         bool rh_on[HC];
         int rh_dst[HC];
         uint32_t rh_src[HC];
-        const int r_RW = T * (q.r_hx + q.r_hy);
+        const int r_RW = TH * q.r_hx + T * q.r_hy;
         const uint32_t r_rec_slice = (uint32_t) (n_tiles * r_RW);
         if constexpr (RREC) {
             const int rhx = q.r_hx, rhy = q.r_hy;
-            const int re0y = q.r_sy > 0 ? 0 : T - rhy;
+            const int re0y = q.r_sy > 0 ? 0 : TH - rhy;
 #pragma unroll
             for (int h = 0; h < HC; ++h) {
                 const int w = h * 64 + lane;
-                const int nx = T * rhx, ny = T * rhy, nc = rhx * rhy;
+                const int nx = TH * rhx, ny = T * rhy, nc = rhx * rhy;
                 int ntx = tile_x, nty = tile_y, word = 0, cxh = 0, cyh = 0;
                 bool on = false;
                 if (w < nx) { const int row = w / max(rhx, 1), kx = w - row * rhx; ntx += q.r_sx; word = row * rhx + kx; cxh = (q.r_sx > 0 ? T : -rhx) + kx; cyh = row; on = true; }
-                else if (w < nx + ny) { const int m = w - nx, ky = m / T, col = m - ky * T; nty += q.r_sy; word = nx + ky * T + col; cxh = col; cyh = (q.r_sy > 0 ? T : -rhy) + ky; on = true; }
+                else if (w < nx + ny) { const int m = w - nx, ky = m / T, col = m - ky * T; nty += q.r_sy; word = nx + ky * T + col; cxh = col; cyh = (q.r_sy > 0 ? TH : -rhy) + ky; on = true; }
                 else if (w < nx + ny + nc) {
                     const int m = w - nx - ny, ky = m / max(rhx, 1), kx = m - ky * rhx;
                     ntx += q.r_sx; nty += q.r_sy;
                     word = (re0y + ky) * rhx + kx;
-                    cxh = (q.r_sx > 0 ? T : -rhx) + kx; cyh = (q.r_sy > 0 ? T : -rhy) + ky;
+                    cxh = (q.r_sx > 0 ? T : -rhx) + kx; cyh = (q.r_sy > 0 ? TH : -rhy) + ky;
                     on = true;
                 }
                 on = on && (unsigned) ntx < (unsigned) p.tiles_x && (unsigned) nty < (unsigned) p.tiles_y &&
@@ -457,16 +426,16 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
         // slices ahead of the compute waves; per slice the wave waits until the NEXT slice's 4 loads have landed, then joins
         // the barrier behind which that slice is read. (Past the last slice the last one is requested again, into slots already
         // consumed: the count of loads in flight stays what the waits assume.)
-        constexpr int L = 4; // loads per slice
+        constexpr int L = NB; // loads per slice
         constexpr int A = FS - 1;
         const int lsi = NS > 1 ? wave - (NWC + HW) : 0;
         const ChunkStream& st = stream(lsi);
-        const int32_t* const ranks = sslot + lsi * 4 * G;
-        const uint8_t* src[4]; // of the slice requested next
-        uint32_t step[4];
+        const int32_t* const ranks = sslot + lsi * NB * G;
+        const uint8_t* src[NB]; // of the slice requested next
+        uint32_t step[NB];
         auto rebase = [&](int zg) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const int32_t slot = ranks[b * G + zg];
                 const bool one = slot < 0;
                 const float* const base = one ? p.ones : ((uint32_t) slot < st.fs_cap ? st.fs_keep + (size_t) (uint32_t) slot * 2048 : st.fs_spill + (size_t) ((uint32_t) slot - st.fs_cap) * 2048);
@@ -474,14 +443,14 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 step[b] = one ? 0u : 1024u;
             }
         };
-        const uint32_t ring_lds = (uint32_t) (uintptr_t) fring + (uint32_t) (lsi * 4 * kSweepFBlock * 4); // (a flat LDS address: its low half is the LDS byte address)
+        const uint32_t ring_lds = (uint32_t) (uintptr_t) fring + (uint32_t) (lsi * NB * kSweepFBlock * 4); // (a flat LDS address: its low half is the LDS byte address)
         int req = 0;       // slice requested next
         int req_slot = 0;  // its ring slot
         auto request = [&]() {
             if constexpr (!(TBRM_SWEEP_EXP & 2)) {
                 const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t) req_slot * (uint32_t) (kFSlot * 4));
 #pragma unroll
-                for (int b = 0; b < 4; ++b) sweep_dma_block(src[b], dst + (uint32_t) (b * kSweepFBlock * 4));
+                for (int b = 0; b < NB; ++b) sweep_dma_block(src[b], dst + (uint32_t) (b * kSweepFBlock * 4));
             }
             req_slot = req_slot + 1 == FS ? 0 : req_slot + 1;
             if (req + 1 < n) {
@@ -489,7 +458,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
                 if ((req & 7) == 0) rebase(req >> 3);
                 else {
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) src[b] += step[b];
+                    for (int b = 0; b < NB; ++b) src[b] += step[b];
                 }
             }
         };
@@ -666,7 +635,7 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
                     if constexpr (TBRM_SWEEP_EXP & 2) fac[si] = (v2f) 1.0f;
-                    else { fac[si].x = f_at[si * 4 * kSweepFBlock]; fac[si].y = f_at[si * 4 * kSweepFBlock + 16]; }
+                    else { fac[si].x = f_at[si * NB * kSweepFBlock]; fac[si].y = f_at[si * NB * kSweepFBlock + 16]; }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const float* const pt = plane(CUR, si) + tap[si][k];
@@ -773,69 +742,66 @@ __global__ __launch_bounds__(sweep_threads(MODE)) void k_light_sweep(const Chunk
     }
 }
 
-template <int MODE, int AXIS, int PF, int HC, bool RREC = false, int LFMT = FMT_U8>
+template <int MODE, int AXIS, int PF, int HC, int TH, bool RREC = false, int LFMT = FMT_U8>
 static hipError_t launch_sweep5(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     static std::atomic<uint64_t> attr_done{0};
-    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC, LFMT>, attr_done, 159 * 1024); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC, LFMT>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE)), sweep_lds_bytes(MODE, p.n_steps, LFMT), s, p, q);
+    if (const hipError_t e = allow_big_lds(k_light_sweep<MODE, AXIS, PF, HC, RREC, LFMT, TH>, attr_done, 159 * 1024); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_light_sweep<MODE, AXIS, PF, HC, RREC, LFMT, TH>), dim3(p.tiles_x * p.tiles_y), dim3(sweep_threads(MODE, TH)), sweep_lds_bytes(MODE, p.n_steps, LFMT, TH), s, p, q);
     return hipGetLastError();
 }
-template <int MODE, int AXIS, int PF>
+// Requests run two slices ahead of their use (three for the six-chunk records, whose ring of three slices is what fits the
+// registers): distances 3, 4 and 6 lost to 2 in every measurement of rounds 3 and 4 and are not instantiated.
+template <int MODE, int AXIS, int TH>
 static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
-    const int hc = sweep_halo_chunks(q.hx, q.hy);
+    const int hc = sweep_halo_chunks(q.hx, q.hy, TH);
     if (q.lv_f32) { // float light volumes: Add and fused Change, up to three words per lane and stream (sweep_fit)
         if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE) {
             if (q.r_from_records) return hipErrorInvalidConfiguration;
-            if (hc <= 2) return launch_sweep5<MODE, AXIS, PF, 2, false, FMT_F32>(p, q, s);
-            if (hc <= 3) return launch_sweep5<MODE, AXIS, PF, 3, false, FMT_F32>(p, q, s);
+            if (hc <= 2) return launch_sweep5<MODE, AXIS, 2, 2, TH, false, FMT_F32>(p, q, s);
+            if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH, false, FMT_F32>(p, q, s);
         }
         return hipErrorInvalidConfiguration;
     }
 #if TBRM_SWEEP_EXP
-    if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3>(p, q, s);
+    if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH>(p, q, s);
     return hipErrorInvalidConfiguration;
 #endif
     if constexpr (MODE == PASS_CHANGE) {
         if (q.r_from_records) { // (sweep_fit: both streams' words fit three per lane)
-            const int hc2 = std::max(hc, sweep_halo_chunks(q.r_hx, q.r_hy));
-            if (hc2 <= 3) return launch_sweep5<MODE, AXIS, 2, 3, true>(p, q, s);
-            if (hc2 <= 6) return launch_sweep5<MODE, AXIS, 3, 6, true>(p, q, s);
+            const int hc2 = std::max(hc, sweep_halo_chunks(q.r_hx, q.r_hy, TH));
+            if (hc2 <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH, true>(p, q, s);
+            if (hc2 <= 6) return launch_sweep5<MODE, AXIS, 3, 6, TH, true>(p, q, s);
             return hipErrorInvalidConfiguration;
         }
     }
-    if (hc <= 2) return launch_sweep5<MODE, AXIS, PF, 2>(p, q, s);
-    if (hc <= 3) return launch_sweep5<MODE, AXIS, PF, 3>(p, q, s);
-    if (hc <= 6) return launch_sweep5<MODE, AXIS, 3, 6>(p, q, s); // (six words per lane and stream: a ring of three slices is what fits the registers)
+    if constexpr (TH == 16) { // (a 32 x 16 tile with a reach of one texel hands 49 words on: one per lane)
+        if (hc <= 1) return launch_sweep5<MODE, AXIS, 2, 1, TH>(p, q, s);
+    }
+    if (hc <= 2) return launch_sweep5<MODE, AXIS, 2, 2, TH>(p, q, s);
+    if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH>(p, q, s);
+    if (hc <= 6) return launch_sweep5<MODE, AXIS, 3, 6, TH>(p, q, s); // (six words per lane and stream: a ring of three slices is what fits the registers)
     return hipErrorInvalidConfiguration; // (sweep_fit rules these out)
 }
-template <int MODE, int AXIS>
-static hipError_t launch_sweep3(const ChunkParams& p, const SweepParams& q, hipStream_t s)
+template <int MODE, int TH>
+hipError_t launch_sweep_unit(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
-    // (distances 4 and 6 lost to 2 and 3 in every measurement: not instantiated any more)
-    if (q.prefetch <= 2) return launch_sweep4<MODE, AXIS, 2>(p, q, s);
-    return launch_sweep4<MODE, AXIS, 3>(p, q, s);
+    return p.axis == 0 ? launch_sweep4<MODE, 0, TH>(p, q, s) : (p.axis == 1 ? launch_sweep4<MODE, 1, TH>(p, q, s) : launch_sweep4<MODE, 2, TH>(p, q, s));
 }
-template <int MODE>
-static hipError_t launch_sweep2(const ChunkParams& p, const SweepParams& q, hipStream_t s)
-{
-    return p.axis == 0 ? launch_sweep3<MODE, 0>(p, q, s) : (p.axis == 1 ? launch_sweep3<MODE, 1>(p, q, s) : launch_sweep3<MODE, 2>(p, q, s));
-}
-// advances every tile through the span (j0, n_steps) in one launch; mode PASS_ADD or PASS_CHANGE, UNORM8 light volume, the
-// span whole brick layers of the light volume, the occlusion factors handed over block-compact
-hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s)
-{
-    if (p.n_steps <= 0 || p.tiles_x <= 0 || p.tiles_y <= 0) return hipSuccess;
-    const bool aligned = (p.n_steps & 7) == 0 && (p.j0 & 7) == (p.dir > 0 ? 0 : 7) && p.occ_phase == 0 && p.n_steps <= 8 * kSweepFlagGroups;
-    if (!aligned || !p.compact || !p.ones || !p.a.fs_slot || (sweep_two_streams(mode) && !p.r.fs_slot)) return hipErrorInvalidConfiguration;
-    if (q.r_from_records && (mode != PASS_CHANGE || !q.rec[1])) return hipErrorInvalidConfiguration;
-    if (q.reinit_slice < 0 || q.reinit_slice > 7 || (q.reinit_slice > 0 && p.n_steps < 16)) return hipErrorInvalidConfiguration;
-    if (mode == PASS_ADD) return launch_sweep2<PASS_ADD>(p, q, s);
-    if (mode == PASS_CHANGE) return launch_sweep2<PASS_CHANGE>(p, q, s);
-    if (mode == PASS_ADD2) return launch_sweep2<PASS_ADD2>(p, q, s);
-    if (mode == PASS_PLANES) return launch_sweep2<PASS_PLANES>(p, q, s);
-    return hipErrorInvalidConfiguration;
-}
+
+#ifdef TBRM_SWEEP_UNIT_MODE
+template hipError_t launch_sweep_unit<TBRM_SWEEP_UNIT_MODE, TBRM_SWEEP_UNIT_TH>(const ChunkParams&, const SweepParams&, hipStream_t);
+#else
+// (no unit named: every mode and tile height in this one translation unit — what a plain `hipcc -c` of this file builds)
+template hipError_t launch_sweep_unit<PASS_ADD, 32>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_CHANGE, 32>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_ADD2, 32>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_PLANES, 32>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_ADD, 16>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_CHANGE, 16>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_ADD2, 16>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_unit<PASS_PLANES, 16>(const ChunkParams&, const SweepParams&, hipStream_t);
+#endif
 
 } // namespace tbrm

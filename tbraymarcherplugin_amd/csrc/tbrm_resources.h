@@ -60,13 +60,34 @@ struct FactorKey {
     int32_t clip_mode, axis, dir, start, D, W, H, guard;
     float uvw_off[3], step100;
 };
+// The block lists of a pass (tbrm_block_lists.cpp): which of its 16 x 16 x 8 occlusion blocks can see anything but empty bricks
+// (k_occ_flags), the ascending list of those that can and every block's rank in it (k_occ_compact), the count — or the same for
+// the work units of a dual occlusion launch (k_unit_flags). They depend on the skipping metadata (volume, transfer function,
+// window: tbrm_resources::empty_gen) and on the light only through the integer range of data texels a block's samples touch,
+// which a light that turns by a few degrees does not change: computed once per `sig`, kept with the handle, never rewritten
+// (a later pass with the same signature launches nothing), freed when the metadata they were computed from is gone.
+struct BlockLists {
+    std::vector<int32_t> sig;       // block_lists_signature: everything k_occ_flags reads but the emptiness bits
+    uint64_t empty_gen = 0;         // tbrm_resources::empty_gen they were computed under
+    uint8_t* flags = nullptr;       // [slice group][block y][block x], 1 = nothing to compute
+    uint32_t* list = nullptr;       // the live blocks, ascending
+    int32_t* slot = nullptr;        // rank of every block in `list`, -1 for the flagged ones (null: units of a dual launch)
+    int* count = nullptr;           // device: live blocks
+    int* count_host = nullptr;      // pinned: the same, written by k_occ_compact
+    hipEvent_t ev_done = nullptr;   // ... which this event follows (occlusion stream)
+    size_t blocks = 0, cap = 0;     // blocks of the pass; what the buffers hold
+    bool enqueued = false;          // its kernels are on the occlusion stream
+    uint64_t id = 0;                // never reused within a handle
+    uint64_t a_id = 0, b_id = 0;    // units of a dual launch: the two passes' lists (0: a pass's own lists)
+    int users = 0;                  // factor cache entries whose ranks these are
+    uint64_t last_use = 0;
+    size_t bytes() const { return blocks * (sizeof(uint8_t) + sizeof(uint32_t) + (slot ? sizeof(int32_t) : 0)); }
+};
+
 struct FactorEntry {
     float* base = nullptr;          // cap_blocks x 2048 floats
     size_t cap_blocks = 0;
-    int32_t* slot = nullptr;        // rank of every block of the pass (device), table_blocks entries
-    size_t table_blocks = 0;
-    int* count_host = nullptr;      // pinned: live blocks of the pass, written by a copy behind k_occ_compact
-    hipEvent_t ev_count = nullptr;  // ... which this event follows (occlusion stream)
+    BlockLists* lists = nullptr;    // the ranks its blocks are stored under (borrowed: BlockLists::users)
     hipEvent_t ev_filled = nullptr; // the occlusion that fills the entry is done (occlusion stream)
     hipEvent_t ev_idle = nullptr;   // the last sweep that reads the entry is done (the handle's stream)
     bool read_yet = false;          // (ev_idle has been recorded)
@@ -79,19 +100,14 @@ struct FactorEntry {
     bool pinned = false;            // in use by the operator being planned
     bool spent = false;             // its light has left the scene: first in line for reuse
     uint64_t last_use = 0;
-    size_t bytes() const { return cap_blocks * 2048 * sizeof(float) + table_blocks * sizeof(int32_t); }
+    size_t bytes() const { return cap_blocks * 2048 * sizeof(float); }
 };
 
-// Scratch of the block-compact hand-over: per buffer (axis passes alternate between two) the factor stores of the two streams
-// and the pass's block metadata (flags, work list, ranks, count)
+// Scratch of the block-compact hand-over: per buffer (axis passes take four in rotation) the factor stores of the two streams
+// (the pass's block lists — flags, work list, ranks, count — are BlockLists)
 struct FactorScratch {
     float* store[2] = {nullptr, nullptr};
     size_t store_blocks = 0;
-    uint8_t* flags = nullptr;
-    uint32_t* list = nullptr;
-    int32_t* slot = nullptr;
-    int* count = nullptr;
-    size_t meta_blocks = 0;
     hipEvent_t ev_ready = nullptr;  // the occlusion into this buffer is done (occlusion stream)
     hipEvent_t ev_idle = nullptr;   // the sweep that read this buffer is done (the handle's stream)
     bool used = false;              // (ev_idle has been recorded)
@@ -178,12 +194,10 @@ struct tbrm_resources {
     static constexpr int kFScratch = 4;
     FactorScratch f_scratch[kFScratch];
     int f_buf = 0;                 // buffer of the most recent sweep pass
-    // work units of a dual occlusion launch (flags, ascending list of the live ones, their count): written and read on the
-    // occlusion stream only, one launch after the other
-    uint8_t* dual_flags = nullptr;
-    uint32_t* dual_list = nullptr;
-    int* dual_count = nullptr;
-    size_t dual_units = 0;
+    std::vector<BlockLists*> block_lists; // passes' and dual launches' block lists computed so far (tbrm_block_lists.cpp)
+    uint64_t block_lists_serial = 0;
+    uint64_t block_lists_quiet_gen = 0; // lists older than this empty_gen are read by nothing in flight (new_lists)
+    uint64_t lists_launches = 0;   // passes / dual launches whose lists had to be computed (tbrm_path_counters)
     uint64_t dual_launches = 0;    // occlusion launches that served two passes (tbrm_launch_counters)
     float* d_ones = nullptr;       // 1024 floats of 1.0
     uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
@@ -196,6 +210,7 @@ struct tbrm_resources {
     int* d_alpha_prefix = nullptr;
     bool shell_transparent = false; // valid with empty_valid (ensure_skipping): the Add and the Change shader propagate the same L
     bool minmax_valid = false, empty_valid = false;
+    uint64_t empty_gen = 0;        // bumped whenever d_empty is rewritten (ensure_skipping): what BlockLists were computed from
 
     // Octree render mode: 4-level UNORM16 max pyramid (allocated by the first tbrm_generate_octree)
     uint16_t* d_octree[4]{};
@@ -267,6 +282,7 @@ struct PassPlan {
     FactorEntry* f_entry[2] = {nullptr, nullptr};
     bool f_hit[2] = {false, false};
     int occ_mode = -1;
+    BlockLists* lists = nullptr; // occ_mode >= 0: the pass's block lists (found among the handle's, or new: BlockLists::enqueued)
     int f_buf = 0;              // scratch buffer of this pass
     mutable bool occ_enqueued = false;
     // slab-partitioned passes
@@ -305,6 +321,11 @@ bool dual_fit(const PassPlan& a, const PassPlan& b);                    // may O
 int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& a, const PassPlan& b);
 void quiesce_occ_stream(tbrm_resources* r);  // waits for the occlusion stream and forgets what its buffers hold
 void release_kept(tbrm_resources* r);       // frees the factor cache (the streams must be idle)
+// tbrm_block_lists.cpp
+BlockLists* block_lists_for_pass(tbrm_resources* r, const ChunkParams& p, int occ_mode);  // null: allocation failed (tbrm_last_error)
+BlockLists* block_lists_for_dual(tbrm_resources* r, const BlockLists* a, const BlockLists* b, size_t units);
+bool block_lists_count(BlockLists* l, bool wait, size_t* count); // the live-block count, once it has arrived
+void release_block_lists(tbrm_resources* r); // (the streams must be idle)
 void release_occ_stores(tbrm_resources* r); // frees the occlusion stores and the factor cache (the streams must be idle)
 size_t kept_bytes(const tbrm_resources* r);
 int enqueue_add(tbrm_resources* r, const tbrm_dir_light_params& light, bool added, const tbrm_world_params& world);

@@ -28,7 +28,12 @@ def test_gpus_2_relaunches_itself_under_torchrun():
     ranks = run_bench(["--gpus", "2", "--steps", "3"])
     assert sorted(r["rank"] for r in ranks) == [0, 1]
     assert all(r["world_size"] == 2 and r["gpus"] == 2 and r["master_addr"] == "127.0.0.1" for r in ranks)
-    assert all(r["config"] == 5 for r in ranks)  # north_star's scaling workload: one 2048^2 frame over the GPUs
+    assert all(r["config"] == 3 for r in ranks)  # the SAME workload as N = 1: value(N) / value(1) is a speed-up
+
+
+def test_config_5_is_opt_in_at_n_gpus():
+    ranks = run_bench(["--gpus", "2", "--config", "5"])
+    assert all(r["config"] == 5 for r in ranks)  # north_star's tile-scaling workload (one 2048^2 frame), on request
 
 
 def test_already_launched_ranks_do_not_relaunch():
