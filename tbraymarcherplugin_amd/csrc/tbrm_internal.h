@@ -305,7 +305,7 @@ enum Tunable : int {
     TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)
     TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
     TUNE_LIGHT_SWEEP,        // 0: axis passes never take the pipelined sweep kernel (k_light_sweep); 1: where it applies
-    TUNE_SWEEP_ROWS,         // height of a sweep tile: 16 (two workgroups per CU; default) or 32 (one)
+    TUNE_SWEEP_ROWS,         // height of a sweep tile: 32 (default) or 16 (two workgroups per CU: measured, slower)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
     TUNE_SWEEP_STAGGER_NS,   // start delay of a sweep tile per tile of distance from the upstream corner, ns (0: default; < 0: none)
     TUNE_STREAM_PRIORITY,    // priority of a handle's own stream, read when the handle is created: 0 = default, 1 = the highest the

@@ -7,7 +7,7 @@ namespace tbrm {
 int sweep_tile_rows()
 {
     const int t = tune(TUNE_SWEEP_ROWS);
-    return t == 32 ? 32 : 16;
+    return t == 16 ? 16 : 32; // (32 x 16 measured: the free tile 17 % faster per slice, 16 more hops at 3.5 - 4.3 instead of 2.7 - 3.1 us each: slower)
 }
 
 // advances every tile through the span (j0, n_steps) in one launch; mode PASS_ADD, PASS_CHANGE, PASS_ADD2 or PASS_PLANES, the
