@@ -12,8 +12,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libtbrm.so")
 # (source, object name, extra flags): tbrm_light_chain.hip is compiled once per light-volume format so that the two halves
 # of the chain kernel's instantiations build in parallel
 UNITS = [
-    ("tbrm_api.cpp", "tbrm_api", []), ("tbrm_light_passes.cpp", "tbrm_light_passes", []), ("tbrm_block_lists.cpp", "tbrm_block_lists", []), ("tbrm_host_math.cpp", "tbrm_host_math", []),
-    ("tbrm_kernels.hip", "tbrm_kernels", []), ("tbrm_light_kernels.hip", "tbrm_light_kernels", []),
+    ("tbrm_api.cpp", "tbrm_api", []), ("tbrm_api_render.cpp", "tbrm_api_render", []), ("tbrm_api_slabs.cpp", "tbrm_api_slabs", []), ("tbrm_light_plan.cpp", "tbrm_light_plan", []), ("tbrm_factor_cache.cpp", "tbrm_factor_cache", []), ("tbrm_light_enqueue.cpp", "tbrm_light_enqueue", []),
+    ("tbrm_light_operators.cpp", "tbrm_light_operators", []), ("tbrm_block_lists.cpp", "tbrm_block_lists", []), ("tbrm_host_math.cpp", "tbrm_host_math", []),
+    ("tbrm_kernels.hip", "tbrm_kernels", []), ("tbrm_volume_kernels.hip", "tbrm_volume_kernels", []), ("tbrm_light_kernels.hip", "tbrm_light_kernels", []),
     ("tbrm_light_chain.hip", "tbrm_light_chain_u8", ["-DTBRM_CHAIN_LFMT=0"]), ("tbrm_light_chain.hip", "tbrm_light_chain_f32", ["-DTBRM_CHAIN_LFMT=2"]),
     ("tbrm_light_sweep_dispatch.cpp", "tbrm_light_sweep_dispatch", []),
 ] + [
@@ -22,7 +23,7 @@ UNITS = [
     for t in (16, 32) for m in (1, 0, 2, 5)
 ]
 SOURCES = sorted({u[0] for u in UNITS})
-HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h", "tbrm_light_sweep.h",
+HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h", "tbrm_light_sweep.h", "tbrm_light_passes.h",
            "../../include/tbrm.h"]
 
 # -ffp-contract=off + explicit fma is the arithmetic contract with the oracle (DESIGN.md "Arithmetic spec").

@@ -3,7 +3,7 @@
 // Plays the role of the reference's game-thread operator library:
 //   URaymarchUtils::AddDirLightToSingleVolume / ChangeDirLightInSingleVolume / ClearResourceLightVolumes
 //       Source/Raymarcher/Private/Util/RaymarchUtils.cpp:35-111
-//   (their render-thread drivers, LightingShaders.cpp:35-326, are tbrm_light_passes.cpp)
+//   (their render-thread drivers, LightingShaders.cpp:35-326, are tbrm_light_operators.cpp)
 //   ARaymarchVolume::InitializeRaymarchResources / FreeRaymarchResources
 //       Source/Raymarcher/Private/Actor/RaymarchVolume.cpp:821-949
 // Every call enqueues on the handle's HIP stream (FIFO, like ENQUEUE_RENDER_COMMAND) and returns; parameter
@@ -189,59 +189,15 @@ int end_timed(tbrm_resources* r, int kind)
 
 } // namespace tbrm_host
 
-namespace {
+namespace tbrm_host {
 
 RelayoutParams relayout_params(const void* src, void* dst, const int dims[3], const int bn[3], size_t elem, bool to_bricks)
 {
     return RelayoutParams{src, dst, dims[0], dims[1], dims[2], bn[0], bn[0] * bn[1], bn[2], (int) elem, to_bricks ? 1 : 0};
 }
 
-int build_ray_params(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                     const tbrm_world_params* world, RayParams& p)
-{
-    if (!(rp->steps > 0.0f)) return fail(TBRM_ERR_INVALID_ARG, "steps must be > 0");
-    if (tile->w < 0 || tile->h < 0 || cam->width <= 0 || cam->height <= 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile/camera size");
-    p = RayParams{};
-    p.data = data_view(r);
-    p.data_addr_mode = r->desc.data_address_mode == TBRM_ADDRESS_CLAMP ? ADDR_CLAMP : ADDR_WRAP;
-    p.tf = r->d_tf;
-    p.win = window_dev(r);
-    p.xcd_rows = tune(TUNE_RAY_XCD_ROWS);
-    p.light = r->d_light;
-    for (int c = 0; c < 3; ++c) p.lv_dims[c] = r->lv_dims[c];
-    p.lv_bnx = r->lbn[0];
-    p.lv_bnxy = r->lbn[0] * r->lbn[1];
-    p.lv_fmt = r->lv_fmt;
-    p.lv_wrap_layer = r->res_light.wrap_src;
-    p.lv_wrap_shift = (r->res_light.hi - r->res_light.wrap_src) * 8;
-    const tbrm_vec3d* v[4] = {&cam->position, &cam->forward, &cam->right, &cam->up};
-    float* dst[4] = {p.cam_pos, p.fwd, p.right, p.up};
-    for (int k = 0; k < 4; ++k) {
-        dst[k][0] = (float) v[k]->x; dst[k][1] = (float) v[k]->y; dst[k][2] = (float) v[k]->z;
-    }
-    p.thx = (float) cam->tan_half_fov_x;
-    p.thy = (float) cam->tan_half_fov_y;
-    p.width = cam->width;
-    p.height = cam->height;
-    host_world_to_local(world->volume_transform, p.m);
-    host_local_clipping(*world, p.cc, p.cd);
-    p.clip_mode = raymarch_clip_mode(p.cc, p.cd);
-    {   // (measured: frames of 128^3 / 256^3 volumes lose 15 % to the bookkeeping, 512^3 is even, 2048^2 rays through 512^3 gain 12 %)
-        const int ws = tune(TUNE_RAY_WAVE_SKIP);
-        p.wave_skip = ws > 0 || (ws < 0 && std::min(r->desc.dim_x, std::min(r->desc.dim_y, r->desc.dim_z)) >= 384) ? 1 : 0;
-    }
-    p.share_grid = (r->lv_dims[0] == r->desc.dim_x && r->lv_dims[1] == r->desc.dim_y && r->lv_dims[2] == r->desc.dim_z &&
-                    !r->resident && tune(TUNE_SHARE_GRID)) ? 1 : 0; // (the two volumes of a slab-resident handle relocate different layers)
-    p.tile_x0 = tile->x0; p.tile_y0 = tile->y0; p.tile_w = tile->w; p.tile_h = tile->h;
-    p.row_group_step = tile->row_group_step > 0 ? tile->row_group_step : 1;
-    p.steps = rp->steps;
-    p.jitter_frame = rp->jitter_frame;
-    p.bnx = r->bn[0]; p.bny = r->bn[1]; p.bnz = r->bn[2];
-    p.tab = r->d_ray_tab;
-    return TBRM_OK;
-}
+} // namespace tbrm_host
 
-} // namespace
 
 namespace tbrm_host {
 
@@ -642,214 +598,6 @@ int tbrm_change_dir_light(tbrm_resources* r, const tbrm_dir_light_params* old_li
     return e ? e : e2;
 }
 
-// ---- slab-partitioned illumination (tbrm.h "slabs") ------------------------------------------------------------
-
-int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* removed, const tbrm_dir_light_params* light, int added,
-                          const tbrm_world_params* world, const tbrm_slab* slab, int32_t* n_passes)
-{
-    if (!r || !light || !world || !slab || !n_passes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
-    *n_passes = 0;
-    if (!r->slab_op) r->slab_op = new SlabOp;
-    SlabOp& op = *r->slab_op;
-    op.slab = *slab;
-    op.change = removed != nullptr;
-    op.n = 0;
-    op.current = -1;
-    op.base = base_prop_params(r, *world);
-    if (!op.change) { // enqueue_add
-        int n = 0;
-        if (!host_light_passes(*light, *world, r->lv_dims, r->desc.border_mode, op.a, &n)) return TBRM_OK;
-        op.n = n;
-        op.b_added = added ? 1.0f : -1.0f;
-    } else { // enqueue_change
-        tbrm_light_pass rp[2], ap[2];
-        int rn = 0, an = 0;
-        const bool r_ok = host_light_passes(*removed, *world, r->lv_dims, r->desc.border_mode, rp, &rn);
-        const bool a_ok = host_light_passes(*light, *world, r->lv_dims, r->desc.border_mode, ap, &an);
-        if (!r_ok || !a_ok) return TBRM_OK;
-        if (rp[0].face != ap[0].face || rp[1].face != ap[1].face)
-            return fail(TBRM_ERR_AXES_DIFFER, "the two lights' major axes differ: remove the old light and add the new one "
-                                              "(LightingShaders.cpp:192-198)");
-        for (int i = 0; i < 2; ++i) {
-            if (rp[i].light_alpha == 0.0f && ap[i].light_alpha == 0.0f && rp[i].border_light == 0.0f && ap[i].border_light == 0.0f)
-                continue; // both streams dark: the pass cannot touch the light volume (enqueue_change)
-            op.a[op.n] = ap[i];
-            op.r[op.n] = rp[i];
-            ++op.n;
-        }
-        op.b_added = 0.0f;
-    }
-    for (int i = 0; i < op.n; ++i) { // all or nothing: every pass has to have a chunked (slab-capable) form
-        ChunkFit fit;
-        const tbrm_light_pass* pr_i = op.change ? &op.r[i] : nullptr;
-        const int reach = slice_tap_reach(op.a[i], pr_i);
-        const bool slice_form = reach >= 0 && (op.a[i].axis == 2 || reach <= slab->z_end - slab->z_begin); // one slice per step
-        if (!chunk_fit(r, op.a[i], pr_i, fit) && !slice_form) {
-            const int n = op.n;
-            op.n = 0;
-            return fail(TBRM_ERR_UNSUPPORTED, "pass %d of %d (axis %d) has no slab-partitioned form: its taps reach %d rows from the pixel (%s)",
-                        i, n, (int) op.a[i].axis, reach, g_plan_note);
-        }
-    }
-    // (a slab-partitioned operator is a light operator of its own for the sweep's buffer bookkeeping: its sweeps record their
-    // buffers' own idle events — no "operator done" event is recorded for it, a later operator's occlusion then waits for
-    // everything enqueued so far: wait_for_readers)
-    ++r->op_serial;
-    r->op_many_passes = true;
-    *n_passes = op.n;
-    return TBRM_OK;
-}
-
-int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
-{
-    if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!r->slab_op || pass < 0 || pass >= r->slab_op->n) return fail(TBRM_ERR_INVALID_ARG, "no such pass (tbrm_slab_light_begin first)");
-    if (int e = bind(r)) return e;
-    SlabOp& op = *r->slab_op;
-    op.current = -1;
-    const int e = plan_pass(r, op.base, op.a[pass], op.change ? &op.r[pass] : nullptr, op.b_added, &op.slab, op.plan);
-    if (e == TBRM_ERR_UNSUPPORTED)
-        return fail(e, "pass %d (axis %d) has no slab-partitioned form: %s", (int) pass, (int) op.a[pass].axis, g_plan_note);
-    if (e) return e;
-    op.current = pass;
-    const PassPlan& pl = op.plan;
-    out->axis = pl.p.axis;
-    out->dir = pl.dir;
-    out->lateral = pl.lateral ? 1 : 0;
-    out->streams = pl.two_streams() ? 2 : 1;
-    out->plane_w = pl.p.W;
-    out->plane_h = pl.p.H;
-    out->chunk_slices = pl.M;
-    out->chunks_of_pass = pl.chunks_of_pass;
-    out->first_chunk = pl.first_chunk_of_pass;
-    out->n_chunks = pl.n_chunks;
-    out->halo_rows = pl.lateral ? (pl.sliced ? pl.halo_rows : kChunkTile) : 0;
-    out->plane_elem_bytes = pl.sliced ? (r->lv_fmt == FMT_U8 ? 1 : 4) : 4;
-    return TBRM_OK;
-}
-
-int tbrm_slab_pass_chunk(tbrm_resources* r, int32_t chunk)
-{
-    if (!r || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight (tbrm_slab_pass_begin first)");
-    const PassPlan& pl = r->slab_op->plan;
-    if (chunk < 0 || chunk >= pl.n_chunks) return fail(TBRM_ERR_INVALID_ARG, "chunk %d of %d", chunk, pl.n_chunks);
-    if (int e = bind(r)) return e;
-    return enqueue_plan_chunk(r, pl, chunk);
-}
-
-int tbrm_slab_pass_plane(tbrm_resources* r, int32_t boundary, int32_t stream, void** device_plane)
-{
-    if (!r || !device_plane || !r->slab_op || r->slab_op->current < 0) return fail(TBRM_ERR_INVALID_ARG, "no pass in flight");
-    const PassPlan& pl = r->slab_op->plan;
-    if (boundary < 0 || boundary > pl.n_chunks || stream < 0 || stream >= (pl.two_streams() ? 2 : 1))
-        return fail(TBRM_ERR_INVALID_ARG, "boundary %d / stream %d out of range", boundary, stream);
-    *device_plane = pl.sliced ? sliced_plane(r, pl, boundary, stream) : (void*) plan_plane(r, boundary, stream);
-    return TBRM_OK;
-}
-
-// ---- slab-resident handles: moving their layers in and out -------------------------------------------------------------
-
-namespace {
-// where brick layer `layer` of a volume lives, or null when the handle does not hold it
-char* layer_address(const tbrm_resources::Residency& q, int layer)
-{
-    if (layer >= q.lo && layer < q.hi) return (char*) q.alloc + (size_t) (layer - q.lo) * q.layer_bytes;
-    if (layer == q.wrap_src) return (char*) q.alloc + (size_t) (q.hi - q.lo) * q.layer_bytes;
-    return nullptr;
-}
-} // namespace
-
-int tbrm_slab_resident_slices(const tbrm_resources* r, int32_t data[3], int32_t light[3])
-{
-    if (!r || !data || !light) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    const tbrm_resources::Residency* q[2] = {&r->res_data, &r->res_light};
-    const int depth[2] = {r->desc.dim_z, r->lv_dims[2]};
-    int32_t* out[2] = {data, light};
-    for (int k = 0; k < 2; ++k) {
-        out[k][0] = q[k]->lo * 8;
-        out[k][1] = std::min(q[k]->hi * 8, depth[k]);
-        out[k][2] = q[k]->wrap_src >= 0 ? q[k]->wrap_src * 8 : -1;
-    }
-    return TBRM_OK;
-}
-
-int tbrm_upload_volume_slices(tbrm_resources* r, int32_t z_begin, int32_t z_count, const void* host_voxels, size_t n_bytes)
-{
-    if (!r || !host_voxels) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    const int nz = r->desc.dim_z;
-    const size_t esz = format_bytes(r->desc.data_format), slice = (size_t) r->desc.dim_x * r->desc.dim_y * esz;
-    if (z_begin < 0 || z_count <= 0 || z_begin + z_count > nz || z_begin % 8 || ((z_begin + z_count) % 8 && z_begin + z_count != nz))
-        return fail(TBRM_ERR_INVALID_ARG, "slices [%d, %d): whole brick layers (multiples of 8) of a volume %d deep", z_begin, z_begin + z_count, nz);
-    if (n_bytes != slice * (size_t) z_count) return fail(TBRM_ERR_INVALID_ARG, "%d slices are %zu bytes, got %zu", z_count, slice * (size_t) z_count, n_bytes);
-    if (int e = bind(r)) return e;
-    quiesce_occ_stream(r);
-    void* staging = nullptr;
-    HIP_TRY(hipMalloc(&staging, n_bytes));
-    hipError_t e1 = hipMemcpyAsync(staging, host_voxels, n_bytes, hipMemcpyHostToDevice, r->stream);
-    int code = TBRM_OK;
-    for (int layer = z_begin / 8; e1 == hipSuccess && layer < ceil_div(z_begin + z_count, 8); ++layer) { // layer by layer: the wrap copy lives elsewhere
-        char* dst = layer_address(r->res_data, layer);
-        if (!dst) { code = fail(TBRM_ERR_INVALID_ARG, "data slices %d.. are not resident on this handle", layer * 8); break; }
-        const int lz = std::min(8, nz - layer * 8);
-        const int dims[3] = {r->desc.dim_x, r->desc.dim_y, lz}, bn[3] = {r->dbn[0], r->dbn[1], 1};
-        e1 = launch_relayout(relayout_params((const char*) staging + (size_t) (layer * 8 - z_begin) * slice, dst, dims, bn, esz, true), r->stream);
-    }
-    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
-    (void) hipFree(staging);
-    if (code != TBRM_OK) return code;
-    HIP_TRY(e1);
-    r->has_volume = true;
-    r->octree_valid = false;
-    r->minmax_valid = false;
-    ++r->data_gen;
-    return TBRM_OK;
-}
-
-int tbrm_download_light_slices(tbrm_resources* r, int32_t z_begin, int32_t z_count, void* host_out, size_t n_bytes)
-{
-    if (!r || !host_out) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    const int nz = r->lv_dims[2];
-    const size_t esz = r->lv_fmt == FMT_U8 ? 1 : 4, slice = (size_t) r->lv_dims[0] * r->lv_dims[1] * esz;
-    if (z_begin < 0 || z_count <= 0 || z_begin + z_count > nz || z_begin % 8 || ((z_begin + z_count) % 8 && z_begin + z_count != nz))
-        return fail(TBRM_ERR_INVALID_ARG, "slices [%d, %d): whole brick layers (multiples of 8) of a light volume %d deep", z_begin, z_begin + z_count, nz);
-    if (n_bytes != slice * (size_t) z_count) return fail(TBRM_ERR_INVALID_ARG, "%d slices are %zu bytes, got %zu", z_count, slice * (size_t) z_count, n_bytes);
-    if (int e = bind(r)) return e;
-    void* staging = nullptr;
-    HIP_TRY(hipMalloc(&staging, n_bytes));
-    hipError_t e1 = hipSuccess;
-    int code = TBRM_OK;
-    for (int layer = z_begin / 8; e1 == hipSuccess && layer < ceil_div(z_begin + z_count, 8); ++layer) {
-        const tbrm_resources::Residency& q = r->res_light;
-        char* src = (layer >= q.lo && layer < q.hi) ? layer_address(q, layer) : nullptr; // the layer itself, not a wrap copy of it
-        if (!src) { code = fail(TBRM_ERR_INVALID_ARG, "light-volume slices %d.. are not resident on this handle", layer * 8); break; }
-        const int lz = std::min(8, nz - layer * 8);
-        const int dims[3] = {r->lv_dims[0], r->lv_dims[1], lz}, bn[3] = {r->lbn[0], r->lbn[1], 1};
-        e1 = launch_relayout(relayout_params(src, (char*) staging + (size_t) (layer * 8 - z_begin) * slice, dims, bn, esz, false), r->stream);
-    }
-    if (e1 == hipSuccess && code == TBRM_OK) e1 = hipMemcpyAsync(host_out, staging, n_bytes, hipMemcpyDeviceToHost, r->stream);
-    if (e1 == hipSuccess) e1 = hipStreamSynchronize(r->stream);
-    (void) hipFree(staging);
-    if (code != TBRM_OK) return code;
-    HIP_TRY(e1);
-    return sweep_failed(r); // (the slices of a light volume a failed sweep left undefined are not handed out as good)
-}
-
-int tbrm_slab_light_halo(tbrm_resources* r, int32_t side, void** send_layer, void** recv_layer, size_t* layer_bytes)
-{
-    if (!r || !send_layer || !recv_layer || !layer_bytes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!r->resident) return fail(TBRM_ERR_INVALID_ARG, "not a slab-resident handle");
-    if (side != 0 && side != 1) return fail(TBRM_ERR_INVALID_ARG, "side is 0 (towards z = 0) or 1");
-    const tbrm_resources::Residency& q = r->res_light;
-    const int first = r->owned.z_begin / 8, last = r->owned.z_end / 8 - 1, layers = r->lbn[2];
-    const int send = side == 0 ? first : last;
-    const int recv = side == 0 ? (first == 0 ? layers - 1 : first - 1) : (last == layers - 1 ? 0 : last + 1); // across the ends: the wrap copy
-    *send_layer = layer_address(q, send);
-    *recv_layer = (recv >= first && recv <= last) ? nullptr : layer_address(q, recv); // a handle that owns everything has no halo
-    *layer_bytes = q.layer_bytes;
-    return TBRM_OK;
-}
-
 int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)
 {
     if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
@@ -861,229 +609,6 @@ int tbrm_clear_light_volume(tbrm_resources* r, float clear_value)
     const size_t n = (size_t) r->lbn[0] * r->lbn[1] * 512 * (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0));
     HIP_TRY(launch_fill(q.alloc, r->lv_fmt, n, clear_value, r->stream));
     return end_timed(r, 0);
-}
-
-int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                             const tbrm_world_params* world, const float* device_scene_depth, float* device_out_rgba)
-{
-    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: frames are marched with tbrm_raymarch_lit_slab_device");
-    if (!r || !cam || !tile || !rp || !world || !device_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
-    if (int e = bind(r)) return e;
-    RayParams p;
-    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
-    p.depth = device_scene_depth;
-    p.out = device_out_rgba;
-    if (rp->enable_skipping) {
-        if (int e = ensure_skipping(r)) return e;
-        p.empty_bits = r->d_empty;
-        p.skip_dist = r->d_dist[0];
-    }
-    if (int e = begin_timed(r, 1)) return e;
-    HIP_TRY(launch_raymarch(p, r->stream));
-    ++r->launches[2];
-    if (tune(TUNE_OCC_AFTER_FRAME) && r->occ_stream) {
-        if (!r->frame_done) HIP_TRY(hipEventCreateWithFlags(&r->frame_done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(r->frame_done, r->stream));
-        r->frame_pending = true;
-    }
-    return end_timed(r, 1);
-}
-
-int tbrm_raymarch_lit_slab_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                                  const tbrm_world_params* world, const float* device_scene_depth, float* device_state_rgba,
-                                  const tbrm_slab* slab, int direction)
-{
-    if (!r || !cam || !tile || !rp || !world || !device_state_rgba || !slab) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
-    if (slab->z_begin < 0 || slab->z_end > r->lv_dims[2] || slab->z_begin >= slab->z_end)
-        return fail(TBRM_ERR_INVALID_ARG, "slab [%d, %d) of a light volume %d deep", slab->z_begin, slab->z_end, r->lv_dims[2]);
-    if (int e = bind(r)) return e;
-    RayParams p;
-    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
-    p.depth = device_scene_depth;
-    p.out = device_state_rgba;
-    p.slab_on = 1;
-    p.slab_z0 = slab->z_begin;
-    p.slab_z1 = slab->z_end;
-    p.slab_dir = direction > 0 ? 1 : (direction < 0 ? -1 : 0);
-    if (r->resident && (slab->z_begin != r->owned.z_begin || slab->z_end != r->owned.z_end))
-        return fail(TBRM_ERR_INVALID_ARG, "a slab-resident handle marches its own slab [%d, %d) only", r->owned.z_begin, r->owned.z_end);
-    if (rp->enable_skipping) {
-        if (int e = ensure_skipping(r)) return e;
-        p.empty_bits = r->d_empty;
-        p.skip_dist = r->d_dist[0];
-    }
-    if (int e = begin_timed(r, 1)) return e;
-    HIP_TRY(launch_raymarch(p, r->stream));
-    ++r->launches[2];
-    return end_timed(r, 1);
-}
-
-int tbrm_raymarch_lit(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                      const tbrm_world_params* world, float* host_out_rgba)
-{
-    if (!r || !tile || !host_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (tile->w < 0 || tile->h < 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile size");
-    const size_t bytes = (size_t) tile->w * tile->h * 4 * sizeof(float);
-    if (bytes == 0) return TBRM_OK;
-    if (int e = bind(r)) return e;
-    if (bytes > r->out_bytes) {
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        (void) hipFree(r->d_out);
-        r->d_out = nullptr;
-        r->out_bytes = 0;
-        HIP_TRY(hipMalloc((void**) &r->d_out, bytes));
-        r->out_bytes = bytes;
-    }
-    if (int e = tbrm_raymarch_lit_device(r, cam, tile, rp, world, nullptr, r->d_out)) return e;
-    HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return sweep_failed(r); // (a frame lit by a light volume that a failed sweep left undefined is not handed out as good)
-}
-
-int tbrm_raymarch_intensity_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                                   const tbrm_world_params* world, const float* device_scene_depth, float* device_out_rgba)
-{
-    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: only the lit march has a slab form");
-    if (!r || !cam || !tile || !rp || !world || !device_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!r->has_volume) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume");
-    if (int e = bind(r)) return e;
-    RayParams p;
-    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
-    p.depth = device_scene_depth;
-    p.out = device_out_rgba;
-    if (int e = begin_timed(r, 1)) return e;
-    HIP_TRY(launch_raymarch_intensity(p, r->stream));
-    ++r->launches[2];
-    return end_timed(r, 1);
-}
-
-int tbrm_raymarch_intensity(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                            const tbrm_world_params* world, float* host_out_rgba)
-{
-    if (!r || !tile || !host_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (tile->w < 0 || tile->h < 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile size");
-    const size_t bytes = (size_t) tile->w * tile->h * 4 * sizeof(float);
-    if (bytes == 0) return TBRM_OK;
-    if (int e = bind(r)) return e;
-    if (bytes > r->out_bytes) {
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        (void) hipFree(r->d_out);
-        r->d_out = nullptr;
-        r->out_bytes = 0;
-        HIP_TRY(hipMalloc((void**) &r->d_out, bytes));
-        r->out_bytes = bytes;
-    }
-    if (int e = tbrm_raymarch_intensity_device(r, cam, tile, rp, world, nullptr, r->d_out)) return e;
-    HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return TBRM_OK;
-}
-
-int tbrm_octree_mip_dims(const tbrm_resources* r, int mip, int32_t out_dims[3])
-{
-    if (!r || !out_dims || mip < 0 || mip > 3) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
-    const int d[3] = {r->desc.dim_x, r->desc.dim_y, r->desc.dim_z};
-    for (int c = 0; c < 3; ++c) {
-        int p2 = 1;
-        while (p2 < d[c]) p2 <<= 1; // FMath::RoundUpToPowerOfTwo (RaymarchVolume.cpp:876-877)
-        out_dims[c] = std::max(p2 >> mip, 1);
-    }
-    return TBRM_OK;
-}
-
-int tbrm_generate_octree(tbrm_resources* r)
-{
-    if (r && r->resident) return fail(TBRM_ERR_UNSUPPORTED, "slab-resident handle: only the lit march has a slab form");
-    if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (!r->has_volume) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume");
-    if (int e = bind(r)) return e;
-    for (int m = 0; m < 4; ++m) {
-        int32_t d[3];
-        (void) tbrm_octree_mip_dims(r, m, d);
-        for (int c = 0; c < 3; ++c) r->oct_dims[m][c] = d[c];
-        if (!r->d_octree[m]) HIP_TRY(hipMalloc((void**) &r->d_octree[m], (size_t) d[0] * d[1] * d[2] * sizeof(uint16_t)));
-        OctreeParams op{};
-        op.data = data_view(r);
-        op.lower = m ? r->d_octree[m - 1] : nullptr;
-        for (int c = 0; c < 3; ++c) { op.dims[c] = d[c]; op.lower_dims[c] = m ? r->oct_dims[m - 1][c] : 0; }
-        op.out = r->d_octree[m];
-        HIP_TRY(launch_octree_level(op, m == 0, r->stream));
-    }
-    r->octree_valid = true;
-    return TBRM_OK;
-}
-
-int tbrm_download_octree_mip(tbrm_resources* r, int mip, uint16_t* host_out, size_t bytes)
-{
-    if (!r || !host_out || mip < 0 || mip > 3) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
-    if (!r->octree_valid) return fail(TBRM_ERR_NOT_INITIALIZED, "no octree: call tbrm_generate_octree after uploading the volume");
-    if (int e = bind(r)) return e;
-    const size_t need = (size_t) r->oct_dims[mip][0] * r->oct_dims[mip][1] * r->oct_dims[mip][2] * sizeof(uint16_t);
-    if (bytes != need) return fail(TBRM_ERR_INVALID_ARG, "octree level %d is %zu bytes, got %zu", mip, need, bytes);
-    HIP_TRY(hipMemcpyAsync(host_out, r->d_octree[mip], need, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return TBRM_OK;
-}
-
-int tbrm_raymarch_octree_device(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                                const tbrm_world_params* world, int octree_mip, const float* device_scene_depth, float* device_out_rgba)
-{
-    if (!r || !cam || !tile || !rp || !world || !device_out_rgba || octree_mip < 0 || octree_mip > 3) return fail(TBRM_ERR_INVALID_ARG, "bad argument");
-    if (!r->has_volume || !r->has_tf) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
-    if (!r->octree_valid) return fail(TBRM_ERR_NOT_INITIALIZED, "no octree: call tbrm_generate_octree after uploading the volume");
-    if (int e = bind(r)) return e;
-    RayParams p;
-    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
-    p.depth = device_scene_depth;
-    p.out = device_out_rgba;
-    p.octree = r->d_octree[octree_mip];
-    for (int c = 0; c < 3; ++c) p.oct_dims[c] = r->oct_dims[octree_mip][c];
-    p.oct_depth0 = (float) r->oct_dims[0][2];
-    if (int e = begin_timed(r, 1)) return e;
-    HIP_TRY(launch_raymarch_octree(p, r->stream));
-    ++r->launches[2];
-    return end_timed(r, 1);
-}
-
-int tbrm_raymarch_octree(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                         const tbrm_world_params* world, int octree_mip, float* host_out_rgba)
-{
-    if (!r || !tile || !host_out_rgba) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (tile->w < 0 || tile->h < 0) return fail(TBRM_ERR_INVALID_ARG, "bad tile size");
-    const size_t bytes = (size_t) tile->w * tile->h * 4 * sizeof(float);
-    if (bytes == 0) return TBRM_OK;
-    if (int e = bind(r)) return e;
-    if (bytes > r->out_bytes) {
-        HIP_TRY(hipStreamSynchronize(r->stream));
-        (void) hipFree(r->d_out);
-        r->d_out = nullptr;
-        r->out_bytes = 0;
-        HIP_TRY(hipMalloc((void**) &r->d_out, bytes));
-        r->out_bytes = bytes;
-    }
-    if (int e = tbrm_raymarch_octree_device(r, cam, tile, rp, world, octree_mip, nullptr, r->d_out)) return e;
-    HIP_TRY(hipMemcpyAsync(host_out_rgba, r->d_out, bytes, hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    return TBRM_OK;
-}
-
-int tbrm_count_nominal_samples(tbrm_resources* r, const tbrm_camera* cam, const tbrm_tile* tile, const tbrm_raymarch_params* rp,
-                               const tbrm_world_params* world, uint64_t* out_samples)
-{
-    if (!r || !cam || !tile || !rp || !world || !out_samples) return fail(TBRM_ERR_INVALID_ARG, "null argument");
-    if (int e = bind(r)) return e;
-    RayParams p;
-    if (int e = build_ray_params(r, cam, tile, rp, world, p)) return e;
-    p.sample_counter = r->d_counter;
-    HIP_TRY(hipMemsetAsync(r->d_counter, 0, sizeof(unsigned long long), r->stream));
-    HIP_TRY(launch_count_samples(p, r->stream));
-    unsigned long long v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, r->d_counter, sizeof(v), hipMemcpyDeviceToHost, r->stream));
-    HIP_TRY(hipStreamSynchronize(r->stream));
-    *out_samples = v;
-    return TBRM_OK;
 }
 
 int tbrm_download_light_volume(tbrm_resources* r, void* host_out, size_t n_bytes)

@@ -149,14 +149,6 @@ struct RawTaps {
         t[4] = load_raw<FMT>(data, o.z1 + o.y0 + o.x0); t[5] = load_raw<FMT>(data, o.z1 + o.y0 + o.x1);
         t[6] = load_raw<FMT>(data, o.z1 + o.y1 + o.x0); t[7] = load_raw<FMT>(data, o.z1 + o.y1 + o.x1);
     }
-    // UNORM8 taps decoded through a 256-entry table of decode_u8's values (LDS): one address shift + one LDS read per tap instead
-    // of convert + multiply + fma — the same floats
-    __device__ __forceinline__ float filter_lut(const float* lut, float fx, float fy, float fz) const
-    {
-        const float c00 = lerp_(lut[t[0]], lut[t[1]], fx), c10 = lerp_(lut[t[2]], lut[t[3]], fx);
-        const float c01 = lerp_(lut[t[4]], lut[t[5]], fx), c11 = lerp_(lut[t[6]], lut[t[7]], fx);
-        return lerp_(lerp_(c00, c10, fy), lerp_(c01, c11, fy), fz);
-    }
     __device__ __forceinline__ float filter(float fx, float fy, float fz) const
     {
         const float c00 = lerp_(decode_raw<FMT>(t[0]), decode_raw<FMT>(t[1]), fx), c10 = lerp_(decode_raw<FMT>(t[2]), decode_raw<FMT>(t[3]), fx);

@@ -4,8 +4,7 @@
 //   k_raymarch_lit     : PerformRaymarchCubeSetup + PerformWindowedLitRaymarch
 //                        (RaymarchMaterialCommon.usf:23-78, WindowedRaymarchMaterials.usf:21-96).
 //   k_fill             : ClearTextureShader.usf:12-16 / ClearVolumeTextureShader.usf:14-20.
-//   k_brick_minmax/k_brick_empty : empty-space-skipping metadata (no reference counterpart; skipped samples are
-//                        exactly the ones whose corrected opacity is 0, so results are unchanged).
+//   (skipping metadata, relayout, self-tests: tbrm_volume_kernels.hip)
 //
 // Compiled with -ffp-contract=off; see tbrm_device_math.h for the arithmetic contract.
 #include "tbrm_device_sampling.h"
@@ -152,13 +151,6 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // in order. The stage takes the ray's LightEnergy as the slabs before it left it (p.out, in place), accumulates the
 // samples it owns exactly where the unpartitioned loop would, and hands the state on. Positions are still reached by
 // performing every addition of the ray, so every sample, and the early exit, are bit for bit those of the whole march.
-#ifndef TBRM_RAY_EXP
-#define TBRM_RAY_EXP 0 // timing experiments (WRONG frames; tools/ray_ablation.sh): 1 = no pow, 2 = no light-volume taps, 4 = no data taps
-#endif                 // (constant value), 8 = no in-order accumulation (every lane adds its own sample), 16 = no leap-distance look-up;
-                       // A/B variants with RIGHT frames: 32 = the four lanes of a ray exchange their samples by DPP quad broadcasts instead
-                       // of through LDS, 64 = the same with selects instead of exec-mask regions (both measured, both lost), 128 = the light
-                       // volume's UNORM8 taps decoded through a 256-entry LDS table instead of convert + multiply + fma (a tie: 0.515 - 0.527
-                       // against 0.515 - 0.522 ms)
 #ifdef TBRM_RAY_STATS // diagnostics build (tools/ray_stats.sh): how full the waves of the lit march are
 __device__ unsigned long long g_ray_stats[4]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples
 extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsigned long long* out, int reset)
@@ -171,18 +163,6 @@ extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsig
     return 0;
 }
 #endif
-
-// lane t of the caller's DPP quad (lanes 4k .. 4k + 3), in every lane of the quad
-template <int T>
-__device__ __forceinline__ float quad_bcast(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), T * 0x55, 0xf, 0xf, true));
-}
-template <class F>
-__device__ __forceinline__ void sweep4(F&& f)
-{
-    f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
-}
 
 // TAB: the data volume's texel -> voxel-offset arithmetic (address mode, +1 tap, bricked offset, brick index of the leap-distance
 // look-up: ~45 integer instructions per sample, more than the filter itself) comes out of three small tables the workgroup copies
@@ -203,8 +183,6 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
     constexpr int LSH = kRayLanes == 4 ? 2 : 3;
     __shared__ float4 s_tf[256];
     __shared__ float4 s_x[256]; // per lane: (colour * alpha, alpha) of its sample; alpha < 0: nothing to accumulate
-    __shared__ float s_u8[(TBRM_RAY_EXP & 128) ? 256 : 1]; // (A/B variant 128: decode_u8 of every code, for the light volume's taps)
-    if constexpr (TBRM_RAY_EXP & 128) s_u8[threadIdx.x] = decode_u8(threadIdx.x);
     s_tf[threadIdx.x] = p.tf[threadIdx.x];
     if constexpr (!TAB) __syncthreads();
 
@@ -330,7 +308,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 tab_dt.x0 = ax.x; tab_dt.x1 = bx1.x; tab_dt.y0 = ay.x; tab_dt.y1 = by1.x; tab_dt.z0 = az.x; tab_dt.z1 = bz1.x;
                 tab_brick = ax.y + ay.y + az.y;
             }
-            if (p.skip_dist && !(TBRM_RAY_EXP & 16)) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
+            if (p.skip_dist) { // a sample based in a brick that maps every reachable value to opacity 0 is an exact no-op
                 int dist;
                 if constexpr (TAB) dist = p.skip_dist[tab_brick];
                 else {
@@ -373,20 +351,17 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 texel_split_bounded(sp2, lnz, lz, gz);
                 ltaps.issue(p.light, tap_offsets<ADDR_WRAP, SLAB>(lightv, lx, ly, lz));
             }
-            const float v = (TBRM_RAY_EXP & 4) ? 0.6f + fx * 0.01f : dtaps.filter(fx, fy, fz);
+            const float v = dtaps.filter(fx, fy, fz);
             // SampleWindowedTransferFunction (WindowedSampling.usf:20-37)
-            const float tpos = (TBRM_RAY_EXP & 4) ? tf_position(v, p.win.center, p.win.width) : window_position<DFMT != FMT_F32>(v, p.win);
+            const float tpos = window_position<DFMT != FMT_F32>(v, p.win);
             if (!((tpos < 0.0f && p.win.low_cutoff > 0.0f) || (tpos > 1.0f && p.win.high_cutoff > 0.0f))) {
                 const float4 cs = sample_tf(s_tf, tpos);
                 const float a_sat = saturate_(cs.w);
                 if (a_sat != 0.0f) { // else 1 - pow(1, s) = 0: the sample contributes exactly nothing
                     // (a_sat in (0, 1]; the step is 100 / steps or 100 x a fraction in (0, 1): >= 0 unless the host passed a negative
                     // step count, which build_ray_params rejects — pow01_ is pow_ on that domain, bit for bit)
-                    const float a = (TBRM_RAY_EXP & 1) ? a_sat * step * 0.01f : 1.0f - pow01_(1.0f - a_sat, step);
-                    float l;
-                    if constexpr (TBRM_RAY_EXP & 2) l = gx;
-                    else if constexpr (LFMT == FMT_U8 && (TBRM_RAY_EXP & 128)) l = ltaps.filter_lut(s_u8, gx, gy, gz);
-                    else l = ltaps.filter(gx, gy, gz);
+                    const float a = 1.0f - pow01_(1.0f - a_sat, step);
+                    const float l = ltaps.filter(gx, gy, gz);
                     x = make_float4((cs.x * l) * a, (cs.y * l) * a, (cs.z * l) * a, a);
                 }
             }
@@ -396,45 +371,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         // the ray; the early exit belongs to the full steps only (:75-79). A trip in which no lane of the wave has
         // anything to accumulate (empty space, windowed-out values) needs no exchange.
         const bool any_x = __builtin_amdgcn_ballot_w64(x.w >= 0.0f || x.w != x.w) != 0;
-        if (any_x && (TBRM_RAY_EXP & 8)) {
-            if (!done && !(x.w < 0.0f)) {
-                const float om = 1.0f - le3;
-                le0 = le0 + (x.x * om); le1 = le1 + (x.y * om); le2 = le2 + (x.z * om); le3 = le3 + (x.w * om);
-                if (le3 > 0.95f && base < max_steps) { le3 = 1.0f; done = true; }
-            }
-        } else if (any_x && kRayLanes == 4 && (TBRM_RAY_EXP & 64)) {
-            // (A/B variant, measured and lost like the next one: the DPP replay without exec-mask regions — selects instead)
-            sweep4([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                const float cx = quad_bcast<t>(x.x), cy = quad_bcast<t>(x.y), cz = quad_bcast<t>(x.z), cw = quad_bcast<t>(x.w);
-                const bool use = !done && !(cw < 0.0f);
-                const float om = 1.0f - le3;
-                const float n0 = le0 + (cx * om), n1 = le1 + (cy * om), n2 = le2 + (cz * om), n3 = le3 + (cw * om);
-                const bool ex = use && n3 > 0.95f && base + t < max_steps;
-                le0 = use ? n0 : le0;
-                le1 = use ? n1 : le1;
-                le2 = use ? n2 : le2;
-                le3 = ex ? 1.0f : (use ? n3 : le3);
-                done = done || ex;
-            });
-        } else if (any_x && kRayLanes == 4 && (TBRM_RAY_EXP & 32)) {
-            // (A/B variant, round 4: the four lanes of a ray are one DPP quad, lane t's sample reaches the other three as
-            // quad_perm:[t,t,t,t] moves — no LDS round trip and no wave barrier on the serial part. Measured at config 3: 0.556 -
-            // 0.559 ms per frame against 0.539 - 0.551 for the LDS exchange below: sixteen v_mov_dpp issue slots per trip cost more
-            // than one ds_write_b128 + four ds_read_b128, whose latency the other five waves of the SIMD hide.)
-            sweep4([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                const float4 c = make_float4(quad_bcast<t>(x.x), quad_bcast<t>(x.y), quad_bcast<t>(x.z), quad_bcast<t>(x.w));
-                if (!done && !(c.w < 0.0f)) {
-                    const float om = 1.0f - le3;
-                    le0 = le0 + (c.x * om);
-                    le1 = le1 + (c.y * om);
-                    le2 = le2 + (c.z * om);
-                    le3 = le3 + (c.w * om);
-                    if (le3 > 0.95f && base + t < max_steps) { le3 = 1.0f; done = true; }
-                }
-            });
-        } else if (any_x) {
+        if (any_x) {
             s_x[threadIdx.x] = x;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -749,244 +686,6 @@ hipError_t launch_count_samples(const RayParams& p, hipStream_t s)
     if (p.tile_w <= 0 || p.tile_h <= 0) return hipSuccess;
     const dim3 grid((p.tile_w + 15) / 16, (p.tile_h + 15) / 16), block(256);
     hipLaunchKernelGGL(k_count_samples, grid, block, 0, s, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// empty-space-skipping metadata
-
-// Per brick b: min/max of every voxel a sample whose base tap lies in b can touch: [8b, 8b+8] per axis,
-// addressed like the raymarch sampler. NaN voxels poison the range to [-inf, +inf] (never skipped).
-template <int FMT, int MODE>
-__global__ __launch_bounds__(64) void k_brick_minmax(const BrickParams p)
-{
-    const int b = blockIdx.x;
-    const int bx = b % p.bnx, by = (b / p.bnx) % p.bny, bz = b / (p.bnx * p.bny);
-    if (bz < p.bz0 || bz >= p.bz1) { // slab-resident volumes: not held here
-        if (threadIdx.x == 0) p.minmax[b] = make_float2(-__builtin_inff(), __builtin_inff());
-        return;
-    }
-    float mn = __builtin_inff(), mx = -__builtin_inff();
-    bool nan = false;
-    for (int t = threadIdx.x; t < 9 * 9 * 9; t += 64) {
-        const int dx = t % 9, dy = (t / 9) % 9, dz = t / 81;
-        int x = bx * kBrick + dx, y = by * kBrick + dy, z = bz * kBrick + dz;
-        // the +8 tap only exists as the "+1" neighbour of an in-range base tap
-        if (x > p.data.nx || y > p.data.ny || z > p.data.nz) continue;
-        x = address<MODE>(x, p.data.nx);
-        y = address<MODE>(y, p.data.ny);
-        z = address<MODE>(z, p.data.nz);
-        const float v = load_voxel<FMT>(p.data.data, brick_off(x, y, z, p.data.bnx, p.data.bnxy));
-        if (v != v) nan = true;
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mn = fminf(mn, __shfl_down(mn, o, 64));
-        mx = fmaxf(mx, __shfl_down(mx, o, 64));
-        nan = nan || __shfl_down((int) nan, o, 64);
-    }
-    if (threadIdx.x == 0) p.minmax[b] = nan ? make_float2(-__builtin_inff(), __builtin_inff()) : make_float2(mn, mx);
-}
-
-hipError_t launch_brick_minmax(const BrickParams& p, hipStream_t s)
-{
-    const int n = p.bnx * p.bny * p.bnz;
-    if (n == 0) return hipSuccess;
-#define TBRM_BM(F, M) hipLaunchKernelGGL((k_brick_minmax<F, M>), dim3(n), dim3(64), 0, s, p)
-    const bool clamp = p.addr_mode == ADDR_CLAMP;
-    switch (p.data.fmt) {
-        case FMT_U8: if (clamp) TBRM_BM(FMT_U8, ADDR_CLAMP); else TBRM_BM(FMT_U8, ADDR_WRAP); break;
-        case FMT_U16: if (clamp) TBRM_BM(FMT_U16, ADDR_CLAMP); else TBRM_BM(FMT_U16, ADDR_WRAP); break;
-        default: if (clamp) TBRM_BM(FMT_F32, ADDR_CLAMP); else TBRM_BM(FMT_F32, ADDR_WRAP); break;
-    }
-#undef TBRM_BM
-    return hipGetLastError();
-}
-
-// A brick is empty when every value in [min,max] maps to corrected opacity 0: the TF position is monotone in
-// the value (width > 0), so it suffices that the part of [pos(min), pos(max)] that survives the cutoffs only
-// touches TF texels with alpha <= 0.
-__device__ __forceinline__ bool range_maps_to_zero_opacity(float vmin, float vmax, const WindowDev& win, const int* alpha_prefix)
-{
-    if (!(win.width > 0.0f && vmin <= vmax && vmin > -__builtin_inff() && vmax < __builtin_inff())) return false;
-    float lo = tf_position(vmin, win.center, win.width);
-    float hi = tf_position(vmax, win.center, win.width);
-    if (!(lo == lo && hi == hi)) return false;
-    bool all_cut = false;
-    if (win.low_cutoff > 0.0f) {
-        if (hi < 0.0f) all_cut = true;
-        lo = fmaxf(lo, 0.0f);
-    }
-    if (win.high_cutoff > 0.0f) {
-        if (lo > 1.0f) all_cut = true;
-        hi = fminf(hi, 1.0f);
-    }
-    if (all_cut) return true;
-    int i_lo, i_hi;
-    float f;
-    texel_split(lo, 256.0f, i_lo, f);
-    texel_split(hi, 256.0f, i_hi, f);
-    i_lo = min(max(i_lo, 0), 255);
-    i_hi = min(max(i_hi + 1, 0), 255);
-    return (alpha_prefix[i_hi + 1] - alpha_prefix[i_lo]) == 0;
-}
-
-__global__ __launch_bounds__(256) void k_brick_empty(const EmptyParams p)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    bool empty = false;
-    if (b < p.n_bricks) {
-        const float2 mm = p.minmax[b];
-        empty = range_maps_to_zero_opacity(mm.x, mm.y, p.win, p.alpha_prefix);
-    }
-    const unsigned long long m = __ballot(empty);
-    const int lane = threadIdx.x & 63;
-    if (b < p.n_bricks || true) {
-        if (lane == 0) p.bits[(blockIdx.x * 256 + threadIdx.x) >> 5] = (uint32_t) m;
-        if (lane == 32) p.bits[(blockIdx.x * 256 + threadIdx.x) >> 5] = (uint32_t) (m >> 32);
-    }
-}
-
-hipError_t launch_brick_empty(const EmptyParams& p, hipStream_t s)
-{
-    if (p.n_bricks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_brick_empty, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-// Is the volume's shell transparent to the light shaders? *flag (preset to 1) is cleared when some brick of the outer brick
-// layer can produce a non-zero opacity from a blend of its values (min/max over the brick and its apron) with the data
-// sampler's border colour. When it stays 1, every sample of a light pass whose position lies outside the unit cube — taps
-// in that layer and beyond it — has CurrentSample exactly 0 under the Change shader's rules (ChangeDirLightShader.usf
-// samples unconditionally), which is what the Add shader's uvw == saturate(uvw) guard makes it (AddDirLightShader.usf:98):
-// the two shaders then propagate the same values for a light, and the contribution cache may serve either from the other's.
-__global__ __launch_bounds__(256) void k_shell_transparent(const EmptyParams p, int bnx, int bny, int bnz, float border, int* flag)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= p.n_bricks) return;
-    const int bx = b % bnx, by = (b / bnx) % bny, bz = b / (bnx * bny);
-    if (bx != 0 && bx != bnx - 1 && by != 0 && by != bny - 1 && bz != 0 && bz != bnz - 1) return;
-    const float2 mm = p.minmax[b];
-    if (!range_maps_to_zero_opacity(fminf(mm.x, border), fmaxf(mm.y, border), p.win, p.alpha_prefix)) *flag = 0;
-}
-
-hipError_t launch_shell_transparent(const EmptyParams& p, int bnx, int bny, int bnz, float border, int* flag, hipStream_t s)
-{
-    if (p.n_bricks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_shell_transparent, dim3((p.n_bricks + 255) / 256), dim3(256), 0, s, p, bnx, bny, bnz, border, flag);
-    return hipGetLastError();
-}
-
-// ---- empty-space leaping: Chebyshev distance (in bricks) to the nearest non-empty brick -------------------------
-// D(b) = the largest t <= kSkipDistCap such that every brick within Chebyshev distance < t of b is empty (0: b itself
-// is not). Erosion by a cube is separable, so three 1D passes give the exact value: T_x = distance along x to the
-// nearest non-empty brick; T_xy(b) = max{t : T_x(b + dy) >= t for all |dy| < t}; the same along z. Neighbour indices
-// follow the raymarch sampler's addressing (wrap: a torus; clamp: the edge brick repeats).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_brick_dist(const DistParams p)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    const int nb = p.bn[0] * p.bn[1] * p.bn[2];
-    if (b >= nb) return;
-    int c[3] = {b % p.bn[0], (b / p.bn[0]) % p.bn[1], b / (p.bn[0] * p.bn[1])};
-    const int stride = p.axis == 0 ? 1 : (p.axis == 1 ? p.bn[0] : p.bn[0] * p.bn[1]);
-    const int n = p.axis == 0 ? p.bn[0] : (p.axis == 1 ? p.bn[1] : p.bn[2]);
-    const int c0 = p.axis == 0 ? c[0] : (p.axis == 1 ? c[1] : c[2]);
-    const int row = b - c0 * stride;
-    auto value = [&](int ci) -> int { // the previous pass's T at coordinate ci of this row (pass 0: 0 / cap from the bits)
-        ci = address<MODE>(ci, n);
-        const int q = row + ci * stride;
-        if (p.in) return p.in[q];
-        return ((p.bits[q >> 5] >> (q & 31)) & 1u) ? kSkipDistCap : 0;
-    };
-    int t = value(c0);
-    for (int d = 1; d < t; ++d) {
-        const int m = min(value(c0 - d), value(c0 + d));
-        t = min(t, max(m, d));
-    }
-    p.out[b] = (uint8_t) t;
-}
-
-hipError_t launch_brick_dist(const DistParams& p, int addr_mode, hipStream_t s)
-{
-    const int nb = p.bn[0] * p.bn[1] * p.bn[2];
-    const dim3 grid((nb + 255) / 256), block(256);
-    if (addr_mode == ADDR_CLAMP) hipLaunchKernelGGL(k_brick_dist<ADDR_CLAMP>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(k_brick_dist<ADDR_WRAP>, grid, block, 0, s, p);
-    return hipGetLastError();
-}
-
-__global__ void k_selftest_decode(float* u8, float* u16)
-{
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < 256) u8[c] = decode_u8(c);
-    if (c < 65536) u16[c] = decode_u16(c);
-}
-__global__ void k_selftest_roundtrip(const float* in, float* out, size_t n)
-{
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = through_format<FMT_U8>(in[i]);
-}
-hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_selftest_roundtrip, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, d_in, d_out, n);
-    return hipGetLastError();
-}
-hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_selftest_decode, dim3(256), dim3(256), 0, s, d_u8, d_u16);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// linear (UVolumeTexture mip, x fastest) <-> bricked. One workgroup moves a run of 16 bricks along x (128 x 8 x 8 voxels)
-// through LDS: the linear side is read / written as 64 rows of 128 consecutive voxels (128-512 bytes each, consecutive lanes
-// on consecutive voxels), the bricked side as ONE contiguous run of 16 bricks with 16-byte accesses (bricks that follow each
-// other along x follow each other in memory). (Round 1 moved one brick per workgroup, i.e. 8-voxel row fragments on the linear
-// side: 8x read amplification by the FETCH_SIZE counter.)
-constexpr int kRelayoutSeg = 16; // bricks per workgroup
-template <typename E>
-__global__ __launch_bounds__(256) void k_relayout(const RelayoutParams p)
-{
-    __shared__ __attribute__((aligned(16))) E s_run[kRelayoutSeg * 512];
-    const int segs = (p.bnx + kRelayoutSeg - 1) / kRelayoutSeg;
-    const int b = blockIdx.x;
-    const int seg = b % segs, by = (b / segs) % (p.bnxy / p.bnx), bz = b / (segs * (p.bnxy / p.bnx));
-    const int bx0 = seg * kRelayoutSeg, nb = min(kRelayoutSeg, p.bnx - bx0);
-    E* bricked = (E*) (p.to_bricks ? p.dst : const_cast<void*>(p.src)) + ((size_t) bz * p.bnxy + (size_t) by * p.bnx + bx0) * 512;
-    E* linear = (E*) (p.to_bricks ? const_cast<void*>(p.src) : p.dst);
-    constexpr int V = 16 / (int) sizeof(E); // voxels per 16-byte access
-    const int run = nb * 512;
-    if (!p.to_bricks) { // bricked -> LDS
-        for (int i = threadIdx.x * V; i < run; i += 256 * V) *(uint4*) (s_run + i) = *(const uint4*) (bricked + i);
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < 64 * 128; i += 256) { // row (y, z) of the run, voxel xl along it
-        const int row = i >> 7, xl = i & 127;
-        const int x = bx0 * 8 + xl, y = by * 8 + (row & 7), z = bz * 8 + (row >> 3);
-        if ((xl >> 3) >= nb) continue;
-        const bool in = x < p.nx && y < p.ny && z < p.nz;
-        const size_t li = ((size_t) z * p.ny + y) * (size_t) p.nx + x;
-        const int si = (xl >> 3) * 512 + (row << 3) + (xl & 7);
-        if (p.to_bricks) s_run[si] = in ? linear[li] : E(0); // padding voxels are zeroed
-        else if (in) linear[li] = s_run[si];
-    }
-    if (p.to_bricks) { // LDS -> bricked
-        __syncthreads();
-        for (int i = threadIdx.x * V; i < run; i += 256 * V) *(uint4*) (bricked + i) = *(const uint4*) (s_run + i);
-    }
-}
-
-hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s)
-{
-    const int segs = (p.bnx + kRelayoutSeg - 1) / kRelayoutSeg;
-    const int n = segs * (p.bnxy / (p.bnx > 0 ? p.bnx : 1)) * p.bnz;
-    if (n == 0) return hipSuccess;
-    if (p.elem_bytes == 1) hipLaunchKernelGGL(k_relayout<uint8_t>, dim3(n), dim3(256), 0, s, p);
-    else if (p.elem_bytes == 2) hipLaunchKernelGGL(k_relayout<uint16_t>, dim3(n), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_relayout<uint32_t>, dim3(n), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

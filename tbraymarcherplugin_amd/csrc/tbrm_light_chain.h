@@ -1,5 +1,5 @@
 // tbrm_light_chain.h — what the chain kernel (tbrm_light_chain.hip), the occlusion kernel (tbrm_light_kernels.hip) and
-// the host-side planner (tbrm_light_passes.cpp) have to agree on: the window geometry of a chain workgroup, the shape of
+// the host-side planner (tbrm_light_plan.cpp) have to agree on: the window geometry of a chain workgroup, the shape of
 // its LDS planes and the global->LDS copy helpers. Internal.
 #pragma once
 #include "tbrm_internal.h"

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
     // volume — and stage the same halo bricks — run behind the same L2.
     //
     // The grid may be smaller than the work (a launch that runs beside the chain of the previous span on the occlusion
-    // stream, tbrm_light_passes.cpp, holds only as many workgroups as fit next to the chain's on every CU, all resident from
+    // stream, tbrm_light_enqueue.cpp, holds only as many workgroups as fit next to the chain's on every CU, all resident from
     // the start, so none is ever waiting to take a slot the next chain launch needs): a workgroup then walks its XCD's
     // eighth with the stride of the grid.
     const int groups = (p.n_steps + kOccDepth - 1) / kOccDepth;
@@ -414,10 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
     if (!p.occ_list && p.occ_flags && p.occ_flags[id]) continue; // list off (A/B runs)
     if (gy < p.roi_by0 || gy >= p.roi_by1) continue;             // dense span of a slab-partitioned pass
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
-#ifndef TBRM_OCC_EXP
-#define TBRM_OCC_EXP 0 // timing experiments (WRONG results): 1 = no sample loop (what the per-workgroup setup costs), 2 = no brick staging, 4 = write-through (sc1) factor stores (results right)
-#endif
-    const int nk = (TBRM_OCC_EXP & 1) ? 0 : min(kOccDepth, p.n_steps - k0);
+    const int nk = min(kOccDepth, p.n_steps - k0);
 
     s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
     if (threadIdx.x < NS * kOccDepth) { // slice-axis taps of each step of this workgroup (wave-uniform values)
@@ -487,7 +484,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
         const int wave_base = (threadIdx.x >> 6) * 64, lane = threadIdx.x & 63;
         for (int cb = wave_base; cb < total; cb += 256) {
             const int c = cb + lane;
-            if (c < total && !(TBRM_OCC_EXP & 2)) {
+            if (c < total) {
                 const uint32_t gb = s_brick[c / PIECES];
                 dma_16((const char*) p.data.data + ((size_t) gb * 512 * ESZ + (size_t) (c % PIECES) * 16), smem + (size_t) cb * 16);
             }
@@ -633,8 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                 }
                 float occ = 0.0f;
                 if (aw > 0.0f && inside) occ = windowed_alpha<DFMT != FMT_F32>(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
-                if constexpr (TBRM_OCC_EXP & 4) __hip_atomic_store(out + q * out_step, 1 - occ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (write-through: what a finer hand-over to the sweep would need)
-                else out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
+                out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }
         }
     };

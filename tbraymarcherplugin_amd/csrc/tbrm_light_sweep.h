@@ -1,5 +1,5 @@
 // tbrm_light_sweep.h — what k_light_sweep (tbrm_light_sweep.hip, compiled as one translation unit per mode and tile height)
-// and the host-side planner (tbrm_light_passes.cpp) have to agree on: tile shape, LDS budget, hand-off record layout. Internal.
+// and the host-side planner (tbrm_light_plan.cpp) have to agree on: tile shape, LDS budget, hand-off record layout. Internal.
 #pragma once
 #include "tbrm_internal.h"
 

@@ -46,12 +46,6 @@
 #include <type_traits>
 #include <utility>
 
-// Timing ablations of the slice loop (tools/sweep_ablation.sh builds one library per value; results are WRONG, only the
-// sweep_debug = 1 timings mean anything): 1 no light-volume update, 2 no factor loads, 4 idle hand-off wave, 8 no barrier.
-#ifndef TBRM_SWEEP_EXP
-#define TBRM_SWEEP_EXP 0
-#endif
-
 namespace tbrm {
 
 template <class F, int... S>
@@ -354,7 +348,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                 bool reinit = false;
                 if constexpr (FIRST) reinit = K8 + 1 == q.reinit_slice;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
-                if (PUB && (TBRM_SWEEP_EXP & 4) == 0 && s > 0) {
+                if (PUB && s > 0) {
                     uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RWS));
 #pragma unroll
                     for (int h = 0; h < HC; ++h)
@@ -406,8 +400,8 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         }
                     }
                 }
-                if constexpr (CON && (!LAST || K8 + PF <= 6) && !(TBRM_SWEEP_EXP & 4)) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
-                if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
+                if constexpr (CON && (!LAST || K8 + PF <= 6)) request_halo(s + PF, std::integral_constant<int, (K8 + PF) & 7>{});
+                lds_barrier();
             }, std::make_integer_sequence<int, 8>{});
         };
         if (q.reinit_slice > 0) group(0, std::true_type{}, std::false_type{}); // (G >= 2: the launcher's check)
@@ -447,7 +441,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
         int req = 0;       // slice requested next
         int req_slot = 0;  // its ring slot
         auto request = [&]() {
-            if constexpr (!(TBRM_SWEEP_EXP & 2)) {
+            {
                 const uint32_t dst = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t) req_slot * (uint32_t) (kFSlot * 4));
 #pragma unroll
                 for (int b = 0; b < NB; ++b) sweep_dma_block(src[b], dst + (uint32_t) (b * kSweepFBlock * 4));
@@ -473,7 +467,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
         for (int s = 0; s < n; ++s) {
             request(); // slice s + A, into the slot slice s - 1 was read from
             landed();  // slice s + 1
-            if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
+            lds_barrier();
         }
         sweep_wait_loads<0>();
     } else {
@@ -634,8 +628,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                 const float* const f_at = f_lane + (K8 % FS) * kFSlot;
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
-                    if constexpr (TBRM_SWEEP_EXP & 2) fac[si] = (v2f) 1.0f;
-                    else { fac[si].x = f_at[si * NB * kSweepFBlock]; fac[si].y = f_at[si * NB * kSweepFBlock + 16]; }
+                    fac[si].x = f_at[si * NB * kSweepFBlock]; fac[si].y = f_at[si * NB * kSweepFBlock + 16];
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const float* const pt = plane(CUR, si) + tap[si][k];
@@ -643,7 +636,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         cb[si][k].x = pt[CS]; cb[si][k].y = pt[CS + 1];
                     }
                 }
-                if constexpr (LVS && !(TBRM_SWEEP_EXP & 1))
+                if constexpr (LVS)
                     if (K8 > 0 || g > 0) light_volume_update(code_old);
                 // this slice, operation by operation over the streams: a slice is one dependent chain per stream, and the two
                 // chains of a Change are independent — side by side they fill each other's issue gaps
@@ -667,7 +660,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
 #pragma unroll
                 for (int si = 0; si < NS; ++si) lv_l[si] = xa[si] * fac[si];
                 if constexpr (F32) { // a float buffer returns what was written (:120); the light volume takes L at once
-                    if constexpr (LV && !(TBRM_SWEEP_EXP & 1)) {
+                    if constexpr (LV) {
                         bool real = true; // (not the slices in front of a ragged downward pass: SweepParams::reinit_slice)
                         if constexpr (FIRST) real = K8 >= q.reinit_slice;
                         if (real) lv_update_f32(g * 8 + K8, lv_l);
@@ -708,7 +701,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         if (in_pl[1]) stream(si).plane_out[own_idx[1]] = pval[si].y;
                     }
                 }
-                if constexpr (!(TBRM_SWEEP_EXP & 8)) lds_barrier();
+                lds_barrier();
             }, std::make_integer_sequence<int, 8>{});
         };
         __builtin_amdgcn_s_setprio(2); // (ahead of any occlusion workgroup that shares the CU: this loop is one dependent chain)
@@ -764,10 +757,6 @@ static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipS
         }
         return hipErrorInvalidConfiguration;
     }
-#if TBRM_SWEEP_EXP
-    if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH>(p, q, s);
-    return hipErrorInvalidConfiguration;
-#endif
     if constexpr (MODE == PASS_CHANGE) {
         if (q.r_from_records) { // (sweep_fit: both streams' words fit three per lane)
             const int hc2 = std::max(hc, sweep_halo_chunks(q.r_hx, q.r_hy, TH));

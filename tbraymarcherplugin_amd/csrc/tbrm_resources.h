@@ -1,6 +1,6 @@
 // tbrm_resources.h — what the host side of the library shares between its translation units: the handle behind the
 // C-ABI's opaque tbrm_resources, error reporting, and the light-pass layer (planning and enqueueing the axis passes of the
-// Add / Change operators, tbrm_light_passes.cpp) that tbrm_api.cpp's entry points drive. Internal; not installed.
+// Add / Change operators, tbrm_light_plan.cpp / tbrm_light_enqueue.cpp / tbrm_light_operators.cpp) that tbrm_api.cpp's entry points drive. Internal; not installed.
 #pragma once
 
 #include "../../include/tbrm.h"
@@ -252,8 +252,10 @@ void fill_stream(PropStream& s, const tbrm_light_pass& p);
 int begin_timed(tbrm_resources* r, int kind);
 int end_timed(tbrm_resources* r, int kind);
 int ensure_skipping(tbrm_resources* r);
+int raymarch_clip_mode(const float cc[3], const float cd[3]);
+RelayoutParams relayout_params(const void* src, void* dst, const int dims[3], const int bn[3], size_t elem, bool to_bricks);
 
-// ---- the light-pass layer (tbrm_light_passes.cpp) ------------------------------------------------------------------------
+// ---- the light-pass layer (tbrm_light_plan.cpp, tbrm_factor_cache.cpp, tbrm_light_enqueue.cpp, tbrm_light_operators.cpp) ------------------------------------------------------------------------
 // Range of (tap index - pixel index) of the previous-slice bilinear fetch over one buffer axis, evaluated with the
 // kernel's own fp32 sequence (texel_split of ((c+0.5)/size + offset)); hi includes the +1 tap.
 struct TapRange { int lo = 0, hi = 0; bool ok = false; };

@@ -3,21 +3,9 @@
 # prints the counts for the benchmark's frame: tools/ray_stats.sh build | run
 set -e
 cd "$(dirname "$0")/.."
-CS=tbraymarcherplugin_amd/csrc
 OUT=tools/tmp/exp
 if [ "${1:-build}" = build ]; then
-  python -c "from tbraymarcherplugin_amd import build as tb; tb.build(verbose=False)"
-  mkdir -p $OUT
-  FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -Wno-unused-function"
-  for u in tbrm_api tbrm_light_passes tbrm_host_math; do hipcc $FLAGS -c -x hip $CS/$u.cpp -o $OUT/$u.o & done
-  hipcc $FLAGS -DTBRM_RAY_STATS -c -x hip $CS/tbrm_kernels.hip -o $OUT/tbrm_kernels.o &
-  hipcc $FLAGS -c -x hip $CS/tbrm_light_kernels.hip -o $OUT/lk.o &
-  hipcc $FLAGS -c -x hip $CS/tbrm_light_sweep.hip -o $OUT/sweep.o &
-  hipcc $FLAGS -DTBRM_CHAIN_LFMT=0 -c -x hip $CS/tbrm_light_chain.hip -o $OUT/chain_u8.o &
-  hipcc $FLAGS -DTBRM_CHAIN_LFMT=2 -c -x hip $CS/tbrm_light_chain.hip -o $OUT/chain_f32.o &
-  wait
-  hipcc --offload-arch=gfx950 -shared -fPIC -fvisibility=hidden $OUT/tbrm_api.o $OUT/tbrm_light_passes.o $OUT/tbrm_host_math.o $OUT/tbrm_kernels.o $OUT/lk.o $OUT/chain_u8.o $OUT/chain_f32.o $OUT/sweep.o -o $OUT/libtbrm_raystats.so
-  rm -f $OUT/*.o
+  python tools/build_variant.py raystats --only tbrm_kernels -DTBRM_RAY_STATS
 else
   TBRM_LIB_PATH=$PWD/$OUT/libtbrm_raystats.so python - <<'PY'
 import ctypes as C, os, sys
