@@ -198,6 +198,8 @@ struct SweepParams {
     int reinit_slice;       // > 0: the launch's first reinit_slice slices lie in front of the volume (a pass that runs downwards from a
                             // depth that is no multiple of 8, padded to whole brick layers): slice reinit_slice - 1 hands on the pass's
                             // initial plane instead of what it computed
+    int n_real;             // slices of the launch that lie inside the volume when the padding comes last (an upward pass whose depth is
+                            // no multiple of 8): the slices from n_real on leave the light volume alone. n_steps: none are padding
     int* error;             // set when a tile gave up waiting (bit 0) or found its taps outside the halo (bit 1)
     unsigned long long give_up_ticks; // how long a poll waits for a neighbour's word, in 10 ns ticks of wall_clock64 (tunable sweep_timeout_ms)
 };

@@ -71,16 +71,20 @@ static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<Pas
         probe.lap("plan");
     }
     r->op_many_passes = specs.size() > 2;
-    std::vector<char> is_second(specs.size(), 0);
+    // A pair is ONE entry of the schedule the caller was given (enqueue_add_batch: light a's pass, then light b's, voxel by voxel):
+    // whether the two passes share a sweep or — should one of them not be on the sweep after all, or the pair not fit one tile
+    // order — run one after the other, the partner takes its turn HERE, right behind the first, never at its own later index.
+    std::vector<char> is_second(specs.size(), 0), pair_sweeps(specs.size(), 0);
     if (partner.size() != specs.size()) partner.assign(specs.size(), -1); // (also after an ADD2 spec was split: chain batches carry none)
     for (size_t i = 0; i < specs.size(); ++i) {
         const int j = partner[i];
-        // a pair needs both passes on the sweep; anything else: each on its own
-        if (j < 0 || (size_t) j >= specs.size() || !chunked[i] || !chunked[(size_t) j] || !plans[i].sweep || !plans[(size_t) j].sweep) partner[i] = -1;
-        else is_second[(size_t) j] = 1;
+        if (j < 0 || (size_t) j >= specs.size() || (size_t) j == i || is_second[i]) { partner[i] = -1; continue; }
+        is_second[(size_t) j] = 1;
+        // sharing a sweep needs both passes on the sweep
+        pair_sweeps[i] = chunked[i] && chunked[(size_t) j] && plans[i].sweep && plans[(size_t) j].sweep;
     }
     bool any_pair = false;
-    for (int j : partner) any_pair = any_pair || j >= 0;
+    for (size_t i = 0; i < specs.size(); ++i) any_pair = any_pair || (partner[i] >= 0 && pair_sweeps[i]);
     if (any_pair) // (a group of two lights: four passes, four scratch buffers — every occlusion can go first)
         for (size_t k = 0; k < specs.size(); ++k) {
             if (!chunked[k]) continue;
@@ -88,26 +92,14 @@ static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<Pas
                                                                                                        : enqueue_sweep_occlusion(r, plans[k]);
             if (e) { quiesce_occ_stream(r); return e; }
         }
-    for (size_t i = 0; i < specs.size(); ++i) {
+    auto run_single = [&](size_t i) -> int {
         const PassSpec& q = specs[i];
-        if (is_second[i]) continue; // (swept together with its partner)
-        if (partner[i] >= 0) {
-            const size_t j = (size_t) partner[i];
-            SweepFit fit;
-            if (sweep_fit(r, specs[i].a, &specs[j].a, PASS_CHANGE, fit) && !fit.two_way) {
-                if (int e = enqueue_sweep_pair(r, plans[i], plans[j], fit)) { quiesce_occ_stream(r); return e; }
-                r->passes[0] += 2;
-                probe.lap("pair");
-                continue;
-            }
-            is_second[j] = 0; // (does not fit after all: both on their own, in the order given)
-        }
         if (!chunked[i]) {
             PropParams p = base;
             p.b_added = q.b_added;
             if (int e = enqueue_pass_sliced(r, p, q.a, q.two ? &q.r : nullptr)) return e;
             ++r->passes[2];
-            continue;
+            return TBRM_OK;
         }
         ++r->passes[plans[i].sweep ? 0 : 1];
         const PassPlan* next = i + 1 < specs.size() && chunked[i + 1] ? &plans[i + 1] : nullptr;
@@ -124,6 +116,24 @@ static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<Pas
         for (int c = 0; c < plans[i].n_chunks; ++c)
             if (int e = enqueue_plan_chunk(r, plans[i], c, next)) return e; // (enqueue_plan_chunk has drained the second stream)
         probe.lap("pass");
+        return TBRM_OK;
+    };
+    for (size_t i = 0; i < specs.size(); ++i) {
+        if (is_second[i]) continue; // (took its turn with its partner)
+        if (partner[i] >= 0) {
+            const size_t j = (size_t) partner[i];
+            SweepFit fit;
+            if (pair_sweeps[i] && sweep_fit(r, specs[i].a, &specs[j].a, PASS_CHANGE, fit) && !fit.two_way) {
+                if (int e = enqueue_sweep_pair(r, plans[i], plans[j], fit)) { quiesce_occ_stream(r); return e; }
+                r->passes[0] += 2;
+                probe.lap("pair");
+                continue;
+            }
+            if (int e = run_single(i)) return e; // (no shared sweep after all: the same two passes, in the same order)
+            if (int e = run_single(j)) return e;
+            continue;
+        }
+        if (int e = run_single(i)) return e;
     }
     if (r->occ_stream) { // "this operator's sweeps are done" (wait_for_readers)
         const int k = (int) (r->op_serial % tbrm_resources::kOpEvents);

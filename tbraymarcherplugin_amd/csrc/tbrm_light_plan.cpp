@@ -565,6 +565,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : 1500;
     q.debug = tune(TUNE_SWEEP_DEBUG);
     q.reinit_slice = pa.dir < 0 ? pad : 0;
+    q.n_real = pa.dir > 0 ? D - pad : D;
     q.lv_f32 = r->lv_fmt != FMT_U8 ? 1 : 0;
     plan.rec_words = words;
     {

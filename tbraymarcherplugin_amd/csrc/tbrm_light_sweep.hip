@@ -661,8 +661,10 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                 for (int si = 0; si < NS; ++si) lv_l[si] = xa[si] * fac[si];
                 if constexpr (F32) { // a float buffer returns what was written (:120); the light volume takes L at once
                     if constexpr (LV) {
-                        bool real = true; // (not the slices in front of a ragged downward pass: SweepParams::reinit_slice)
+                        bool real = true; // (not the slices a ragged pass is padded with: in front of a downward pass,
+                                          // SweepParams::reinit_slice, behind an upward one, SweepParams::n_real)
                         if constexpr (FIRST) real = K8 >= q.reinit_slice;
+                        if constexpr (LAST) real = g * 8 + K8 < q.n_real;
                         if (real) lv_update_f32(g * 8 + K8, lv_l);
                     }
 #pragma unroll
@@ -694,6 +696,15 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                     plane(CUR ^ 1, si)[own[1]] = in_pl[1] ? pval[si].y : st.border_light;
                 }
                 lv_prev = lv_layer + (uint32_t) (down ? 7 - K8 : K8) * kLvStep;
+                if constexpr (LVS && (FIRST || LAST)) { // the slices a ragged pass is padded with leave the padding voxels as they are
+                    bool pad = false;               // (their factors were never computed: k_light_occlusion walks the volume's own slices)
+                    if constexpr (FIRST) pad = K8 < q.reinit_slice;
+                    if constexpr (LAST) pad = g * 8 + K8 >= q.n_real;
+                    if (pad) {
+#pragma unroll
+                        for (int si = 0; si < NS; ++si) lv_l[si] = (v2f) 0.0f;
+                    }
+                }
                 if constexpr (LV && LAST && K8 == 7) { // the state the next span starts from
 #pragma unroll
                     for (int si = 0; si < NS; ++si) {

@@ -20,6 +20,7 @@ hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mo
     if (!aligned || !p.compact || !p.ones || !p.a.fs_slot || (sweep_two_streams(mode) && !p.r.fs_slot)) return hipErrorInvalidConfiguration;
     if (q.r_from_records && (mode != PASS_CHANGE || !q.rec[1])) return hipErrorInvalidConfiguration;
     if (q.reinit_slice < 0 || q.reinit_slice > 7 || (q.reinit_slice > 0 && p.n_steps < 16)) return hipErrorInvalidConfiguration;
+    if (q.n_real > p.n_steps || q.n_real <= p.n_steps - 8) return hipErrorInvalidConfiguration; // (padding: less than one brick layer)
     if (q.tile_rows != 16 && q.tile_rows != 32) return hipErrorInvalidConfiguration;
     if (p.tiles_x != (p.W + kSweepTile - 1) / kSweepTile || p.tiles_y != (p.H + q.tile_rows - 1) / q.tile_rows) return hipErrorInvalidConfiguration;
     const bool half = q.tile_rows == 16;

@@ -104,3 +104,41 @@ def test_example_renders_an_mhd_file(tmp_path, gpu):
     mean_alpha = float(p.stdout.split("mean alpha")[1].split(")")[0])
     assert 0.01 < mean_alpha < 0.95
     assert np.frombuffer(data[-96 * 64 * 3:], dtype=np.uint8).max() > 20    # something lit is visible
+
+
+TILES_SRC = os.path.join(ROOT, "tests", "cpp", "tiles_test.cpp")
+
+
+def build_tiles(tmp_path, rccl=False):
+    exe = str(tmp_path / ("tiles_test_rccl" if rccl else "tiles_test"))
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__"] + (["-DTBRM_TILES_WITH_RCCL"] if rccl else []) +
+                   ["-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", TILES_SRC, "-o", exe, "-L", LIB_DIR, "-ltbrm", "-L", "/opt/rocm/lib",
+                    "-lamdhip64"] + (["-lrccl"] if rccl else []) + [f"-Wl,-rpath,{LIB_DIR}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_tile_driver_compiles_and_links_with_gxx(tmp_path, abi_mod, rccl):
+    """include/tbrm_tiles.hpp (FTileGroup: N handles in one process, interleaved 8-row tiles, gather by peer copies or — linked
+    from C++ — RCCL's ncclAllGather)"""
+    assert os.path.exists(build_tiles(tmp_path, rccl))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_handles,mode", [(2, 0), (4, 0), (3, 1), (4, 1), (1, 0)])
+def test_tile_driver_on_gpu(tmp_path, gpu, n_handles, mode):
+    """N whole-volume handles driven from C++ on one GPU: a light turns on every replica, each marches its interleaved rows, the tiles
+    are gathered to one handle (mode 0) or to all (1) by copies ordered with events only — light volumes and frames bit-identical
+    to one handle doing everything alone, four steps back to back"""
+    p = subprocess.run([build_tiles(tmp_path), str(n_handles), str(mode)], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
+    assert f"light volumes: 0 of {n_handles} replicas differ" in p.stdout and "frames: 0 differ" in p.stdout
+
+
+@pytest.mark.gpu
+def test_tile_driver_gathers_with_rccl_from_cpp(tmp_path, gpu):
+    """the same with the gather as ncclAllGather on the handles' own streams (one communicator per handle, ncclCommInitAll): what
+    a box with ONE GPU can run of it is a group of one — RCCL refuses two ranks on one device"""
+    p = subprocess.run([build_tiles(tmp_path, True), "1", "2"], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
+    assert "frames: 0 differ" in p.stdout

@@ -556,3 +556,37 @@ def test_float_light_volumes_are_swept(gpu, oracle_mod, tunables, dims, cache):
         assert p["passes_sweep"] > 0 and p["passes_slice"] == 0, p
         # (a float pass of more than three hand-off words per lane, or whose lights pull two ways, still takes the chain)
         assert p["passes_chain"] <= p["passes_sweep"] // 8, p
+
+
+@pytest.mark.parametrize("light_32bit", [False, True])
+def test_padding_voxels_of_a_ragged_light_volume_are_left_alone(gpu, oracle_mod, light_32bit):
+    """The bricked light volume has voxels beyond the volume's own (whole 8 x 8 x 8 bricks), and a ragged pass is swept over whole
+    brick layers: the slices it is padded with — whose occlusion factors nobody computed — must not write there. The raw tensor is
+    what tbrm_light_volume_device_ptr and the multi-GPU combine hand out: garbage (NaNs, in a float volume) would travel."""
+    from tbraymarcherplugin_amd import sharding
+
+    dims = (67, 45, 53)
+    vol = S.make_volume_numpy(dims, np.uint16, 0x5EED0C11)
+    res = abi.Resources(dims, abi.FMT_G16, light_32bit)
+    world = S.default_world()
+    with res:
+        res.upload_volume(vol)
+        res.set_tf_lut(abi.color_curve_to_lut(S.TF_A_KEYS))
+        res.set_windowing(abi.WindowingParams(0.5, 0.9, True, False))
+        res.clear_light_volume(0.25)
+        for d in [(1, .35, -.5), (-.4, 1, -.3), (.2, -.3, -1), (-1, -.6, .4), (.6, -1, -.2), (-.3, .2, 1)]:
+            res.add_dir_light(abi.DirLightParams(d, 0.1), True, world)
+        res.flush()
+        p = res.path_counters()
+        assert p["passes_sweep"] == 12 and p["passes_chain"] == 0 and p["passes_slice"] == 0, p
+        raw = sharding.device_light_tensor(res).cpu().numpy()
+    nx, ny, nz = dims  # (x fastest)
+    bn = [(n + 7) // 8 for n in (nx, ny, nz)]
+    bricks = raw.reshape(bn[2], bn[1], bn[0], 8, 8, 8)  # [bz][by][bx][z][y][x]
+    dense = bricks.transpose(0, 3, 1, 4, 2, 5).reshape(bn[2] * 8, bn[1] * 8, bn[0] * 8)
+    inside = np.zeros(dense.shape, dtype=bool)
+    inside[:nz, :ny, :nx] = True
+    clear = np.float32(0.25) if light_32bit else np.uint8(64)  # trunc(0.25 * 255 + 0.5)
+    pad = dense[~inside]
+    assert np.all(pad == clear), f"{np.count_nonzero(pad != clear)} of {pad.size} padding voxels changed (e.g. {pad[pad != clear][:4]})"
+    assert np.any(dense[inside] != clear)
