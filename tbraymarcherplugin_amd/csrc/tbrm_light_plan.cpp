@@ -92,7 +92,7 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
     }
     const int th = sweep_tile_rows();
     if (!opposite) return fit.hx <= 14 && fit.hy <= 14 && sweep_halo_chunks(fit.hx, fit.hy, th) <= (f32 ? 3 : 6);
-    if (tune(TUNE_LIGHT_SWEEP) == 2 || f32) return false; // (diagnostics: such passes take the chain, as before round 3's last week)
+    if (tune(TUNE_LIGHT_SWEEP) == 2) return false; // (diagnostics: such passes take the chain, as before round 3's last week)
     fit.two_way = true;
     fit.sx = side[0][0].side; fit.hx = side[0][0].reach; fit.sy = side[0][1].side; fit.hy = side[0][1].reach;
     fit.r_sx = side[1][0].side; fit.r_hx = side[1][0].reach; fit.r_sy = side[1][1].side; fit.r_hy = side[1][1].reach;
@@ -103,7 +103,7 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
         for (int si = 0; si < 2; ++si) (side[si][ax].side < 0 ? lo : hi) = std::max(side[si][ax].side < 0 ? lo : hi, side[si][ax].reach);
         room[ax] = lo + hi;
     }
-    return room[0] <= 14 && room[1] <= 14 && sweep_halo_chunks(fit.hx, fit.hy, th) <= 6 && sweep_halo_chunks(fit.r_hx, fit.r_hy, th) <= 6;
+    return room[0] <= 14 && room[1] <= 14 && sweep_halo_chunks(fit.hx, fit.hy, th) <= (f32 ? 3 : 6) && sweep_halo_chunks(fit.r_hx, fit.r_hy, th) <= (f32 ? 3 : 6);
 }
 
 void release_sweep(tbrm_resources* r)
@@ -554,7 +554,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.r_sx = sfit.r_sx; q.r_sy = sfit.r_sy; q.r_hx = sfit.r_hx; q.r_hy = sfit.r_hy;
     q.tile_rows = sweep_tile_rows(); // (the sweep's tiles: 32 wide, 16 or 32 high)
     p.tiles_y = ceil_div(p.H, q.tile_rows);
-    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.hx, sfit.hy, q.tile_rows) * (size_t) (r->lv_fmt != FMT_U8 && change ? 2 : 1);
+    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.hx, sfit.hy, q.tile_rows) * (size_t) (r->lv_fmt != FMT_U8 && change && !sfit.two_way ? 2 : 1); // (float records: a word per stream handed over)
     const size_t words1 = sfit.two_way ? (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.r_hx, sfit.r_hy, q.tile_rows) : 0;
     if (words >= ((size_t) 1 << 32) || words1 >= ((size_t) 1 << 32)) return declined("hand-off records too large");
     if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words1)) return e;
@@ -568,6 +568,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.n_real = pa.dir > 0 ? D - pad : D;
     q.lv_f32 = r->lv_fmt != FMT_U8 ? 1 : 0;
     plan.rec_words = words;
+    plan.rec1_words = words1;
     {
         const int ms = tune(TUNE_SWEEP_TIMEOUT_MS);
         q.give_up_ticks = ms < 0 ? 0ull : (unsigned long long) (ms == 0 ? 2000 : ms) * 100000ull;

@@ -139,9 +139,10 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
     constexpr bool LV = MODE != PASS_PLANES; // the light volume is updated
     constexpr bool F32 = LFMT == FMT_F32;
     constexpr bool LVS = LV && !F32;         // ... through brick layers staged in LDS
-    constexpr int NSW = F32 ? NS : 1;        // hand-off words per cell
+    constexpr int NSH = RREC ? 1 : NS;       // streams handed over from tile to tile in this launch (RREC: stream r comes from records)
+    constexpr int NSW = F32 ? NSH : 1;       // hand-off words per cell
     static_assert(!RREC || MODE == PASS_CHANGE, "only a fused Change takes a stream from records");
-    static_assert(!F32 || (!RREC && (MODE == PASS_ADD || MODE == PASS_CHANGE)), "float light volumes: Add and fused Change");
+    static_assert(!F32 || MODE == PASS_ADD || MODE == PASS_CHANGE || MODE == PASS_PLANES, "float light volumes: Add, fused Change, planes");
     constexpr int RING = kSweepRing;
     static_assert(PF >= 1 && PF < RING, "the request ring holds 8 slices");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         if (pub_cell[h] >= 0) {
                             if constexpr (F32) {
 #pragma unroll
-                                for (int si = 0; si < NS; ++si) {
+                                for (int si = 0; si < NSH; ++si) {
                                     uint32_t w = __float_as_uint(plane(CUR, si)[pub_cell[h]]);
                                     if (w == kSweepNoWord) w = 0x7fc00000u; // (that NaN of all NaNs means "not published yet")
                                     sweep_store_word(rec + (si * RW + h * 64 + lane), w);
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                     for (int h = 0; h < HC; ++h) {
                         if constexpr (F32) {
 #pragma unroll
-                            for (int si = 0; si < NS; ++si) {
+                            for (int si = 0; si < NSH; ++si) {
                                 uint32_t w = hreg[K8][h][si];
                                 if (hal_on[h] && w == kSweepNoWord)
                                     w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (si * RW)), epoch, q.error, q.give_up_ticks, true);
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         for (int h = 0; h < HC; ++h) {
                             const uint32_t w = rreg[K8][h];
                             if (rh_on[h]) {
-                                if ((w >> 16) != (q.r_epoch & 0xffffu)) atomicOr(q.error, 4);
-                                plane(CUR ^ 1, 1)[rh_dst[h]] = reinit ? stream(1).init_value : decode_u8(w & 255u);
+                                if (F32 ? w == kSweepNoWord : (w >> 16) != (q.r_epoch & 0xffffu)) atomicOr(q.error, 4);
+                                plane(CUR ^ 1, 1)[rh_dst[h]] = reinit ? stream(1).init_value : (F32 ? __uint_as_float(w) : decode_u8(w & 255u));
                             }
                         }
                     }
@@ -760,9 +761,14 @@ template <int MODE, int AXIS, int TH>
 static hipError_t launch_sweep4(const ChunkParams& p, const SweepParams& q, hipStream_t s)
 {
     const int hc = sweep_halo_chunks(q.hx, q.hy, TH);
-    if (q.lv_f32) { // float light volumes: Add and fused Change, up to three words per lane and stream (sweep_fit)
-        if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE) {
-            if (q.r_from_records) return hipErrorInvalidConfiguration;
+    if (q.lv_f32) { // float light volumes: Add, fused Change, planes; up to three words per lane and stream (sweep_fit)
+        if constexpr (MODE == PASS_ADD || MODE == PASS_CHANGE || MODE == PASS_PLANES) {
+            if (q.r_from_records) {
+                if constexpr (MODE == PASS_CHANGE) {
+                    if (std::max(hc, sweep_halo_chunks(q.r_hx, q.r_hy, TH)) <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH, true, FMT_F32>(p, q, s);
+                }
+                return hipErrorInvalidConfiguration;
+            }
             if (hc <= 2) return launch_sweep5<MODE, AXIS, 2, 2, TH, false, FMT_F32>(p, q, s);
             if (hc <= 3) return launch_sweep5<MODE, AXIS, 2, 3, TH, false, FMT_F32>(p, q, s);
         }

@@ -590,3 +590,38 @@ def test_padding_voxels_of_a_ragged_light_volume_are_left_alone(gpu, oracle_mod,
     pad = dense[~inside]
     assert np.all(pad == clear), f"{np.count_nonzero(pad != clear)} of {pad.size} padding voxels changed (e.g. {pad[pad != clear][:4]})"
     assert np.any(dense[inside] != clear)
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (96, 72, 40)])
+def test_float_lights_that_pull_two_ways_are_swept(gpu, oracle_mod, dims):
+    """bLightVolume32Bit with a fused Change whose lights pull opposite ways (round 5; until then: the chain): the removed light's
+    planes first, as floats into their own records, then the fused sweep in the added light's order — within the suite's float
+    tolerance of the oracle, every pass on the sweep."""
+    world = S.default_world()
+    vol = S.make_volume_numpy(dims, np.uint16, 0x5EED0902)
+    lut = abi.color_curve_to_lut(S.TF_A_KEYS)
+    win = abi.WindowingParams(0.5, 0.9, True, False)
+    orc = oracle_mod.OracleScene(vol, True)
+    orc.set_tf_lut(lut)
+    orc.set_windowing(win)
+    with abi.Resources(dims, abi.FMT_G16, True) as res:
+        res.upload_volume(vol)
+        res.set_tf_lut(lut)
+        res.set_windowing(win)
+        res.clear_light_volume(0.0)
+        two_launch_passes = 0
+        for k, (d_old, d_new) in enumerate(TWO_WAY):
+            old, new = abi.DirLightParams(d_old, 0.6), abi.DirLightParams(d_new, 0.5 + 0.1 * (k % 3))
+            res.add_dir_light(old, True, world)
+            orc.add_dir_light(old, True, world)
+            before = res.path_counters()
+            res.change_dir_light(old, new, world)
+            orc.change_dir_light(old, new, world)
+            after = res.path_counters()
+            two_launch_passes += (after["launches_sweep"] - before["launches_sweep"]) - (after["passes_sweep"] - before["passes_sweep"])
+            res.flush()
+            err = float(np.abs(res.download_light_volume() - orc.light).max())
+            assert err <= 2e-6, f"two-way float change {d_old} -> {d_new}: max |diff| {err}"
+        p = res.path_counters()
+        assert two_launch_passes >= len(TWO_WAY) // 2, (two_launch_passes, p)  # (planes + fused launch: the two-way form ran)
+        assert p["passes_slice"] == 0 and p["passes_chain"] <= 2, p  # (a reach of more than three words per lane may still decline)
