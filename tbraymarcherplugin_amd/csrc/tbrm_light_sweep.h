@@ -32,13 +32,7 @@ constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x
 
 // slots of the LDS ring of factor slices; the loader runs one less ahead. One-stream slices are short: 8; a two-stream pass
 // leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
-#ifndef TBRM_SWEEP_FS1
-#define TBRM_SWEEP_FS1 8
-#endif
-#ifndef TBRM_SWEEP_FS2
-#define TBRM_SWEEP_FS2 4
-#endif
-constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? TBRM_SWEEP_FS2 : TBRM_SWEEP_FS1; }
+constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? 4 : 8; }
 
 constexpr int sweep_blocks(int th) { return 2 * (th / 16); } // 16 x 16 occlusion blocks under a tile
 constexpr int sweep_bricks(int th) { return 4 * (th / 8); }  // light-volume bricks under a tile

@@ -72,14 +72,6 @@ __device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch,
     return w;
 }
 
-#ifndef TBRM_SWEEP_DMA_NT
-#define TBRM_SWEEP_DMA_NT 0
-#endif
-#if TBRM_SWEEP_DMA_NT
-#define TBRM_SWEEP_DMA_POLICY " nt"
-#else
-#define TBRM_SWEEP_DMA_POLICY ""
-#endif
 // One block slice of occlusion factors (64 lanes x 16 bytes = the 256 floats of a 16 x 16 block) from global memory straight
 // into LDS at `lds_dst` (wave-uniform byte address) + lane * 16: no registers, counted by vmcnt like any load — but invisible
 // to the compiler's own wait-count bookkeeping, which is the point: the loader waits with sweep_wait_loads<N>() for exactly
@@ -87,7 +79,7 @@ __device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch,
 __device__ __forceinline__ void sweep_dma_block(const void* src, uint32_t lds_dst)
 {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" TBRM_SWEEP_DMA_POLICY "\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void sweep_wait_loads() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
