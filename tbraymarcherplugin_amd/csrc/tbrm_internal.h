@@ -194,7 +194,7 @@ struct SweepParams {
                             // bit 1 = every tile leaves four time stamps (10 ns units) in `stamps`
     unsigned long long* stamps; // [tile][4]: start of slice 0, end of slice 63, end of the last slice, after the write-back
     int tile_rows;          // height of a tile: 32, or 16 (two workgroups per CU; tbrm_light_sweep.h sweep_tile_rows); a tile is 32 wide
-    int lv_f32;             // the light volume (and the planes) are floats: k_light_sweep<..., FMT_F32>, records pre-filled with 0xffffffff
+    int lv_f32;             // the light volume (and the planes) are floats: k_light_sweep<..., FMT_F32>, record words are 8-byte {float, launch tag} granules
     int reinit_slice;       // > 0: the launch's first reinit_slice slices lie in front of the volume (a pass that runs downwards from a
                             // depth that is no multiple of 8, padded to whole brick layers): slice reinit_slice - 1 hands on the pass's
                             // initial plane instead of what it computed

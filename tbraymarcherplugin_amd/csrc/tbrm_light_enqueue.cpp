@@ -316,15 +316,12 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
         q1.stamps = nullptr;
         q1.debug &= ~2;
         if (int e = next_sweep_epoch(r, q1.epoch, 2)) return e;
-        if (q.lv_f32) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->sweep_rec[1], 0xffffffffu, plan.rec1_words, r->stream));
         HIP_TRY(launch_light_sweep(pr1, q1, PASS_PLANES, r->stream));
         ++r->launches[0];
         ++r->sweep_launches;
         q.r_epoch = q1.epoch;
     }
     if (int e = next_sweep_epoch(r, q.epoch)) return e;
-    if (q.lv_f32) // float hand-off words carry no tag: "not published yet" is written over the launch's records first
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->sweep_rec[0], 0xffffffffu, plan.rec_words, r->stream));
     q.stamps = nullptr;
     if (q.debug & 2) { // diagnostics: per-tile time stamps of this launch (printed by tbrm_flush)
         const int tiles = p.tiles_x * p.tiles_y;

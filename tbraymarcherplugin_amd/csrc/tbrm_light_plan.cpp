@@ -554,10 +554,12 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.r_sx = sfit.r_sx; q.r_sy = sfit.r_sy; q.r_hx = sfit.r_hx; q.r_hy = sfit.r_hy;
     q.tile_rows = sweep_tile_rows(); // (the sweep's tiles: 32 wide, 16 or 32 high)
     p.tiles_y = ceil_div(p.H, q.tile_rows);
-    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.hx, sfit.hy, q.tile_rows) * (size_t) (r->lv_fmt != FMT_U8 && change && !sfit.two_way ? 2 : 1); // (float records: a word per stream handed over)
+    const size_t words = (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.hx, sfit.hy, q.tile_rows) * (size_t) (r->lv_fmt != FMT_U8 && change && !sfit.two_way ? 2 : 1); // (float records: a granule per stream handed over)
     const size_t words1 = sfit.two_way ? (size_t) D * p.tiles_x * p.tiles_y * (size_t) sweep_record_words(sfit.r_hx, sfit.r_hy, q.tile_rows) : 0;
     if (words >= ((size_t) 1 << 32) || words1 >= ((size_t) 1 << 32)) return declined("hand-off records too large");
-    if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words1)) return e;
+    const size_t gw = r->lv_fmt != FMT_U8 ? 2 : 1; // 32-bit words per record word (float light volumes: {float, launch tag})
+    if (words * gw >= ((size_t) 1 << 32) || words1 * gw >= ((size_t) 1 << 32)) return declined("hand-off records too large");
+    if (int e = ensure_sweep(r, std::max<size_t>(words * gw, 1), words1 * gw)) return e;
     // (the record buffers may still grow while the operator's other passes are planned: taken at enqueue time)
     // (measured at 512^3, profiles/r03_sweep_ablation.txt: requests two slices ahead beat three by 3 - 4 %, start delays of 1 - 2 us
     // per hop tie and beat 3 - 4 us)
@@ -567,8 +569,6 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     q.reinit_slice = pa.dir < 0 ? pad : 0;
     q.n_real = pa.dir > 0 ? D - pad : D;
     q.lv_f32 = r->lv_fmt != FMT_U8 ? 1 : 0;
-    plan.rec_words = words;
-    plan.rec1_words = words1;
     {
         const int ms = tune(TUNE_SWEEP_TIMEOUT_MS);
         q.give_up_ticks = ms < 0 ? 0ull : (unsigned long long) (ms == 0 ? 2000 : ms) * 100000ull;

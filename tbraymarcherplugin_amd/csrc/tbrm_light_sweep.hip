@@ -51,20 +51,36 @@ namespace tbrm {
 template <class F, int... S>
 __device__ __forceinline__ void sweep_each_const(F&& f, std::integer_sequence<int, S...>) { (f(std::integral_constant<int, S>{}), ...); }
 
-__device__ __forceinline__ uint32_t sweep_load_word(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sweep_store_word(uint32_t* p, uint32_t w) { __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (W: uint32_t — a tagged dword of UNORM8 codes — or uint64_t — {float, launch tag}, one naturally aligned 8-byte granule)
+template <class W>
+__device__ __forceinline__ W sweep_load_word(const W* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class W>
+__device__ __forceinline__ void sweep_store_word(W* p, W w) { __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // The slow path of a hand-off: the neighbour has not published the word yet. Its load is inline assembly so that the
 // compiler's wait-count bookkeeping of the caller never sees a loop with a memory operation in it (it would answer with
 // s_waitcnt vmcnt(0) at every later use of a request that is still in flight).
-constexpr uint32_t kSweepNoWord = 0xffffffffu; // float light volumes: what a record word holds until it is published (a NaN no plane holds)
-__device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch, int* error, unsigned long long give_up_ticks, bool f32 = false)
+__device__ __noinline__ uint32_t sweep_poll(const uint32_t* src, uint32_t epoch, int* error, unsigned long long give_up_ticks)
 {
     uint32_t w = 0;
     const unsigned long long t0 = wall_clock64(); // (100 MHz, constant: a starved or shared device gets wall time, not a poll count)
     for (;;) {
         asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
-        if (f32 ? w != kSweepNoWord : (w >> 16) == epoch) return w;
+        if ((w >> 16) == epoch) return w;
+        if (wall_clock64() - t0 >= give_up_ticks) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    atomicOr(error, 1);
+    return w;
+}
+// float light volumes: a record word is {float, launch tag} in one 8-byte granule (one store, one load: nothing can tear)
+__device__ __noinline__ uint64_t sweep_poll(const uint64_t* src, uint32_t epoch, int* error, unsigned long long give_up_ticks)
+{
+    uint64_t w = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
+        if ((uint32_t) (w >> 32) == epoch) return w;
         if (wall_clock64() - t0 >= give_up_ticks) break;
         __builtin_amdgcn_s_sleep(2);
     }
@@ -114,8 +130,8 @@ __device__ __forceinline__ v2f quantize2_unfloored(v2f x) // (>= 0.5: the conver
 // PASS_PLANES launch (SweepParams::r_from_records). MODE PASS_PLANES: one stream, the light volume untouched.
 // LFMT: the light volume's (and the read / write buffers') format. FMT_U8: planes are UNORM8 codes re-quantised every slice, one
 // hand-off word carries a launch tag and both streams' codes, the tile's light-volume bricks are staged in LDS. FMT_F32
-// (bLightVolume32Bit, RaymarchVolume.cpp:857-866): planes are floats as they are, a hand-off word is the float itself (one per
-// stream; the records are filled with kSweepNoWord before the launch instead of being tagged), and the light volume is updated
+// (bLightVolume32Bit, RaymarchVolume.cpp:857-866): planes are floats as they are, a hand-off word is an 8-byte granule {float, launch
+// tag} (one per stream, written by one store and read by one load), and the light volume is updated
 // in place — fire-and-forget fp32 atomic adds, the removed light's as a second add of -L: (LV + La) - Lr rounds twice, like the
 // reference's expression (ChangeDirLightShader.usf:152-154).
 template <int MODE, int AXIS, int PF, int HC, bool RREC, int LFMT, int TH>
@@ -311,7 +327,8 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
         }
         auto handoff = [&](auto pub_c, auto con_c) {
         constexpr bool PUB = decltype(pub_c)::value, CON = decltype(con_c)::value;
-        uint32_t hreg[RING][HC][NSW], rreg[RING][RREC ? HC : 1];
+        using RecW = std::conditional_t<F32, uint64_t, uint32_t>;
+        RecW hreg[RING][HC][NSW], rreg[RING][RREC ? HC : 1];
         // (every lane loads: the ones without a halo word read word 0 of the slice — a branch around a load whose result is
         // consumed slices later would make the compiler drain every request in flight at the join)
         auto request_halo = [&](int s, auto slot_c) { // the neighbours' slice s
@@ -319,10 +336,10 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
 #pragma unroll
             for (int h = 0; h < HC; ++h)
 #pragma unroll
-                for (int sw = 0; sw < NSW; ++sw) hreg[SLOT][h][sw] = sweep_load_word((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (sw * RW)));
+                for (int sw = 0; sw < NSW; ++sw) hreg[SLOT][h][sw] = sweep_load_word((const RecW*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (sw * RW)));
             if constexpr (RREC) {
 #pragma unroll
-                for (int h = 0; h < HC; ++h) rreg[SLOT][h] = sweep_load_word((const uint32_t*) q.rec[1] + ((uint32_t) s * r_rec_slice + rh_src[h]));
+                for (int h = 0; h < HC; ++h) rreg[SLOT][h] = sweep_load_word((const RecW*) q.rec[1] + ((uint32_t) s * r_rec_slice + rh_src[h]));
             }
         };
         sweep_each_const([&](auto sl) {
@@ -342,22 +359,20 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                 if constexpr (FIRST) reinit = K8 + 1 == q.reinit_slice;
                 // the boundary cells of the slice before this one, which the compute waves finished at the last barrier
                 if (PUB && s > 0) {
-                    uint32_t* const rec = (uint32_t*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RWS));
+                    RecW* const rec = (RecW*) q.rec[0] + ((uint32_t) (s - 1) * rec_slice + (uint32_t) (tile_lin * RWS));
 #pragma unroll
                     for (int h = 0; h < HC; ++h)
                         if (pub_cell[h] >= 0) {
                             if constexpr (F32) {
 #pragma unroll
                                 for (int si = 0; si < NSH; ++si) {
-                                    uint32_t w = __float_as_uint(plane(CUR, si)[pub_cell[h]]);
-                                    if (w == kSweepNoWord) w = 0x7fc00000u; // (that NaN of all NaNs means "not published yet")
-                                    sweep_store_word(rec + (si * RW + h * 64 + lane), w);
+                                    sweep_store_word(rec + (si * RW + h * 64 + lane), ((uint64_t) epoch << 32) | __float_as_uint(plane(CUR, si)[pub_cell[h]]));
                                 }
                             } else {
                                 uint32_t w = tag;
 #pragma unroll
                                 for (int si = 0; si < NS; ++si) w |= ((uint32_t) (plane(CUR, si)[pub_cell[h]] * 255.0f + 0.5f) & 255u) << (8 * si); // (v = code / 255: back to the code)
-                                sweep_store_word(rec + (h * 64 + lane), w);
+                                sweep_store_word(rec + (h * 64 + lane), (RecW) w);
                             }
                         }
                 }
@@ -368,13 +383,13 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         if constexpr (F32) {
 #pragma unroll
                             for (int si = 0; si < NSH; ++si) {
-                                uint32_t w = hreg[K8][h][si];
-                                if (hal_on[h] && w == kSweepNoWord)
-                                    w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (si * RW)), epoch, q.error, q.give_up_ticks, true);
-                                if (hal_on[h]) plane(CUR ^ 1, si)[hal_dst[h]] = reinit ? stream(si).init_value : __uint_as_float(w);
+                                uint64_t w = hreg[K8][h][si];
+                                if (hal_on[h] && (uint32_t) (w >> 32) != epoch)
+                                    w = sweep_poll((const uint64_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h] + (uint32_t) (si * RW)), epoch, q.error, q.give_up_ticks);
+                                if (hal_on[h]) plane(CUR ^ 1, si)[hal_dst[h]] = reinit ? stream(si).init_value : __uint_as_float((uint32_t) w);
                             }
                         } else {
-                            uint32_t w = hreg[K8][h][0];
+                            uint32_t w = (uint32_t) hreg[K8][h][0];
                             if (hal_on[h] && (w >> 16) != epoch) w = sweep_poll((const uint32_t*) q.rec[0] + ((uint32_t) s * rec_slice + hal_src[h]), epoch, q.error, q.give_up_ticks);
                             if (hal_on[h]) {
 #pragma unroll
@@ -385,10 +400,10 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                     if constexpr (RREC) { // the removed light's cells: published long ago (a word that is not there is an error)
 #pragma unroll
                         for (int h = 0; h < HC; ++h) {
-                            const uint32_t w = rreg[K8][h];
+                            const RecW w = rreg[K8][h];
                             if (rh_on[h]) {
-                                if (F32 ? w == kSweepNoWord : (w >> 16) != (q.r_epoch & 0xffffu)) atomicOr(q.error, 4);
-                                plane(CUR ^ 1, 1)[rh_dst[h]] = reinit ? stream(1).init_value : (F32 ? __uint_as_float(w) : decode_u8(w & 255u));
+                                if ((uint32_t) (w >> (F32 ? 32 : 16)) != (q.r_epoch & 0xffffu)) atomicOr(q.error, 4);
+                                plane(CUR ^ 1, 1)[rh_dst[h]] = reinit ? stream(1).init_value : (F32 ? __uint_as_float((uint32_t) w) : decode_u8((uint32_t) w & 255u));
                             }
                         }
                     }

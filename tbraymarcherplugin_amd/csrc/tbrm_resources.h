@@ -297,8 +297,6 @@ struct PassPlan {
     // the pass's chunks are spans advanced by the pipelined sweep kernel (one launch per span; sweep_fit)
     bool sweep = false;
     SweepParams sq{};
-    size_t rec_words = 0;       // hand-off words of the launch (float light volumes: filled with "not published" before it)
-    size_t rec1_words = 0;      // ... of the removed light's planes launch in front of a two-way Change
     int halo_rows = 0;          // lateral: rows a slice's taps can reach beyond a slab
 };
 
