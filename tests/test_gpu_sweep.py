@@ -626,3 +626,39 @@ def test_float_lights_that_pull_two_ways_are_swept(gpu, oracle_mod, dims):
         assert two_launch_passes >= len(TWO_WAY) // 2, (two_launch_passes, p)  # (planes + fused launch: the two-way form ran)
         # (a float pass of more than three hand-off words per lane still declines: the flat volume's steep second passes)
         assert p["passes_slice"] == 0 and p["passes_chain"] <= (2 if max(dims) == min(dims) else p["passes_sweep"] // 2), p
+
+
+def test_block_lists_are_kept_with_the_handle(gpu, oracle_mod, tunables):
+    """Round 5: the empty-block flags, work list and ranks of a pass depend on the light only through the integer range of data texels
+    a block's samples touch; a light that turns by a few degrees finds the lists of the call before (tbrm_path_counters:
+    block_lists_built does not move), a new window makes every list stale (rebuilt, results still the oracle's), and a factor cache
+    entry keeps the ranks it was filled under."""
+    for cache in (-1, 0):
+        tunables("light_cache_mb", cache)
+        world = S.default_world()
+        res, orc = scene(oracle_mod, (96, 96, 96), seed=0x5EED0E00)
+        with res:
+            d = (1, .35, -.5)
+            res.add_dir_light(abi.DirLightParams(d, 0.4), True, world)
+            orc.add_dir_light(abi.DirLightParams(d, 0.4), True, world)
+            built = []
+            for k in range(6):
+                new_d = S.rotate_z(d, 3.0)
+                res.change_dir_light(abi.DirLightParams(d, 0.4), abi.DirLightParams(new_d, 0.4), world)
+                orc.change_dir_light(abi.DirLightParams(d, 0.4), abi.DirLightParams(new_d, 0.4), world)
+                d = new_d
+                built.append(res.path_counters()["block_lists_built"])
+                same(res, orc, f"cache {cache}, turn {k}")
+            assert built[-1] == built[2], built  # (the first calls may meet new signatures; after them nothing is built)
+            win = abi.WindowingParams(0.45, 0.8, True, False)
+            res.set_windowing(win)
+            orc.set_windowing(win)
+            res.clear_light_volume(0.0)
+            orc.clear_light_volume(0.0)
+            res.add_dir_light(abi.DirLightParams(d, 0.4), True, world)
+            orc.add_dir_light(abi.DirLightParams(d, 0.4), True, world)
+            assert res.path_counters()["block_lists_built"] > built[-1]  # a new window: new emptiness bits, new lists
+            same(res, orc, f"cache {cache}, new window")
+            res.change_dir_light(abi.DirLightParams(d, 0.4), abi.DirLightParams(S.rotate_z(d, -3.0), 0.4), world)
+            orc.change_dir_light(abi.DirLightParams(d, 0.4), abi.DirLightParams(S.rotate_z(d, -3.0), 0.4), world)
+            same(res, orc, f"cache {cache}, change under the new window")
