@@ -100,7 +100,7 @@ static void prune(tbrm_resources* r)
     std::vector<BlockLists*> keep;
     std::sort(r->block_lists.begin(), r->block_lists.end(), [](const BlockLists* a, const BlockLists* b) { return a->last_use > b->last_use; });
     for (BlockLists* l : r->block_lists) {
-        if (l->users > 0 || keep.size() < kMaxLists / 2) keep.push_back(l); // (the operator being planned holds the most recent ones)
+        if (l->users > 0 || l->last_use > r->block_lists_op_floor || keep.size() < kMaxLists / 2) keep.push_back(l); // (never the ones the operator being planned holds)
         else free_lists(l);
     }
     // (units lists whose passes' lists went: ids are never reused, so they are merely never found again)

@@ -41,6 +41,7 @@ static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<Pas
 {
     if (int e = sweep_failed(r)) return e; // (an earlier sweep left the light volume undefined: nothing to build on)
     ++r->op_serial;
+    r->block_lists_op_floor = r->block_lists_serial;
     if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)
         if (int e = ensure_skipping(r)) return e;
     struct Unpin { // planning pins cache entries (use_kept / kept_new): released on every way out

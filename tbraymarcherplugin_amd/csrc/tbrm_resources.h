@@ -196,6 +196,7 @@ struct tbrm_resources {
     int f_buf = 0;                 // buffer of the most recent sweep pass
     std::vector<BlockLists*> block_lists; // passes' and dual launches' block lists computed so far (tbrm_block_lists.cpp)
     uint64_t block_lists_serial = 0;
+    uint64_t block_lists_op_floor = 0;  // block_lists_serial when the operator being planned began: its plans point at younger lists
     uint64_t block_lists_quiet_gen = 0; // lists older than this empty_gen are read by nothing in flight (new_lists)
     uint64_t lists_launches = 0;   // passes / dual launches whose lists had to be computed (tbrm_path_counters)
     uint64_t dual_launches = 0;    // occlusion launches that served two passes (tbrm_launch_counters)
