@@ -6,7 +6,7 @@ set -u
 OUT=gpurun_out/${1:-round}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" | tail -8) > "$OUT/tests.txt"
+(timeout 1800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error|FAILED|ERROR" | tail -8) > "$OUT/tests.txt"
 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python bench.py --no-cpu-baseline --timed-only > "$OUT/bench_n1_under_rocprof.json" 2> /dev/null
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_bench_n1.csv" \;
