@@ -402,6 +402,10 @@ TBRM_API int tbrm_light_volume_device_ptr(tbrm_resources* res, void** out_ptr, s
  * filtered out of UNORM data): compares it with the IEEE quotient for EVERY float in [0, 1] and returns the number of
  * mismatching bit patterns (0 expected); *out_fast_path = 0 when the library divides for this window anyway. */
 TBRM_API int tbrm_selftest_window_division(int device, float center, float width, uint64_t* out_mismatches, int* out_fast_path);
+/* Device self-test of the opacity correction's short form (1 - pow(1 - a, step), WindowedSampling.usf:35, AddDirLightShader.usf:111:
+ * the kernels never use the power itself, so they skip what cannot show in 1 - r): compares it with 1 - pow for EVERY float
+ * 1 - a in [0, 1] at the two given step sizes (finite, >= 0) and returns the number of mismatching bit patterns (0 expected). */
+TBRM_API int tbrm_selftest_opacity_correction(int device, float step0, float step1, uint64_t* out_mismatches);
 TBRM_API int tbrm_launch_counters(const tbrm_resources* res, uint64_t out[3]);
 /* Of out[0] above, the launches of the pipelined sweep kernel (one per axis pass; the rest are chunks of the chained kernel). */
 TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);

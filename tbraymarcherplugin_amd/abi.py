@@ -125,7 +125,7 @@ SYMBOLS = [
     "tbrm_generate_octree", "tbrm_octree_mip_dims", "tbrm_download_octree_mip", "tbrm_raymarch_octree", "tbrm_raymarch_octree_device",
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
-    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_selftest_window_division", "tbrm_launch_counters", "tbrm_sweep_launches", "tbrm_path_counters", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
+    "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_selftest_window_division", "tbrm_selftest_opacity_correction", "tbrm_launch_counters", "tbrm_sweep_launches", "tbrm_path_counters", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
@@ -209,6 +209,7 @@ def load():
     lib.tbrm_selftest_unorm_decode.argtypes = [C.c_int, vp, vp]
     lib.tbrm_selftest_unorm8_roundtrip.argtypes = [C.c_int, vp, C.c_size_t, vp]
     lib.tbrm_selftest_window_division.argtypes = [C.c_int, C.c_float, C.c_float, P(C.c_uint64), P(C.c_int)]
+    lib.tbrm_selftest_opacity_correction.argtypes = [C.c_int, C.c_float, C.c_float, P(C.c_uint64)]
     lib.tbrm_flush.argtypes = [vp]
     lib.tbrm_stream.argtypes = [vp, P(vp)]
     lib.tbrm_last_gpu_time_ms.argtypes = [vp, C.c_int, P(C.c_float)]

@@ -704,6 +704,23 @@ int tbrm_selftest_window_division(int device, float center, float width, uint64_
     return TBRM_OK;
 }
 
+int tbrm_selftest_opacity_correction(int device, float step0, float step1, uint64_t* out_mismatches)
+{
+    if (!out_mismatches) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (!(step0 >= 0.0f) || !(step1 >= 0.0f) || std::isinf(step0) || std::isinf(step1)) return fail(TBRM_ERR_INVALID_ARG, "the short form is used for finite step sizes >= 0 only");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**) &d, sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = launch_selftest_opacity_correction(step0, step1, d, nullptr);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d, sizeof(bad), hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    HIP_TRY(e);
+    *out_mismatches = bad;
+    return TBRM_OK;
+}
+
 int tbrm_launch_counters(const tbrm_resources* r, uint64_t out[3])
 {
     if (!r || !out) return fail(TBRM_ERR_INVALID_ARG, "null argument");

@@ -210,6 +210,17 @@ __device__ __forceinline__ float sample_tf_alpha(const float* tf_alpha, float po
     return lerp_(tf_alpha[i0], tf_alpha[i1], f);
 }
 
+// the same from a table of pairs: entry i + 1 = (alpha[clamp(i)], alpha[clamp(i + 1)]) for i = -1 .. 255 (257 entries, built by the
+// workgroup) — one clamp and one 8-byte LDS read instead of two clamps and two reads; the same two operands, the same lerp
+__device__ __forceinline__ float sample_tf_alpha(const float2* tf_alpha_pairs, float pos)
+{
+    int i0;
+    float f;
+    texel_split(pos, 256.0f, i0, f);
+    const float2 ab = tf_alpha_pairs[min(max(i0, -1), 255) + 1];
+    return lerp_(ab.x, ab.y, f);
+}
+
 // GetTransferFuncPosition for a value filtered out of UNORM data (in [0, 1]: the range the host's fast_div vouches for); float data
 // always divides
 template <bool UNORM_DATA>
@@ -222,29 +233,31 @@ __device__ __forceinline__ float window_position(float value, const WindowDev& w
 }
 
 // SampleWindowedTransferFunction(...).a  (WindowedSampling.usf:20-37)
-template <bool UNORM_DATA = false>
-__device__ __forceinline__ float windowed_alpha(float value, float step, const float* tf_alpha, const WindowDev& w)
+// (NONNEG: the caller has checked step >= 0 — wave-uniform, so outside its loop — and the general pow_ drops out of the instantiation)
+template <bool UNORM_DATA = false, bool NONNEG = false, class TF = float>
+__device__ __forceinline__ float windowed_alpha(float value, float step, const TF* tf_alpha, const WindowDev& w)
 {
     const float pos = window_position<UNORM_DATA>(value, w);
     if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return 0.0f;
     const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
     if (a == 0.0f) return 0.0f; // 1 - pow(1, s) == 0 exactly
-    return 1.0f - (step >= 0.0f ? pow01_(1.0f - a, step) : pow_(1.0f - a, step)); // (a in (0, 1]; step >= 0: wave-uniform)
+    if constexpr (NONNEG) return one_minus_pow01_(1.0f - a, step);
+    else return step >= 0.0f ? one_minus_pow01_(1.0f - a, step) : 1.0f - pow_(1.0f - a, step); // (a in (0, 1]; step >= 0: wave-uniform)
 }
 
 // windowed_alpha(value, step0, ...) and windowed_alpha(value, step1, ...), bit for bit, sharing everything up to the opacity
 // correction's exponent (one sample position, two axis passes)
-template <bool UNORM_DATA = false>
-__device__ __forceinline__ void windowed_alpha2(float value, float step0, float step1, const float* tf_alpha, const WindowDev& w, float& a0, float& a1)
+template <bool UNORM_DATA = false, bool NONNEG = false, class TF = float>
+__device__ __forceinline__ void windowed_alpha2(float value, float step0, float step1, const TF* tf_alpha, const WindowDev& w, float& a0, float& a1)
 {
     a0 = 0.0f; a1 = 0.0f;
     const float pos = window_position<UNORM_DATA>(value, w);
     if ((pos < 0.0f && w.low_cutoff > 0.0f) || (pos > 1.0f && w.high_cutoff > 0.0f)) return;
     const float a = saturate_(sample_tf_alpha(tf_alpha, pos));
     if (a == 0.0f) return;
+    if (NONNEG || (step0 >= 0.0f && step1 >= 0.0f)) { one_minus_pow01_2_(1.0f - a, step0, step1, a0, a1); return; } // (wave-uniform)
     float p0, p1;
-    if (step0 >= 0.0f && step1 >= 0.0f) pow01_2_(1.0f - a, step0, step1, p0, p1); // (wave-uniform)
-    else pow2_(1.0f - a, step0, step1, p0, p1);
+    pow2_(1.0f - a, step0, step1, p0, p1);
     a0 = 1.0f - p0;
     a1 = 1.0f - p1;
 }

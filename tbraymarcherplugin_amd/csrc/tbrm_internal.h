@@ -340,6 +340,7 @@ int tune(Tunable t);
 hipError_t launch_selftest_decode(float* d_u8, float* d_u16, hipStream_t s);
 hipError_t launch_selftest_roundtrip(const float* d_in, float* d_out, size_t n, hipStream_t s);
 hipError_t launch_selftest_window_division(const WindowDev& w, unsigned long long* d_mismatches, hipStream_t s);
+hipError_t launch_selftest_opacity_correction(float step0, float step1, unsigned long long* d_mismatches, hipStream_t s);
 hipError_t launch_relayout(const RelayoutParams& p, hipStream_t s);
 size_t chunk_lds_bytes(const ChunkParams& p, int mode, int lv_fmt);
 size_t occlusion_lds_bytes(const ChunkParams& p); // dynamic LDS of an occlusion workgroup (the bricks it stages)

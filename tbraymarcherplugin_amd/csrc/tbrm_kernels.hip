@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
                 if (a_sat != 0.0f) { // else 1 - pow(1, s) = 0: the sample contributes exactly nothing
                     // (a_sat in (0, 1]; the step is 100 / steps or 100 x a fraction in (0, 1): >= 0 unless the host passed a negative
                     // step count, which build_ray_params rejects — pow01_ is pow_ on that domain, bit for bit)
-                    const float a = 1.0f - pow01_(1.0f - a_sat, step);
+                    const float a = one_minus_pow01_(1.0f - a_sat, step);
                     const float l = ltaps.filter(gx, gy, gz);
                     x = make_float4((cs.x * l) * a, (cs.y * l) * a, (cs.z * l) * a, a);
                 }
@@ -489,6 +489,27 @@ __global__ __launch_bounds__(256) void k_selftest_window_division(WindowDev w, u
 hipError_t launch_selftest_window_division(const WindowDev& w, unsigned long long* d_mismatches, hipStream_t s)
 {
     hipLaunchKernelGGL(k_selftest_window_division, dim3(256 * 64), dim3(256), 0, s, w, d_mismatches);
+    return hipGetLastError();
+}
+
+// ---- self-test of the opacity correction's short form (one_minus_pow01_ against 1 - pow01_, every float in [0, 1]) --------------------
+__global__ __launch_bounds__(256) void k_selftest_opacity_correction(float step0, float step1, unsigned long long* mismatches)
+{
+    const uint32_t last = 0x3f800000u; // 1.0f
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= last; i += (uint64_t) gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t) i);
+        float p0, p1, s0, s1;
+        pow01_2_(x, step0, step1, p0, p1);
+        one_minus_pow01_2_(x, step0, step1, s0, s1);
+        const float a = 1.0f - pow01_(x, step0), b = one_minus_pow01_(x, step0);
+        if (__float_as_uint(1.0f - p0) != __float_as_uint(s0) || __float_as_uint(1.0f - p1) != __float_as_uint(s1) || __float_as_uint(a) != __float_as_uint(b)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+hipError_t launch_selftest_opacity_correction(float step0, float step1, unsigned long long* d_mismatches, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_selftest_opacity_correction, dim3(256 * 64), dim3(256), 0, s, step0, step1, d_mismatches);
     return hipGetLastError();
 }
 

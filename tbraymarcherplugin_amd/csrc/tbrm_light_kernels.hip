@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
     constexpr int NS = (MODE == PASS_ADD || MODE == PASS_CHANGE_ONE) ? 1 : 2; // PASS_CHANGE_ONE: one stream with the Change shader's rules
     constexpr bool GUARD = MODE == PASS_ADD || MODE == PASS_ADD2; // all(uvw == saturate(uvw)): the Add shader only (AddDirLightShader.usf:98)
     constexpr int ESZ = DFMT == FMT_U8 ? 1 : (DFMT == FMT_U16 ? 2 : 4);
-    __shared__ float s_alpha[256];
+    __shared__ float2 s_alpha[257]; // pairs (alpha[clamp(i)], alpha[clamp(i + 1)]) at i + 1: sample_tf_alpha
     __shared__ float s_w[2][kOccDepth], s_f[2][kOccDepth];
     __shared__ int s_i[2][kOccDepth], s_flags[2][kOccDepth]; // flags: bit0 tap0 in range, bit1 tap1 in range, bit2 w == saturate(w)
     __shared__ int s_b0[3], s_nb[3], s_staged, s_interior;
@@ -416,7 +416,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
     const int px0 = gx * kOccTile, py0 = gy * kOccTile, k0 = gz * kOccDepth;
     const int nk = min(kOccDepth, p.n_steps - k0);
 
-    s_alpha[threadIdx.x] = p.tf[threadIdx.x].w;
+    {
+        const float a_t = p.tf[threadIdx.x].w, a_n = p.tf[min((int) threadIdx.x + 1, 255)].w;
+        s_alpha[threadIdx.x + 1] = make_float2(a_t, a_n);
+        if (threadIdx.x == 0) s_alpha[0] = make_float2(a_t, a_t);
+    }
     if (threadIdx.x < NS * kOccDepth) { // slice-axis taps of each step of this workgroup (wave-uniform values)
         const int si = threadIdx.x / kOccDepth, q = threadIdx.x % kOccDepth;
         const ChunkStream& s = si == 0 ? p.a : p.r;
@@ -600,6 +604,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
             PlaneVal lo{}, hi{};
             int held = INT32_MIN / 2; // slice-axis texel index of `lo`; `hi` is the plane after it
 
+            // (the opacity correction's step sizes are >= 0 unless the host was handed garbage: decided here, outside the loop)
+            auto slices = [&](auto nonneg_c) {
+            constexpr bool NONNEG = decltype(nonneg_c)::value;
+            // the step sizes in vector registers (as scalars they are spilled around this loop and fetched back every trip)
+            float step_v0 = DUAL ? d.pass[0].step100[si] : s.step100, step_v1 = DUAL ? d.pass[1].step100[si] : 0.0f;
+            asm volatile("" : "+v"(step_v0), "+v"(step_v1));
             for (int q = 0; q < nk; ++q) {
                 const float fs = s_f[si][q];
                 const int fl = s_flags[si][q];
@@ -620,7 +630,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                 if constexpr (DUAL) {
                     float occ0 = 0.0f, occ1 = 0.0f;
                     if (aw > 0.0f && inside) {
-                        windowed_alpha2<DFMT != FMT_F32>(combine(lo, hi, fs), d.pass[0].step100[si], d.pass[1].step100[si], s_alpha, p.win, occ0, occ1);
+                        windowed_alpha2<DFMT != FMT_F32, NONNEG>(combine(lo, hi, fs), step_v0, step_v1, s_alpha, p.win, occ0, occ1);
                         occ0 = occ0 * aw;
                         occ1 = occ1 * aw;
                     }
@@ -629,9 +639,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TBRM_OCC_WA
                     continue;
                 }
                 float occ = 0.0f;
-                if (aw > 0.0f && inside) occ = windowed_alpha<DFMT != FMT_F32>(combine(lo, hi, fs), s.step100, s_alpha, p.win) * aw;
+                if (aw > 0.0f && inside) occ = windowed_alpha<DFMT != FMT_F32, NONNEG>(combine(lo, hi, fs), step_v0, s_alpha, p.win) * aw;
                 out[q * out_step] = 1 - occ; // handed over as the factor of AddDirLightShader.usf:117
             }
+            };
+            const bool steps_nonneg = DUAL ? (d.pass[0].step100[si] >= 0.0f && d.pass[1].step100[si] >= 0.0f) : s.step100 >= 0.0f;
+            if (steps_nonneg) slices(std::true_type{});
+            else slices(std::false_type{});
         }
     };
     using T_ = std::true_type; using F_ = std::false_type;

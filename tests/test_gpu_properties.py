@@ -312,6 +312,22 @@ def test_division_free_window_position_is_the_ieee_quotient(gpu, center, width):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("step0,step1", [(100.0 / 512.0, 100.0 / 724.0), (100.0 / 128.0, 100.0 / 128.0), (0.0, 1.0e-6), (0.37, 4.0), (100.0, 1.0e4), (3.0e38, 1.0e-30),
+                                         (1.0e-45, 1.0)])
+def test_short_opacity_correction_is_one_minus_pow(gpu, step0, step1):
+    """The kernels evaluate 1 - pow(1 - a, step) (WindowedSampling.usf:35) without the parts of the exponential that cannot show in
+    1 - r (a power below 2^-25 is gone there): the device compares the short form with 1 - pow for EVERY float 1 - a in [0, 1], as
+    a single power and as the dual occlusion launch's pair — the same bits."""
+    import ctypes as C
+
+    lib = abi.load()
+    bad = C.c_uint64(123)
+    abi.check(lib.tbrm_selftest_opacity_correction(0, step0, step1, C.byref(bad)))
+    assert bad.value == 0, (step0, step1, bad.value)
+    assert lib.tbrm_selftest_opacity_correction(0, -1.0, 1.0, C.byref(bad)) == abi.ERR_INVALID_ARG
+
+
+@pytest.mark.gpu
 def test_windows_the_host_does_not_vouch_for_keep_the_division(gpu):
     import ctypes as C
     import struct
