@@ -30,9 +30,17 @@ constexpr int kSweepFlagGroups = 128;                  // slice groups of a span
 constexpr int kSweepFBlock = 256 + 16;                 // floats per staged 16 x 16 block slice of occlusion factors: the four
                                                        // blocks under a tile start 16 banks apart (a lane pair's columns c, c + 16)
 
-// slots of the LDS ring of factor slices; the loader runs one less ahead. One-stream slices are short: 8; a two-stream pass
-// leaves the other half of the LDS to the occlusion workgroups that share the CU: 4 (measured: 4, 6 and 8 tie)
-constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? 4 : 8; }
+// slots of the LDS ring of factor slices; the loader runs one less ahead. Eight for one and for two streams (round 5: with a
+// ring of eight a slice's factors land a barrier earlier and the compute waves read them in front of the barrier instead of
+// behind it — k_light_sweep EARLY —: a fused Change's sweeps 0.63 -> 0.61 ms; rounds 3 and 4 ran two-stream passes with four
+// slots to leave LDS to occlusion workgroups beside them, which never paid). Build-time switches for A/B builds (tools/build_variant.py):
+#ifndef TBRM_SWEEP_TWO_STREAM_SLOTS
+#define TBRM_SWEEP_TWO_STREAM_SLOTS 8
+#endif
+#ifndef TBRM_SWEEP_EARLY_READS
+#define TBRM_SWEEP_EARLY_READS 1
+#endif
+constexpr int sweep_factor_slots(int mode) { return sweep_two_streams(mode) ? TBRM_SWEEP_TWO_STREAM_SLOTS : 8; }
 
 constexpr int sweep_blocks(int th) { return 2 * (th / 16); } // 16 x 16 occlusion blocks under a tile
 constexpr int sweep_bricks(int th) { return 4 * (th / 8); }  // light-volume bricks under a tile

@@ -180,6 +180,11 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
     // the ring of factor slices, [slot][si][2 x 2 blocks][kSweepFBlock]: filled FS - 1 slices ahead by the loader wave
     float* const fring = (float*) (sslot + NS * NB * G);
     constexpr int FS = sweep_factor_slots(MODE); // (divides the loop's eight slices: a slice's slot is a constant)
+    // EARLY: what a compute wave reads of the next slice that no other compute wave writes — its factors, the bytes of the voxels it
+    // updates — is read at the END of a slice, in front of the barrier, where the wave would wait anyway: the burst of LDS reads
+    // behind the barrier, which all eight waves start at once and the arithmetic waits for, is a third shorter
+    constexpr bool EARLY_LV = TBRM_SWEEP_EARLY_READS != 0;   // the voxels' bytes
+    constexpr bool EARLY = EARLY_LV && FS >= 8;              // ... and the factors (the loader lands a slice one barrier earlier: a ring of eight)
     constexpr int kFSlot = NS * NB * kSweepFBlock; // floats per slot
     auto stream = [&](int si) -> const ChunkStream& { return si == 0 ? p.a : p.r; };
 
@@ -464,8 +469,12 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                 }
             }
         };
-        auto landed = [&]() { // everything but the last A - 1 slices' loads
-            sweep_wait_loads<(A - 1) * L>();
+        // EARLY: the compute waves read slice s + 1's factors at the end of slice s, in front of the barrier: a slice has to have
+        // landed one barrier earlier
+        constexpr int AW = EARLY ? A - 2 : A - 1;
+        static_assert(AW >= 1, "at least one slice of factor loads stays in flight");
+        auto landed = [&]() { // everything but the last AW slices' loads
+            sweep_wait_loads<AW * L>();
         };
         __builtin_amdgcn_s_setprio(3); // (like the hand-off wave: few instructions, and every other wave waits for them at the barrier)
         rebase(0);
@@ -613,6 +622,15 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
             lv_prev[lv_at[0]] = (uint8_t) (w0 ? (uint32_t) qn.x : code_old[0]);
             lv_prev[lv_at[1]] = (uint8_t) (w1 ? (uint32_t) qn.y : code_old[1]);
         };
+        // EARLY: read at the end of the slice before
+        v2f fac_n[NS];
+        uint32_t code_n[R] = {0, 0};
+#pragma unroll
+        for (int si = 0; si < NS; ++si) fac_n[si] = (v2f) 1.0f;
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int si = 0; si < NS; ++si) { fac_n[si].x = f_lane[si * NB * kSweepFBlock]; fac_n[si].y = f_lane[si * NB * kSweepFBlock + 16]; }
+        }
         auto group = [&](int g, auto first_c, auto last_c) {
             constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
             uint8_t* const lv_layer = lvt + (g % 3) * kLvBuf;
@@ -629,14 +647,15 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                 uint32_t code_old[R] = {0, 0};
                 if constexpr (LVS) {
 #pragma unroll
-                    for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
+                    for (int k = 0; k < R; ++k) code_old[k] = EARLY_LV ? code_n[k] : (uint32_t) lv_prev[lv_at[k]];
                 }
                 // per stream and row: the taps' two columns, each (row iy, row iy + 1)
                 v2f ca[NS][R], cb[NS][R], fac[NS];
                 const float* const f_at = f_lane + (K8 % FS) * kFSlot;
 #pragma unroll
                 for (int si = 0; si < NS; ++si) {
-                    fac[si].x = f_at[si * NB * kSweepFBlock]; fac[si].y = f_at[si * NB * kSweepFBlock + 16];
+                    if constexpr (EARLY) fac[si] = fac_n[si];
+                    else { fac[si].x = f_at[si * NB * kSweepFBlock]; fac[si].y = f_at[si * NB * kSweepFBlock + 16]; }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const float* const pt = plane(CUR, si) + tap[si][k];
@@ -713,6 +732,15 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
                         for (int si = 0; si < NS; ++si) lv_l[si] = (v2f) 0.0f;
                     }
                 }
+                if constexpr (EARLY) { // the next slice's factors (landed a barrier ago)
+                    const float* const f_nx = f_lane + ((K8 + 1) % FS) * kFSlot;
+#pragma unroll
+                    for (int si = 0; si < NS; ++si) { fac_n[si].x = f_nx[si * NB * kSweepFBlock]; fac_n[si].y = f_nx[si * NB * kSweepFBlock + 16]; }
+                }
+                if constexpr (EARLY_LV && LVS) { // the voxels this slice's L goes to
+#pragma unroll
+                    for (int k = 0; k < R; ++k) code_n[k] = lv_prev[lv_at[k]];
+                }
                 if constexpr (LV && LAST && K8 == 7) { // the state the next span starts from
 #pragma unroll
                     for (int si = 0; si < NS; ++si) {
@@ -735,7 +763,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
         if constexpr (LVS) { // the last slice's voxels, then the last layer
             uint32_t code_old[R];
 #pragma unroll
-            for (int k = 0; k < R; ++k) code_old[k] = lv_prev[lv_at[k]];
+            for (int k = 0; k < R; ++k) code_old[k] = EARLY_LV ? code_n[k] : (uint32_t) lv_prev[lv_at[k]];
             light_volume_update(code_old);
         }
     }
