@@ -430,14 +430,30 @@ def main():
                   f"{bool(torch.equal(out, full[rows]))}, gathered[rank] vs out: {bool(torch.equal(gathered[rank], out))}", flush=True)
 
     # ---- per-kernel GPU time with HIP events on the library's stream (separate, untimed pass) -------------
-    for k in range(max(3, min(args.steps, 10))):
+    n_event = max(3, min(args.steps, 20))
+    for k in range(n_event):
         one_step(args.warmup + args.steps + k, True)
     for h in pending:
         if h is not None:
             h.wait()
     torch.cuda.synchronize()
-    ray_ms = float(np.mean(ms_ray))
-    illum_ms = float(np.mean(ms_illum)) if ms_illum else 0.0
+    # the MEAN of the event-timed calls, without the calls that took more than 3x the median: a call in which the handle's factor
+    # cache grows (hipMemGetInfo + hipMalloc between the operator's enqueues: milliseconds of host time inside its event pair, a few
+    # times per scene) or the first launch of a kernel instantiation on a fresh box (code-object load) is not a launch duration.
+    # Every call's time, and how many were left out, are in gpu_ms_spread. (Calls that take the remove + add path — the light's
+    # major axis changes, every 6th - 7th step — are 30 - 50 % longer and stay in the mean: they are the benchmark's operators.)
+    def robust_mean(ms):
+        if not ms:
+            return 0.0, 0
+        med = float(np.median(ms))
+        kept = [t for t in ms if t <= 3.0 * med]
+        return float(np.mean(kept)), len(ms) - len(kept)
+
+    ray_ms, ray_dropped = robust_mean(ms_ray)
+    illum_ms, illum_dropped = robust_mean(ms_illum)
+    spread = {"raymarch": [round(float(t), 4) for t in ms_ray], "change_dir_light": [round(float(t), 4) for t in ms_illum],
+              "left_out_above_3x_median": {"raymarch": ray_dropped, "change_dir_light": illum_dropped},
+              "note": "every event-timed call of the gpu_ms pass; gpu_ms quotes their mean without the calls above 3x the median"}
 
     # ---- slab mode: the partitioned + gathered light volume must equal the unpartitioned operator's (untimed replay) ----
     slab_ok = None
@@ -452,7 +468,7 @@ def main():
         res.clear_light_volume(0.0)
         for l in replay:
             res.add_dir_light(l, True, world)
-        for k in range(args.warmup + args.steps + max(3, min(args.steps, 10))):
+        for k in range(args.warmup + args.steps + n_event):
             li = k % len(replay)
             ang[li] += 5.0
             new = abi.DirLightParams(S.rotate_z(light_dirs[li], ang[li]), replay[li].light_intensity)
@@ -515,9 +531,13 @@ def main():
         unc = []
         for li in range(len(lights)):
             new = abi.DirLightParams(S.rotate_z(light_dirs[li], angle[li] + 5.0), lights[li].light_intensity)
-            res.flush()
-            unc.append(gpu_ms(torch, lib_stream, lambda: res.change_dir_light(lights[li], new, world)))
-            res.change_dir_light(new, lights[li], world)
+            best = None
+            for _ in range(2):  # (the better of two, like timed(): the first call of a kernel instantiation loads its code object)
+                res.flush()
+                t = gpu_ms(torch, lib_stream, lambda: res.change_dir_light(lights[li], new, world))
+                best = t if best is None else min(best, t)
+                res.change_dir_light(new, lights[li], world)
+            unc.append(best)
         ops_ms["change_dir_light_uncached"] = float(np.mean(unc))
         abi.set_tunable("light_cache_mb", cache_default)
         res.set_windowing(win)
@@ -595,7 +615,8 @@ def main():
             issue = {"source": where}
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_source,
-                "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4)}
+                "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4),
+                "launch_ms_is": f"mean of {len(ms_ray)} event-timed calls, those above 3x the median left out (gpu_ms_spread lists every call)"}
 
     # ---- CPU baseline: the oracle on this host's cores, rank 0, N=1 only, bounded sample -------------------
     cpu = parity = None
@@ -636,6 +657,7 @@ def main():
             "gpu_ms": dict({"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4)},
                            **{k: round(v, 4) for k, v in ops_ms.items()},
                            first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
+            "gpu_ms_spread": spread,
             "distributed": None if dist is None else {
                 "backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ms_per_step_per_rank": per_rank_ms,
                 "light_update": args.light_update if slab_member is None else "slabs",

@@ -152,12 +152,13 @@ __device__ __forceinline__ bool tile_pixel(const RayParams& p, int& i, int& j, i
 // samples it owns exactly where the unpartitioned loop would, and hands the state on. Positions are still reached by
 // performing every addition of the ray, so every sample, and the early exit, are bit for bit those of the whole march.
 #ifdef TBRM_RAY_STATS // diagnostics build (tools/ray_stats.sh): how full the waves of the lit march are
-__device__ unsigned long long g_ray_stats[4]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples
+__device__ unsigned long long g_ray_stats[6]; // trips of a wave through the loop, lanes not done, lanes sampling, trips in which any lane samples,
+                                              // trips in which any lane has something to accumulate (alpha != 0), such lanes
 extern "C" __attribute__((visibility("default"))) int tbrm_debug_ray_stats(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ray_stats), sizeof(g_ray_stats)) != hipSuccess) return 1;
     if (reset) {
-        const unsigned long long z[4] = {0, 0, 0, 0};
+        const unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_ray_stats), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
@@ -371,6 +372,12 @@ __global__ __launch_bounds__(256, 6) void k_raymarch_lit(const RayParams p) // 6
         // the ray; the early exit belongs to the full steps only (:75-79). A trip in which no lane of the wave has
         // anything to accumulate (empty space, windowed-out values) needs no exchange.
         const bool any_x = __builtin_amdgcn_ballot_w64(x.w >= 0.0f || x.w != x.w) != 0;
+#ifdef TBRM_RAY_STATS
+        {
+            const unsigned long long nx = __builtin_popcountll(__builtin_amdgcn_ballot_w64(x.w >= 0.0f || x.w != x.w));
+            if (lane == 0 && nx) { atomicAdd(&g_ray_stats[4], 1ull); atomicAdd(&g_ray_stats[5], nx); }
+        }
+#endif
         if (any_x) {
             s_x[threadIdx.x] = x;
             __builtin_amdgcn_wave_barrier();

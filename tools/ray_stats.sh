@@ -28,15 +28,16 @@ for config in (3, 5):
     cam = S.default_camera(fb, fb)
     out = torch.empty((fb, fb, 4), dtype=torch.float32, device="cuda")
     lib = abi.load()
-    st = (C.c_ulonglong * 4)()
+    st = (C.c_ulonglong * 6)()
     res.flush()
     lib.tbrm_debug_ray_stats(st, 1)
     res.raymarch_lit_device(cam, abi.Tile(0, 0, fb, fb, 1), abi.RaymarchParams(float(cfg["steps"]), -1, True), world, out.data_ptr())
     res.flush()
     lib.tbrm_debug_ray_stats(st, 0)
-    trips, notdone, live, busy = [int(v) for v in st]
+    trips, notdone, live, busy, contrib_trips, contrib = [int(v) for v in st]
     print(f"config {config}: wave trips {trips}, lanes not done {notdone / (64 * trips):.3f} of the lanes; trips in which any lane samples {busy / trips:.3f}, "
-          f"lanes sampling in those {live / (64 * max(busy, 1)):.3f}")
+          f"lanes sampling in those {live / (64 * max(busy, 1)):.3f}; trips in which any lane has alpha != 0: {contrib_trips / max(busy, 1):.3f} of the sampling trips, "
+          f"lanes with alpha != 0 in those {contrib / (64 * max(contrib_trips, 1)):.3f}, of all sampling lanes {contrib / max(live, 1):.3f}")
     res.close()
 PY
 fi
