@@ -180,10 +180,8 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * load; 4 / 8), chain_fast_loop (1), chain_rect_planes (1), occ_overlap (2 = workgroups per CU of an occlusion launch that
  * runs beside a chunked chain; 0 = one after the other), light_sweep (1 = axis passes take the pipelined sweep kernel where
  * it applies; 2 = except the passes of a Change whose two lights pull opposite ways, which otherwise take two sweeps; 0 = the
- * chunked chain everywhere), sweep_prefetch (0 = 2 slices), sweep_stagger_ns (0 = default start delay per
- * tile of distance, < 0 none), sweep_rows (unused), stream_priority (of a handle's own stream, read by tbrm_resources_create: 0 = default, 1 = highest, -1 = lowest),
- * occ_priority (0 = the occlusion stream has the lowest priority the device
- * offers, 1 = the handle's stream's; read when the handle first needs the stream), sweep_debug (diagnostics: bit 0 tiles do not
+ * chunked chain everywhere), sweep_prefetch (0 = 2 slices), stream_priority (of a handle's own stream, read by tbrm_resources_create: 0 = default, 1 = highest, -1 = lowest),
+ * sweep_debug (diagnostics: bit 0 tiles do not
  * wait for each other, bits 3 / 4 skip buffer hazards — WRONG light volumes —; bit 1 prints per-tile time stamps at tbrm_flush,
  * bit 2 the host's time per operator phase, bit 5 leaves out the events behind tbrm_last_gpu_time_ms), occ_dual (1 = the two
  * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
@@ -194,8 +192,7 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * divide), slab_sweep (0; 1 = a slab's share of a pass along z
  * runs as one sweep instead of the chunked chain: measured, a tie or a loss), gpu_timing (1 = operators record the HIP events behind
  * tbrm_last_gpu_time_ms; 0 = they do not, and tbrm_last_gpu_time_ms fails until an operator has run with it on again), ray_tables (1 = the
- * lit march reads the data taps' offsets out of LDS tables where a step is at most one texel; 0 = computes them per sample), occ_after_frame (0; 1 = an
- * operator's occlusion waits for the lit frame in front of it: measured, loses), ray_xcd_rows (1 = the lit march deals its 8 x 8
+ * lit march reads the data taps' offsets out of LDS tables where a step is at most one texel; 0 = computes them per sample), ray_xcd_rows (1 = the lit march deals its 8 x 8
  * pixel blocks to the GPU's eight XCDs row by row — horizontal neighbours, which march through the same bricks, share an L2 —; n = in
  * bands of n rows; 0 = in launch order, i.e. round-robin block by block: 10 % slower at 512^3). Unknown name: TBRM_ERR_INVALID_ARG. */
 TBRM_API int tbrm_set_tunable(const char* name, int32_t value);

@@ -9,6 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtbrm.so")
 
+SWEEP_TILE_ROWS = 16 if os.environ.get("TBRM_BUILD_VARIANTS") == "1" else 32
+
 # (source, object name, extra flags): tbrm_light_chain.hip is compiled once per light-volume format so that the two halves
 # of the chain kernel's instantiations build in parallel
 UNITS = [
@@ -18,9 +20,10 @@ UNITS = [
     ("tbrm_light_chain.hip", "tbrm_light_chain_u8", ["-DTBRM_CHAIN_LFMT=0"]), ("tbrm_light_chain.hip", "tbrm_light_chain_f32", ["-DTBRM_CHAIN_LFMT=2"]),
     ("tbrm_light_sweep_dispatch.cpp", "tbrm_light_sweep_dispatch", []),
 ] + [
-    # k_light_sweep: one unit per mode (PASS_ADD 0, PASS_CHANGE 1, PASS_ADD2 2, PASS_PLANES 5) and tile height
-    ("tbrm_light_sweep.hip", f"tbrm_light_sweep_m{m}_t{t}", [f"-DTBRM_SWEEP_UNIT_MODE={m}", f"-DTBRM_SWEEP_UNIT_TH={t}"])
-    for t in (16, 32) for m in (1, 0, 2, 5)
+    # k_light_sweep: one unit per mode (PASS_ADD 0, PASS_CHANGE 1, PASS_ADD2 2, PASS_PLANES 5); tile height 32 — the 32 x 16 form
+    # (measured slower) is the variant build: TBRM_BUILD_VARIANTS=1 compiles the library with 16-row tiles instead
+    ("tbrm_light_sweep.hip", f"tbrm_light_sweep_m{m}_t{SWEEP_TILE_ROWS}", [f"-DTBRM_SWEEP_UNIT_MODE={m}", f"-DTBRM_SWEEP_UNIT_TH={SWEEP_TILE_ROWS}"])
+    for m in (1, 0, 2, 5)
 ]
 SOURCES = sorted({u[0] for u in UNITS})
 HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_device_sampling.h", "tbrm_host_math.h", "tbrm_light_chain.h", "tbrm_light_sweep.h", "tbrm_light_passes.h",
@@ -29,7 +32,7 @@ HEADERS = ["tbrm_internal.h", "tbrm_resources.h", "tbrm_device_math.h", "tbrm_de
 # -ffp-contract=off + explicit fma is the arithmetic contract with the oracle (DESIGN.md "Arithmetic spec").
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-    "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function", f"-DTBRM_SWEEP_TILE_ROWS={SWEEP_TILE_ROWS}",
 ]
 
 

@@ -34,8 +34,8 @@ struct TunableDef { const char* name; int def; };
 const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
-    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_rows", 0}, {"sweep_prefetch", 0}, {"sweep_stagger_ns", 0}, {"stream_priority", 0}, {"occ_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_after_frame", 0}, {"occ_dual", 1}, {"ray_xcd_rows", 1},
+    {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_prefetch", 0}, {"stream_priority", 0}, {"sweep_debug", 0},
+    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_dual", 1}, {"ray_xcd_rows", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -445,7 +445,6 @@ int tbrm_resources_destroy(tbrm_resources* r)
         for (hipEvent_t e : r->op_done)
             if (e) (void) hipEventDestroy(e);
     }
-    if (r->frame_done) (void) hipEventDestroy(r->frame_done);
     for (uint16_t* o : r->d_octree) (void) hipFree(o);
     for (uint8_t* d : r->d_dist) (void) hipFree(d);
     (void) hipFree(r->d_alpha_prefix);

@@ -83,11 +83,6 @@ int tbrm_raymarch_lit_device(tbrm_resources* r, const tbrm_camera* cam, const tb
     if (int e = begin_timed(r, 1)) return e;
     HIP_TRY(launch_raymarch(p, r->stream));
     ++r->launches[2];
-    if (tune(TUNE_OCC_AFTER_FRAME) && r->occ_stream) {
-        if (!r->frame_done) HIP_TRY(hipEventCreateWithFlags(&r->frame_done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(r->frame_done, r->stream));
-        r->frame_pending = true;
-    }
     return end_timed(r, 1);
 }
 

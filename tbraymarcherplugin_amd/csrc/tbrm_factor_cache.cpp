@@ -93,7 +93,7 @@ int ensure_occ_stream(tbrm_resources* r)
     if (r->occ_stream) return TBRM_OK;
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, tune(TUNE_OCC_PRIORITY) == 1 ? 0 : least));
+    HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least)); // (the handle's stream's priority instead: measured, no gain)
     for (int k = 0; k < 2; ++k) {
         HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_fork[k], event_flags()));
         HIP_TRY(hipEventCreateWithFlags(&r->occ_ev_ready[k], event_flags()));

@@ -307,12 +307,9 @@ enum Tunable : int {
     TUNE_CHAIN_RECT_PLANES,  // 0: no 72 x 48 LDS planes (a pass with taps two texels wide along x runs 8-slice chunks in square planes)
     TUNE_OCC_OVERLAP,        // workgroups per CU of an occlusion launch that runs beside the previous span's chain (0: never beside it)
     TUNE_LIGHT_SWEEP,        // 0: axis passes never take the pipelined sweep kernel (k_light_sweep); 1: where it applies
-    TUNE_SWEEP_ROWS,         // height of a sweep tile: 32 (default) or 16 (two workgroups per CU: measured, slower)
     TUNE_SWEEP_PREFETCH,     // slices ahead that a sweep tile requests its neighbours' hand-off records (0: default)
-    TUNE_SWEEP_STAGGER_NS,   // start delay of a sweep tile per tile of distance from the upstream corner, ns (0: default; < 0: none)
     TUNE_STREAM_PRIORITY,    // priority of a handle's own stream, read when the handle is created: 0 = default, 1 = the highest the
                              // device offers, -1 = the lowest
-    TUNE_OCC_PRIORITY,       // the occlusion stream's priority: 0 = the lowest the device offers, 1 = the handle's stream's
     TUNE_SWEEP_DEBUG,        // diagnostics. 1: sweep tiles do not wait for each other (WRONG results), 2: per-tile time stamps, 4: host
                              // time per operator phase on stderr, 8 / 16: the occlusion stream skips its waits for the scratch
                              // store / the cache entry to be idle (WRONG results: what gates its start?), 32: no timing events
@@ -327,8 +324,6 @@ enum Tunable : int {
     TUNE_RAY_TABLES,         // 0: k_raymarch_lit computes the data taps' offsets per sample even where its LDS offset tables apply
     TUNE_SWEEP_EPOCH_PRESET, // > 0: a handle's first sweep launch continues from this launch tag (a test hook: the 16-bit tags of the
                              // hand-off records start over after 65535 launches)
-    TUNE_OCC_AFTER_FRAME,    // 1: an operator's occlusion does not start beside a lit frame that is still running (both are bound by
-                             // the same thing, the vector ALUs) but beside the sweeps behind it (which leave two thirds of the issue slots idle)
     TUNE_OCC_DUAL,           // 1: the two axis passes of a light share ONE occlusion launch where their sampling positions are bit-equal
                              // (DualOcc); 0: one launch per pass
     TUNE_RAY_XCD_ROWS,       // k_raymarch_lit: rows of pixel blocks per band dealt to one XCD (0: blocks in launch order, i.e. round-robin)

@@ -82,10 +82,6 @@ static int note_readers(tbrm_resources* r, const PassPlan& plan, uint64_t* op)
 }
 static int wait_for_readers(tbrm_resources* r, uint64_t op)
 {
-    if (r->frame_pending && tune(TUNE_OCC_AFTER_FRAME)) { // (tunable occ_after_frame: not beside the frame that is on its way)
-        HIP_TRY(hipStreamWaitEvent(r->occ_stream, r->frame_done, 0));
-        r->frame_pending = false;
-    }
     if (op == 0) return TBRM_OK;
     const int k = (int) (op % tbrm_resources::kOpEvents);
     if (op != UINT64_MAX && r->op_done_serial[k] >= op) { // (what a later operator recorded in the same slot is later still)

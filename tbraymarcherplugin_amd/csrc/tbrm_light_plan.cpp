@@ -564,7 +564,7 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
     // (measured at 512^3, profiles/r03_sweep_ablation.txt: requests two slices ahead beat three by 3 - 4 %, start delays of 1 - 2 us
     // per hop tie and beat 3 - 4 us)
     q.prefetch = tune(TUNE_SWEEP_PREFETCH) > 0 ? std::min(tune(TUNE_SWEEP_PREFETCH), 6) : 2;
-    q.stagger_ns = tune(TUNE_SWEEP_STAGGER_NS) != 0 ? std::max(tune(TUNE_SWEEP_STAGGER_NS), 0) : 1500;
+    q.stagger_ns = 1500;
     q.debug = tune(TUNE_SWEEP_DEBUG);
     q.reinit_slice = pa.dir < 0 ? pad : 0;
     q.n_real = pa.dir > 0 ? D - pad : D;

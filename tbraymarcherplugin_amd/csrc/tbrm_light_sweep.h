@@ -62,9 +62,12 @@ inline int sweep_halo_chunks(int hx, int hy, int th) { return (th * hx + kSweepT
 inline int sweep_record_words(int hx, int hy, int th) { return th * hx + kSweepTile * hy; }
 
 
-// The tile height a handle's sweeps run with (tunable sweep_rows: 16 or 32; 0 = the default). 32 x 16 tiles put TWO workgroups
-// on a CU: each is a lockstep chain of LDS reads -> arithmetic -> LDS writes -> barrier, and two of them out of phase fill each
-// other's waits (the 32 x 32 form left the vector ALUs idle two thirds of a slice), for 16 more hops of pipeline fill.
+// The tile height the library's sweeps are built with: 32, or — a build variant, measured slower — 16: two workgroups on a CU,
+// each a lockstep chain of LDS reads -> arithmetic -> LDS writes -> barrier, for 16 more hops of pipeline fill.
+#ifndef TBRM_SWEEP_TILE_ROWS
+#define TBRM_SWEEP_TILE_ROWS 32
+#endif
+static_assert(TBRM_SWEEP_TILE_ROWS == 32 || TBRM_SWEEP_TILE_ROWS == 16, "sweep tiles are 32 x 32 or 32 x 16");
 int sweep_tile_rows();
 
 // one translation unit per (mode, tile height): tbrm_light_sweep.hip compiled with -DTBRM_SWEEP_UNIT_MODE / _TH

@@ -4,11 +4,10 @@
 
 namespace tbrm {
 
-int sweep_tile_rows()
-{
-    const int t = tune(TUNE_SWEEP_ROWS);
-    return t == 16 ? 16 : 32; // (32 x 16 measured: the free tile 17 % faster per slice, 16 more hops at 3.5 - 4.3 instead of 2.7 - 3.1 us each: slower)
-}
+// 32 x 32 tiles. The 32 x 16 form (two workgroups per CU) is a build variant (TBRM_BUILD_VARIANTS=1 builds the library with
+// -DTBRM_SWEEP_TILE_ROWS=16): measured in round 5, the free tile is 17 % faster per slice, but 16 more hops at 3.5 - 4.3 instead
+// of 2.7 - 3.1 us each make every pass slower (profiles/r05_sweep_variants_tile_rows_loader_depth.txt).
+int sweep_tile_rows() { return TBRM_SWEEP_TILE_ROWS; }
 
 // advances every tile through the span (j0, n_steps) in one launch; mode PASS_ADD, PASS_CHANGE, PASS_ADD2 or PASS_PLANES, the
 // span whole brick layers of the light volume, the occlusion factors handed over block-compact; q.tile_rows: the tiles' height
@@ -21,13 +20,13 @@ hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mo
     if (q.r_from_records && (mode != PASS_CHANGE || !q.rec[1])) return hipErrorInvalidConfiguration;
     if (q.reinit_slice < 0 || q.reinit_slice > 7 || (q.reinit_slice > 0 && p.n_steps < 16)) return hipErrorInvalidConfiguration;
     if (q.n_real > p.n_steps || q.n_real <= p.n_steps - 8) return hipErrorInvalidConfiguration; // (padding: less than one brick layer)
-    if (q.tile_rows != 16 && q.tile_rows != 32) return hipErrorInvalidConfiguration;
+    if (q.tile_rows != TBRM_SWEEP_TILE_ROWS) return hipErrorInvalidConfiguration;
     if (p.tiles_x != (p.W + kSweepTile - 1) / kSweepTile || p.tiles_y != (p.H + q.tile_rows - 1) / q.tile_rows) return hipErrorInvalidConfiguration;
-    const bool half = q.tile_rows == 16;
-    if (mode == PASS_ADD) return half ? launch_sweep_unit<PASS_ADD, 16>(p, q, s) : launch_sweep_unit<PASS_ADD, 32>(p, q, s);
-    if (mode == PASS_CHANGE) return half ? launch_sweep_unit<PASS_CHANGE, 16>(p, q, s) : launch_sweep_unit<PASS_CHANGE, 32>(p, q, s);
-    if (mode == PASS_ADD2) return half ? launch_sweep_unit<PASS_ADD2, 16>(p, q, s) : launch_sweep_unit<PASS_ADD2, 32>(p, q, s);
-    if (mode == PASS_PLANES) return half ? launch_sweep_unit<PASS_PLANES, 16>(p, q, s) : launch_sweep_unit<PASS_PLANES, 32>(p, q, s);
+    constexpr int TH = TBRM_SWEEP_TILE_ROWS;
+    if (mode == PASS_ADD) return launch_sweep_unit<PASS_ADD, TH>(p, q, s);
+    if (mode == PASS_CHANGE) return launch_sweep_unit<PASS_CHANGE, TH>(p, q, s);
+    if (mode == PASS_ADD2) return launch_sweep_unit<PASS_ADD2, TH>(p, q, s);
+    if (mode == PASS_PLANES) return launch_sweep_unit<PASS_PLANES, TH>(p, q, s);
     return hipErrorInvalidConfiguration;
 }
 

@@ -183,8 +183,6 @@ struct tbrm_resources {
     hipEvent_t op_done[kOpEvents]{};
     uint64_t op_done_serial[kOpEvents]{}; // which operator each was last recorded for (0: never)
     bool op_many_passes = false;   // the operator being enqueued has more than two sweep passes: its buffers may come round again
-    hipEvent_t frame_done = nullptr; // the last lit frame is done (the handle's stream; tunable occ_after_frame)
-    bool frame_pending = false;      // ... recorded since the occlusion stream last waited for it
     uint64_t kept_hits = 0, kept_computed = 0; // stream-passes whose occlusion came from the cache / was computed (tbrm_light_cache_stats)
     size_t f_est_blocks = 0;       // live blocks per pass seen under f_est_key (what a new entry is sized for)
     uint64_t f_est_key[2] = {0, 0};

@@ -30,7 +30,6 @@ python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only
  echo "== the same, light_cache_mb=0"; TBRM_LIGHT_CACHE_MB=0 python tools/change_sequence.py 2>&1 | grep -v amdgpu.ids | head -6
  echo "== tools/sweep_stamps.py (timeline of one sweep launch)"; python tools/sweep_stamps.py 2>&1 | grep -v amdgpu.ids | tee /tmp/stamps32.txt
  echo "== tools/stamps_summary.py of the above (32 x 32 tiles)"; python tools/stamps_summary.py < /tmp/stamps32.txt
- echo "== the same with 32 x 16 tiles, two workgroups per CU (tunable sweep_rows = 16)"; TUNE=sweep_rows=16 python tools/sweep_stamps.py 2>&1 | grep -v amdgpu.ids | python tools/stamps_summary.py
  echo "== tools/host_enqueue_time.py"; python tools/host_enqueue_time.py 2>&1 | grep -v amdgpu.ids) >> "$OUT/operators.txt"
 for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
 TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"

@@ -16,7 +16,7 @@ vol = S.make_volume_torch((n, n, n), cfg["dtype"], S.seed_for_config(3), dev)
 world = S.default_world()
 variants = os.environ.get("VARIANTS", "light_sweep=0;light_sweep=1").split(";")
 for var in variants:
-    tun = dict(light_cache_mb=-1, force_slice_kernel=0, occ_overlap=4, light_sweep=1, sweep_prefetch=0, sweep_stagger_ns=0, occ_slices=0, sweep_debug=0)
+    tun = dict(light_cache_mb=-1, force_slice_kernel=0, occ_overlap=4, light_sweep=1, sweep_prefetch=0, occ_slices=0, sweep_debug=0)
     for kv in var.split(","):
         if kv.strip():
             k, v = kv.split("=")
