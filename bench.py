@@ -14,11 +14,13 @@ N>1 (one process per GPU, torch.distributed/RCCL; `python bench.py --gpus N` fro
 torch.distributed.run): THE SAME WORKLOAD as N=1 — config 3 — at every N, so that value(N) / value(1) is a speed-up: STRONG
 scaling of one fixed frame, rank r renders every N-th group of 8 rows (load-balanced interleave), volumes are replicated,
 the selective light update is computed redundantly on every GPU (no data-path collective: the update of ONE light is one
-serial slice sweep per axis) and the only exchange is the all_gather of the tiles. The line reports the full
-step, the raymarch-only rate, the same workload timed on one GPU in the same run (top-level `speedup_vs_one_gpu`,
-`frame_speedup_vs_one_gpu`) and the Amdahl ceiling the redundant update puts on the step. `--config 5` runs north_star's
-scaling workload instead (512^3, ONE 2048^2 frame, 8 lights, TF-B, skipping on); `--weak` keeps round 1's mode (the
-framebuffer grows to ~N x fb^2 pixels).
+serial slice sweep per axis) and the only exchange is the gather of the tiles (`--gather all`: all_gather, the
+default; `--gather root`: to rank 0 only). The line reports the full step, the same workload timed on one GPU in the same run
+(`speedup_vs_one_gpu`), the Amdahl ceiling the redundant update puts on the step, and — second timed loops, raymarch only,
+WALL CLOCK WITH THE GATHER INSIDE — `frame_delivery` (this workload's frame: one GPU / tiles + all-gather / tiles + gather to
+root; `frame_speedup_vs_one_gpu` is taken from it) and `tile_parallel` (the same three for north_star's tile-scaling workload,
+config 5: 512^3, ONE 2048^2 frame, 8 lights, TF-B, skipping on — at this N and on one GPU in the same run). `--config 5` makes
+config 5 the whole step's workload; `--weak` keeps round 1's mode (the framebuffer grows to ~N x fb^2 pixels).
 
 value = nominal samples of all ranks per step / step time, in Msamples/s (nominal sample = one loop iteration of
 PerformWindowedLitRaymarch that geometry prescribes, independent of early termination and skipping).
@@ -126,6 +128,99 @@ def gpu_ms(torch, stream, fn):
     return float(e0.elapsed_time(e1))
 
 
+def frame_delivery(torch, dist, abi, res, cam, fb_w, fb_h, rp, world, rank, n_gpus, device, lib_stream, one_gpu_dry_run, frames, samples_per_frame, sync=None):
+    """What tile-parallel rendering delivers, by WALL CLOCK (barrier + synchronize on both sides, max over ranks), for the frame of
+    the handle's scene: (a) one GPU renders the whole frame, no exchange; (b) N GPUs render interleaved 8-row tiles and all-gather
+    them (the frame lands in every GPU); (c) the same with a gather to rank 0 only (RCCL send / recv: the frame lands where it is
+    presented). Tiles and gather buffers are double-buffered exactly like the timed step's. Speed-ups are (a) / (b), (a) / (c):
+    they INCLUDE the gather — the ratio of raymarch kernel times does not and reads ~N by construction."""
+    sync = sync or torch.cuda.synchronize  # (tests/test_bench_delivery.py runs this function on CPU tensors over gloo)
+    rows = fb_h // n_gpus
+    tile = abi.Tile(0, 8 * rank, fb_w, rows, n_gpus)
+    full_tile = abi.Tile(0, 0, fb_w, fb_h, 1)
+    red_device = torch.device("cpu") if one_gpu_dry_run else device
+    outs = [torch.empty((rows, fb_w, 4), dtype=torch.float32, device=device) for _ in range(2)]
+    alls = [torch.empty((n_gpus, rows, fb_w, 4), dtype=torch.float32, device=device) for _ in range(2)]
+    roots = [torch.empty((n_gpus, rows, fb_w, 4), dtype=torch.float32, device=device) if rank == 0 else None for _ in range(2)]
+    full = torch.empty((fb_h, fb_w, 4), dtype=torch.float32, device=device)
+
+    def gather(kind, b):
+        if kind == "none":
+            return None
+        if one_gpu_dry_run:  # gloo: staged through host memory, synchronous
+            res.flush()
+            host = outs[b].cpu()
+            if kind == "all":
+                parts = [torch.empty(host.shape, dtype=host.dtype) for _ in range(n_gpus)]
+                dist.all_gather(parts, host)
+                alls[b].copy_(torch.stack(parts))
+            else:
+                parts = [torch.empty(host.shape, dtype=host.dtype) for _ in range(n_gpus)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0:
+                    roots[b].copy_(torch.stack(parts))
+            return None
+        with torch.cuda.stream(lib_stream):  # ordered behind the march on the library's stream; nothing waits on the host
+            if kind == "all":
+                return dist.all_gather_into_tensor(alls[b], outs[b], async_op=True)
+            return dist.gather(outs[b], list(roots[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+
+    def loop(kind, count):
+        pend = [None, None]
+        for k in range(count):
+            b = k & 1
+            if pend[b] is not None:
+                with torch.cuda.stream(lib_stream):
+                    pend[b].wait()
+                pend[b] = None
+            if kind == "none":
+                res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())
+            else:
+                res.raymarch_lit_device(cam, tile, rp, world, outs[b].data_ptr())
+                pend[b] = gather(kind, b)
+        for h in pend:
+            if h is not None:
+                h.wait()
+
+    def timed(kind):
+        loop(kind, 2)
+        res.flush()
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        loop(kind, frames)
+        res.flush()
+        dist.barrier()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / frames * 1e3
+
+    one_ms = timed("none")
+    all_ms = timed("all")
+    root_ms = timed("root")
+    # the frame that reached rank 0 through each gather must be this rank's own render of the whole framebuffer
+    from tbraymarcherplugin_amd import sharding
+
+    res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())
+    res.flush()
+    last = (frames - 1) & 1
+    ok_all = bool(torch.equal(sharding.assemble(alls[last], fb_h, n_gpus), full))
+    ok_root = bool(torch.equal(sharding.assemble(roots[last], fb_h, n_gpus), full)) if rank == 0 else None
+    frame_bytes = fb_w * fb_h * 16
+
+    def rate(ms):
+        return round(samples_per_frame / (ms * 1e-3) / 1e9, 2)
+
+    return {"framebuffer": [fb_w, fb_h], "frames_timed": frames, "nominal_samples_per_frame": int(samples_per_frame),
+            "frame_bytes": frame_bytes, "timing": "wall clock around the loop, barrier + synchronize on both sides, max over ranks; gathers asynchronous and double-buffered",
+            "one_gpu": {"ms_per_frame": round(one_ms, 4), "gsamples_per_s": rate(one_ms)},
+            "tiles_all_gather": {"ms_per_frame": round(all_ms, 4), "gsamples_per_s": rate(all_ms), "speedup_vs_one_gpu": round(one_ms / all_ms, 3),
+                                 "bytes_received_per_gpu": frame_bytes * (n_gpus - 1) // n_gpus, "frame_equals_one_gpu_render": ok_all},
+            "tiles_gather_to_root": {"ms_per_frame": round(root_ms, 4), "gsamples_per_s": rate(root_ms), "speedup_vs_one_gpu": round(one_ms / root_ms, 3),
+                                     "bytes_received_by_root": frame_bytes * (n_gpus - 1) // n_gpus, "frame_equals_one_gpu_render": ok_root}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +245,10 @@ def main():
                     help="N>1: how the step's ChangeDirLight reaches every GPU. redundant (default): every GPU computes it (no exchange). "
                          "broadcast: rank 0 computes it and broadcasts the light volume (SURVEY.md 8e's other option; on the critical path "
                          "Change + broadcast + frame / N cannot beat Change + frame / N: reported for comparison)")
+    ap.add_argument("--gather", choices=["all", "root"], default="all",
+                    help="N>1: how the timed step's tiles are assembled. all (default): all_gather_into_tensor, the frame lands in every GPU. "
+                         "root: a gather to rank 0 only (RCCL send / recv), the frame lands where it is presented. Whatever this is, the line's "
+                         "frame_delivery / tile_parallel blocks time BOTH forms in raymarch-only loops.")
     ap.add_argument("--slab-illumination", action="store_true",
                     help="N>1: the timed ChangeDirLight is partitioned over the ranks in light-volume z slabs (plane halo exchange "
                          "per chunk / z pipeline, slabs.py), followed by an all-gather of the light volume, instead of being "
@@ -274,7 +373,9 @@ def main():
     # Two output tiles / gather buffers: the all-gather of frame k runs (asynchronously, on RCCL's stream) while the light
     # update of frame k+1 is already executing on the library's stream; a buffer is reused only after its gather is done.
     outs = [torch.empty((rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) for _ in range(2)]
-    gathers = [torch.empty((n_gpus, rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) for _ in range(2)] if dist is not None else [None, None]
+    root_only = args.gather == "root" and dist is not None
+    gathers = ([torch.empty((n_gpus, rows_per_rank, fb_w, 4), dtype=torch.float32, device=device) if (rank == 0 or not root_only) else None for _ in range(2)]
+               if dist is not None else [None, None])
     pending = [None, None]
     out, gathered = outs[0], gathers[0]
     my_samples = res.count_nominal_samples(cam, tile, rp, world)
@@ -360,14 +461,23 @@ def main():
         if dist is not None:
             if one_gpu_dry_run:
                 res.flush()
-                parts = [torch.empty(outs[b].shape, dtype=outs[b].dtype) for _ in range(n_gpus)]
-                dist.all_gather(parts, outs[b].cpu())
-                gathers[b].copy_(torch.stack(parts))
+                if root_only:
+                    parts = [torch.empty(outs[b].shape, dtype=outs[b].dtype) for _ in range(n_gpus)] if rank == 0 else None
+                    dist.gather(outs[b].cpu(), parts, dst=0)
+                    if rank == 0:
+                        gathers[b].copy_(torch.stack(parts))
+                else:
+                    parts = [torch.empty(outs[b].shape, dtype=outs[b].dtype) for _ in range(n_gpus)]
+                    dist.all_gather(parts, outs[b].cpu())
+                    gathers[b].copy_(torch.stack(parts))
             else:
                 if os.environ.get("TBRM_BENCH_HOST_SYNC") == "1":  # A/B: drain the library's stream on the host before the gather
                     res.flush()
                 with torch.cuda.stream(lib_stream):
-                    pending[b] = dist.all_gather_into_tensor(gathers[b], outs[b], async_op=True)
+                    if root_only:
+                        pending[b] = dist.gather(outs[b], list(gathers[b].unbind(0)) if rank == 0 else None, dst=0, async_op=True)
+                    else:
+                        pending[b] = dist.all_gather_into_tensor(gathers[b], outs[b], async_op=True)
         last[0] = b
         if record:
             if not args.raymarch_only and slab_member is None:
@@ -419,12 +529,12 @@ def main():
     if dist is not None:
         from tbraymarcherplugin_amd import sharding
 
-        frame = sharding.assemble(gathered, fb_h, n_gpus)
         full = torch.empty((fb_h, fb_w, 4), dtype=torch.float32, device=device)
         res.raymarch_lit_device(cam, abi.Tile(0, 0, fb_w, fb_h, 1), rp, world, full.data_ptr())
         res.flush()
-        gather_ok = bool(torch.equal(frame, full))
-        if not gather_ok and os.environ.get("TBRM_BENCH_DEBUG"):
+        frame = sharding.assemble(gathered, fb_h, n_gpus) if gathered is not None else None  # (--gather root: rank 0 alone holds it)
+        gather_ok = bool(torch.equal(frame, full)) if frame is not None else None
+        if gather_ok is False and os.environ.get("TBRM_BENCH_DEBUG"):
             rows = torch.from_numpy(sharding.rank_rows(fb_h, rank, n_gpus)).to(device)
             print(f"[rank {rank}] frame-full max|d| = {float((frame - full).abs().max())}, own tile vs own full: "
                   f"{bool(torch.equal(out, full[rows]))}, gathered[rank] vs out: {bool(torch.equal(gathered[rank], out))}", flush=True)
@@ -453,6 +563,8 @@ def main():
     illum_ms, illum_dropped = robust_mean(ms_illum)
     spread = {"raymarch": [round(float(t), 4) for t in ms_ray], "change_dir_light": [round(float(t), 4) for t in ms_illum],
               "left_out_above_3x_median": {"raymarch": ray_dropped, "change_dir_light": illum_dropped},
+              "plain_mean": {"raymarch": round(float(np.mean(ms_ray)), 4) if ms_ray else None, "change_dir_light": round(float(np.mean(ms_illum)), 4) if ms_illum else None},
+              "median": {"raymarch": round(float(np.median(ms_ray)), 4) if ms_ray else None, "change_dir_light": round(float(np.median(ms_illum)), 4) if ms_illum else None},
               "note": "every event-timed call of the gpu_ms pass; gpu_ms quotes their mean without the calls above 3x the median"}
 
     # ---- slab mode: the partitioned + gathered light volume must equal the unpartitioned operator's (untimed replay) ----
@@ -575,6 +687,39 @@ def main():
             one_ray_ms = res.last_gpu_time_ms(1)
             one_gpu = {"ms_per_step": round(one_ms, 4), "raymarch_ms": round(one_ray_ms, 4)}
 
+    # ---- N > 1: what the tiles DELIVER, wall clock with the gather inside (second timed loops, raymarch only) -------------
+    # frame_delivery: this run's workload (config 3 by default). tile_parallel: north_star's tile-scaling workload, config 5
+    # (512^3, ONE 2048^2 frame, 8 lights, TF-B) at this N and on one GPU in the same run — the number "tile-parallel scaling" is about.
+    delivery = tile_parallel = None
+    if dist is not None and slab_member is None and not args.timed_only and not args.weak:
+        k_frames = max(5, min(args.steps, 20))
+        delivery = frame_delivery(torch, dist, abi, res, cam, fb_w, fb_h, rp, world, rank, n_gpus, device, lib_stream, one_gpu_dry_run, k_frames, total_samples)
+        delivery["workload"] = f"config {args.config}"
+        if args.config == 5:
+            tile_parallel = delivery
+        else:
+            cfg5 = S.CONFIGS[5]
+            n5, fb5 = cfg5["n"], cfg5["fb"]
+            if fb5 % (8 * n_gpus) == 0:
+                vol5 = S.make_volume_torch((n5, n5, n5), cfg5["dtype"], S.seed_for_config(5), device)
+                res5 = abi.Resources((n5, n5, n5), abi.DTYPE_FMT[np.dtype(cfg5["dtype"])], cfg5["light_32bit"], False, local_rank)
+                torch.cuda.synchronize()
+                res5.upload_volume_device(vol5.data_ptr(), vol5.numel() * vol5.element_size())
+                res5.set_tf_lut(abi.color_curve_to_lut(S.tf_keys(cfg5["tf"])))
+                res5.set_windowing(abi.WindowingParams(*cfg5["window"]))
+                res5.clear_light_volume(0.0)
+                for i in cfg5["lights"]:
+                    res5.add_dir_light(S.light(i), True, world)
+                res5.flush()
+                cam5 = S.default_camera(fb5, fb5)
+                rp5 = abi.RaymarchParams(float(cfg5["steps"]), -1, not args.no_skipping)
+                samples5 = res5.count_nominal_samples(cam5, abi.Tile(0, 0, fb5, fb5, 1), rp5, world)
+                stream5 = torch.cuda.ExternalStream(res5.stream(), device=device)
+                tile_parallel = frame_delivery(torch, dist, abi, res5, cam5, fb5, fb5, rp5, world, rank, n_gpus, device, stream5, one_gpu_dry_run, k_frames, samples5)
+                tile_parallel["workload"] = "config 5: 512^3 uint16 volume, ONE 2048x2048 RGBA f32 frame, 512 steps, 8 dir lights, TF-B, empty-space skipping on; raymarch only"
+                res5.close()
+                del vol5
+
     # ---- roofline of the dominant kernel (algorithmic bytes) -------------------------------
     b_data = np.dtype(cfg["dtype"]).itemsize
     b_light = 4 if cfg["light_32bit"] else 1
@@ -633,7 +778,8 @@ def main():
             # (update + 1/N of the frame); and what was measured
             ceiling = one_gpu["ms_per_step"] / (one_gpu["ms_per_step"] - one_gpu["raymarch_ms"] * (1.0 - 1.0 / n_gpus))
             scaling_note = {"one_gpu_same_workload": one_gpu, "speedup_vs_one_gpu": round(one_gpu["ms_per_step"] / step_ms, 3),
-                            "raymarch_only_speedup_vs_one_gpu": round(one_gpu["raymarch_ms"] / ray_ms, 3),
+                            # ratio of raymarch KERNEL event times: compute only, the gather is not in it (reads ~N by construction)
+                            "raymarch_kernel_speedup_vs_one_gpu": round(one_gpu["raymarch_ms"] / ray_ms, 3),
                             "amdahl_ceiling_with_redundant_light_update": round(ceiling, 3)}
         line = {
             "metric": "volume Msamples/s (rays x steps) at 512^3, 1024^2 view; % HBM roofline",
@@ -669,7 +815,11 @@ def main():
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)
             # N > 1: this line's step against the SAME workload on one GPU in the same run (whole step; the frame alone)
             "speedup_vs_one_gpu": None if scaling_note is None else scaling_note["speedup_vs_one_gpu"],
-            "frame_speedup_vs_one_gpu": None if scaling_note is None else scaling_note["raymarch_only_speedup_vs_one_gpu"],
+            # the frame alone, WALL CLOCK WITH THE GATHER INSIDE (frame_delivery: the form of the timed step's --gather)
+            "frame_speedup_vs_one_gpu": None if delivery is None else delivery["tiles_gather_to_root" if args.gather == "root" else "tiles_all_gather"]["speedup_vs_one_gpu"],
+            "gather": None if dist is None else args.gather,
+            "frame_delivery": delivery,
+            "tile_parallel": tile_parallel,
             "scaling_detail": scaling_note,
             "roofline": roofline,
             "roofline_issue": issue,

@@ -40,49 +40,52 @@ public:
         const int N = (int) Handles.size();
         if (N == 0 || Devices.size() != Handles.size()) throw std::invalid_argument("FTileGroup: one device per handle");
         if (Width <= 0 || Height <= 0 || Height % (8 * N)) throw std::invalid_argument("FTileGroup: the height must split into groups of 8 rows per handle");
+#ifndef TBRM_TILES_WITH_RCCL
+        if (Gather == EGather::Rccl) throw std::invalid_argument("FTileGroup: built without TBRM_TILES_WITH_RCCL"); // (before anything is allocated)
+#endif
         RowsPerHandle = Height / N;
-        for (int k = 0; k < N; ++k) {
-            void* S = nullptr;
-            Check(tbrm_stream(Handles[k], &S), "tbrm_stream");
-            Streams.push_back((hipStream_t) S);
-            Hip(hipSetDevice(Devices[k]), "hipSetDevice");
-            hipEvent_t A = nullptr, B = nullptr;
-            Hip(hipEventCreateWithFlags(&A, hipEventDisableTiming), "hipEventCreateWithFlags");
-            Hip(hipEventCreateWithFlags(&B, hipEventDisableTiming), "hipEventCreateWithFlags");
-            Rendered.push_back(A);
-            Gathered.push_back(B);
-            void *T = nullptr, *F = nullptr, *G = nullptr;
-            Hip(hipMalloc(&T, TileBytes()), "hipMalloc");
-            Hip(hipMalloc(&F, FrameBytes()), "hipMalloc");
-            if (Gather == EGather::Rccl) Hip(hipMalloc(&G, FrameBytes()), "hipMalloc"); // the tiles of all handles, handle-major
-            Tiles.push_back((float*) T);
-            Frames.push_back((float*) F);
-            Staging.push_back((float*) G);
-        }
-        if (Gather == EGather::Rccl) {
+        // every per-handle slot exists (null) before the first allocation: whatever throws below, Release() frees what was made
+        Streams.assign(N, nullptr);
+        Rendered.assign(N, nullptr);
+        Gathered.assign(N, nullptr);
+        Tiles.assign(N, nullptr);
+        Frames.assign(N, nullptr);
+        Staging.assign(N, nullptr);
+        try {
+            for (int k = 0; k < N; ++k) {
+                void* S = nullptr;
+                Check(tbrm_stream(Handles[k], &S), "tbrm_stream");
+                Streams[k] = (hipStream_t) S;
+                Hip(hipSetDevice(Devices[k]), "hipSetDevice");
+                // direct copies between the handles' devices (xGMI); "already enabled" is fine, "not supported" leaves the runtime's staged path
+                for (int j = 0; j < N; ++j)
+                    if (Devices[j] != Devices[k]) {
+                        int Can = 0;
+                        if (hipDeviceCanAccessPeer(&Can, Devices[k], Devices[j]) == hipSuccess && Can) {
+                            const hipError_t E = hipDeviceEnablePeerAccess(Devices[j], 0);
+                            if (E != hipSuccess && E != hipErrorPeerAccessAlreadyEnabled) Hip(E, "hipDeviceEnablePeerAccess");
+                            (void) hipGetLastError();
+                            PeerDirect = true;
+                        }
+                    }
+                Hip(hipEventCreateWithFlags(&Rendered[k], hipEventDisableTiming), "hipEventCreateWithFlags");
+                Hip(hipEventCreateWithFlags(&Gathered[k], hipEventDisableTiming), "hipEventCreateWithFlags");
+                Hip(hipMalloc((void**) &Tiles[k], TileBytes()), "hipMalloc");
+                Hip(hipMalloc((void**) &Frames[k], FrameBytes()), "hipMalloc");
+                if (Gather == EGather::Rccl) Hip(hipMalloc((void**) &Staging[k], FrameBytes()), "hipMalloc"); // the tiles of all handles, handle-major
+            }
 #ifdef TBRM_TILES_WITH_RCCL
-            Comms.resize(N);
-            Nccl(ncclCommInitAll(Comms.data(), N, Devices.data()), "ncclCommInitAll");
-#else
-            throw std::invalid_argument("FTileGroup: built without TBRM_TILES_WITH_RCCL");
+            if (Gather == EGather::Rccl) {
+                Comms.assign(N, nullptr);
+                Nccl(ncclCommInitAll(Comms.data(), N, Devices.data()), "ncclCommInitAll");
+            }
 #endif
+        } catch (...) {
+            Release(); // (a destructor does not run for an object whose constructor threw)
+            throw;
         }
     }
-    ~FTileGroup()
-    {
-        for (tbrm_resources* H : Handles) (void) tbrm_flush(H);
-#ifdef TBRM_TILES_WITH_RCCL
-        for (ncclComm_t C : Comms) (void) ncclCommDestroy(C);
-#endif
-        for (size_t k = 0; k < Handles.size(); ++k) {
-            (void) hipSetDevice(Devices[k]);
-            (void) hipEventDestroy(Rendered[k]);
-            (void) hipEventDestroy(Gathered[k]);
-            (void) hipFree(Tiles[k]);
-            (void) hipFree(Frames[k]);
-            (void) hipFree(Staging[k]);
-        }
-    }
+    ~FTileGroup() { Release(); }
     FTileGroup(const FTileGroup&) = delete;
     FTileGroup& operator=(const FTileGroup&) = delete;
 
@@ -148,8 +151,30 @@ public:
     }
     tbrm_resources* Handle(int k) const { return Handles[k]; }
     const float* Frame(int k) const { return Frames[k]; }
+    bool PeerDirect = false; // some pair of the handles' devices copies directly (hipDeviceEnablePeerAccess succeeded)
 
 private:
+    void Release() // idempotent; also the clean-up of a constructor that threw half way
+    {
+        for (tbrm_resources* H : Handles) (void) tbrm_flush(H);
+#ifdef TBRM_TILES_WITH_RCCL
+        for (ncclComm_t& C : Comms) {
+            if (C) (void) ncclCommDestroy(C);
+            C = nullptr;
+        }
+#endif
+        for (size_t k = 0; k < Tiles.size(); ++k) {
+            (void) hipSetDevice(Devices[k]);
+            if (Rendered[k]) (void) hipEventDestroy(Rendered[k]);
+            if (Gathered[k]) (void) hipEventDestroy(Gathered[k]);
+            (void) hipFree(Tiles[k]);
+            (void) hipFree(Frames[k]);
+            (void) hipFree(Staging[k]);
+            Rendered[k] = Gathered[k] = nullptr;
+            Tiles[k] = Frames[k] = Staging[k] = nullptr;
+        }
+    }
+
     std::vector<tbrm_resources*> Handles;
     std::vector<int> Devices;
     int Width, Height, RowsPerHandle = 0;

@@ -4,6 +4,9 @@
 //   g++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include tests/cpp/tiles_test.cpp -L <lib> -ltbrm -L /opt/rocm/lib -lamdhip64
 //   (+ -DTBRM_TILES_WITH_RCCL -lrccl: the gather by ncclAllGather)
 //   tiles_test <handles> <gather: 0 peer copies to handle 0, 1 peer copies to every handle, 2 RCCL>
+// TBRM_TILES_DEVICES=0,1,2,3 puts handle k on the k-th listed device (wrapping around a shorter list; default: every handle on
+// device 0, the one-GPU box's form) — the same binary runs over 2 - 8 real devices unchanged; the reference handle that does
+// everything alone lives on the first listed device.
 #include "tbrm_tiles.hpp"
 
 #include <cmath>
@@ -42,7 +45,24 @@ int main(int argc, char** argv)
 {
     const int n_handles = argc > 1 ? std::atoi(argv[1]) : 2;
     const int mode = argc > 2 ? std::atoi(argv[2]) : 0;
-    const int n = 64, fw = 136, fh = 96; // (96 = 8 x 12: splits over 1, 2, 3, 4, 6 handles; a width that is no multiple of 8)
+    const int n = 64, fw = 136, fh = n_handles == 8 ? 128 : 96; // (96 = 8 x 12: splits over 1, 2, 3, 4, 6 handles; 128 over 8; a width that is no multiple of 8)
+    std::vector<int> listed;
+    if (const char* e = std::getenv("TBRM_TILES_DEVICES")) {
+        for (const char* c = e; *c;) {
+            char* end = nullptr;
+            const long d = std::strtol(c, &end, 10);
+            if (end == c) break;
+            listed.push_back((int) d);
+            c = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (listed.empty()) listed.push_back(0);
+    int n_dev = 0;
+    TRY(tbrm_device_count(&n_dev));
+    for (int d : listed)
+        if (d < 0 || d >= n_dev) { std::printf("TBRM_TILES_DEVICES names device %d, the box has %d\n", d, n_dev); return 2; }
+    std::vector<int> devices((size_t) n_handles);
+    for (int k = 0; k < n_handles; ++k) devices[(size_t) k] = listed[(size_t) k % listed.size()];
     const std::vector<uint16_t> vol = make_volume(n);
     tbrm_resources_desc desc{};
     desc.dim_x = desc.dim_y = desc.dim_z = n;
@@ -54,7 +74,10 @@ int main(int argc, char** argv)
     const tbrm_windowing_params win{0.5f, 0.9f, 1, 0};
 
     std::vector<tbrm_resources*> handles(n_handles + 1, nullptr); // [n_handles]: the one that does everything alone
-    for (tbrm_resources*& h : handles) {
+    for (size_t k = 0; k < handles.size(); ++k) {
+        tbrm_resources*& h = handles[k];
+        desc.device = k < devices.size() ? devices[k] : listed[0];
+        if (hipSetDevice(desc.device) != hipSuccess) return 4;
         TRY(tbrm_resources_create(&desc, &h));
         TRY(tbrm_upload_volume(h, vol.data(), vol.size() * 2));
         TRY(tbrm_set_tf_lut(h, lut));
@@ -86,9 +109,10 @@ int main(int argc, char** argv)
 
     const std::vector<tbrm_dir_light_params> lights = {{{1, .35, -.5}, 0.5f, 0}, {{-.4, 1, -.3}, 0.4f, 0}, {{.2, -.3, -1}, 0.4f, 0}};
     try {
-        FTileGroup group(handles, std::vector<int>(n_handles, 0), fw, fh, mode == 2 ? FTileGroup::EGather::Rccl : FTileGroup::EGather::PeerCopy);
+        FTileGroup group(handles, devices, fw, fh, mode == 2 ? FTileGroup::EGather::Rccl : FTileGroup::EGather::PeerCopy);
         int flag = 0;
         group.ResetAllLights(lights, world);
+        if (hipSetDevice(listed[0]) != hipSuccess) return 4;
         TRY(tbrm_clear_light_volume(alone, 0.0f));
         for (const auto& l : lights) TRY(tbrm_add_dir_light(alone, &l, 1, &world, &flag, 0));
         size_t frames_bad = 0, light_bad = 0;
@@ -108,11 +132,14 @@ int main(int argc, char** argv)
             const float* frame = group.RenderLit(cam, rp, world, root, mode == 1);
             TRY(tbrm_raymarch_lit(alone, &cam, &full, &rp, &world, want.data()));
             TRY(tbrm_flush(group.Handle(root)));
+            if (hipSetDevice(devices[(size_t) root]) != hipSuccess) return 4;
             if (hipMemcpy(got.data(), frame, got.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 4;
+            if (hipSetDevice(listed[0]) != hipSuccess) return 4;
             frames_bad += std::memcmp(want.data(), got.data(), want.size() * sizeof(float)) != 0;
             if (mode != 0) // every handle holds the frame
                 for (int k = 0; k < n_handles; ++k) {
                     TRY(tbrm_flush(group.Handle(k)));
+                    if (hipSetDevice(devices[(size_t) k]) != hipSuccess) return 4;
                     if (hipMemcpy(got.data(), group.Frame(k), got.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 4;
                     frames_bad += std::memcmp(want.data(), got.data(), want.size() * sizeof(float)) != 0;
                 }
@@ -123,7 +150,9 @@ int main(int argc, char** argv)
             TRY(tbrm_download_light_volume(group.Handle(k), lv.data(), lv.size()));
             light_bad += std::memcmp(ref.data(), lv.data(), ref.size()) != 0;
         }
-        std::printf("light volumes: %zu of %d replicas differ\n", light_bad, n_handles);
+        std::printf("devices:");
+        for (int d : devices) std::printf(" %d", d);
+        std::printf("\nlight volumes: %zu of %d replicas differ\n", light_bad, n_handles);
         std::printf("frames: %zu differ, mean alpha %.6f, %zu bytes moved between the handles\n", frames_bad, sum_a / ((double) fw * fh), group.BytesMoved);
         if (frames_bad != 0 || light_bad != 0 || !(sum_a > 0)) return 1;
     } catch (const std::exception& e) {

@@ -142,3 +142,20 @@ def test_tile_driver_gathers_with_rccl_from_cpp(tmp_path, gpu):
     p = subprocess.run([build_tiles(tmp_path, True), "1", "2"], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
     assert "frames: 0 differ" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_tile_driver_over_every_visible_device(tmp_path, gpu, abi_mod, mode):
+    """the same binary over the box's real devices (TBRM_TILES_DEVICES, one handle per device, up to 8): peer copies to one / to every
+    handle, and RCCL's ncclAllGather across the devices. On a one-GPU box this is a group of one on device 0; on an 8-GPU node it is
+    the first execution of the peer-access / ncclCommInitAll paths on distinct devices."""
+    n = max(1, min(int(abi_mod.device_count()), 8))
+    while n > 1 and (128 if n == 8 else 96) % (8 * n):
+        n -= 1
+    env = dict(os.environ, TBRM_TILES_DEVICES=",".join(str(d) for d in range(n)))
+    p = subprocess.run([build_tiles(tmp_path, mode == 2), str(n), str(mode)], capture_output=True, text=True, env=env)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
+    assert "devices: " + " ".join(str(d) for d in range(n)) in p.stdout
+    assert f"light volumes: 0 of {n} replicas differ" in p.stdout and "frames: 0 differ" in p.stdout
+
