@@ -9,8 +9,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace tbrm_host {
@@ -60,6 +62,57 @@ struct FactorKey {
     int32_t clip_mode, axis, dir, start, D, W, H, guard;
     float uvw_off[3], step100;
 };
+// One device allocation handed out in pieces (host-side bookkeeping only: first fit over an offset-sorted free list, neighbours
+// merged on release). What the factor cache's entries live in once a handle is reserved (tbrm_resources_reserve): an operator that
+// needs a new entry takes a piece and gives back the pieces of entries nothing in flight reads — no hipMalloc, no hipFree, no
+// hipMemGetInfo on the operator path (the reference creates its buffers once, in InitializeRaymarchResources,
+// RaymarchVolume.cpp:821-920, never inside AddDirLightToSingleVolume).
+struct DeviceArena {
+    char* base = nullptr;
+    size_t bytes = 0;
+    std::vector<std::pair<size_t, size_t>> free_; // (offset, size), ascending, never adjacent
+    static constexpr size_t kAlign = 4096;
+    void reset(char* b, size_t n)
+    {
+        base = b;
+        bytes = n;
+        free_.clear();
+        if (b && n) free_.emplace_back(0, n);
+    }
+    bool owns(const void* p) const { return base && (const char*) p >= base && (const char*) p < base + bytes; }
+    static size_t rounded(size_t n) { return (n + kAlign - 1) / kAlign * kAlign; }
+    void* take(size_t n)
+    {
+        n = rounded(std::max<size_t>(n, 1));
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= n) {
+                char* const p = base + free_[i].first;
+                free_[i].first += n;
+                free_[i].second -= n;
+                if (free_[i].second == 0) free_.erase(free_.begin() + (long) i);
+                return p;
+            }
+        return nullptr;
+    }
+    void give(void* p, size_t n)
+    {
+        if (!owns(p)) return;
+        n = rounded(std::max<size_t>(n, 1));
+        const size_t off = (size_t) ((char*) p - base);
+        size_t i = 0;
+        while (i < free_.size() && free_[i].first < off) ++i;
+        free_.insert(free_.begin() + (long) i, std::make_pair(off, n));
+        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) { free_[i].second += free_[i + 1].second; free_.erase(free_.begin() + (long) i + 1); }
+        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) { free_[i - 1].second += free_[i].second; free_.erase(free_.begin() + (long) i); }
+    }
+    size_t free_bytes() const
+    {
+        size_t n = 0;
+        for (const auto& f : free_) n += f.second;
+        return n;
+    }
+};
+
 // The block lists of a pass (tbrm_block_lists.cpp): which of its 16 x 16 x 8 occlusion blocks can see anything but empty bricks
 // (k_occ_flags), the ascending list of those that can and every block's rank in it (k_occ_compact), the count — or the same for
 // the work units of a dual occlusion launch (k_unit_flags). They depend on the skipping metadata (volume, transfer function,
@@ -79,8 +132,10 @@ struct BlockLists {
     bool enqueued = false;          // its kernels are on the occlusion stream
     uint64_t id = 0;                // never reused within a handle
     uint64_t a_id = 0, b_id = 0;    // units of a dual launch: the two passes' lists (0: a pass's own lists)
-    int users = 0;                  // factor cache entries whose ranks these are
+    int users = 0;                  // factor cache entries whose ranks these are (+ the slab operation that holds a plan over them)
     uint64_t last_use = 0;
+    uint64_t last_read_op = 0;      // tbrm_resources::op_serial of the last operator whose launches (occlusion, sweeps) were handed these
+                                    // buffers: they are rewritten only once that operator's "done" event has fired (new_lists)
     size_t bytes() const { return blocks * (sizeof(uint8_t) + sizeof(uint32_t) + (slot ? sizeof(int32_t) : 0)); }
 };
 
@@ -196,7 +251,17 @@ struct tbrm_resources {
     uint64_t block_lists_serial = 0;
     uint64_t block_lists_op_floor = 0;  // block_lists_serial when the operator being planned began: its plans point at younger lists
     uint64_t block_lists_quiet_gen = 0; // lists older than this empty_gen are read by nothing in flight (new_lists)
+    std::vector<BlockLists*> spare_lists;  // made by tbrm_resources_reserve, never used yet: [with ranks], then [without]
     uint64_t lists_launches = 0;   // passes / dual launches whose lists had to be computed (tbrm_path_counters)
+    // tbrm_resources_reserve: everything the light operators would otherwise allocate as they go
+    bool reserved = false;
+    int reserved_lights = 0;
+    DeviceArena cache_arena;       // the factor cache's entries
+    void* cache_arena_alloc = nullptr;
+    std::vector<hipEvent_t> event_pool; // ordering events (event_flags()) not in use
+    size_t device_total_bytes = 0; // hipMemGetInfo at creation (the factor cache's automatic budget: an eighth of it)
+    uint64_t alloc_calls = 0;      // hipMalloc / hipHostMalloc / hipFree / hipHostFree / hipMemGetInfo made inside operators (tbrm_path_counters [12])
+    uint64_t sync_calls = 0;       // host-side waits for a stream made inside operators (tbrm_path_counters [13])
     uint64_t dual_launches = 0;    // occlusion launches that served two passes (tbrm_launch_counters)
     float* d_ones = nullptr;       // 1024 floats of 1.0
     uint64_t data_gen = 1, tf_gen = 1; // bumped by volume uploads / tbrm_set_tf_lut: what cached occlusion was computed from
@@ -321,6 +386,12 @@ bool dual_fit(const PassPlan& a, const PassPlan& b);                    // may O
 int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& a, const PassPlan& b);
 void quiesce_occ_stream(tbrm_resources* r);  // waits for the occlusion stream and forgets what its buffers hold
 void release_kept(tbrm_resources* r);       // frees the factor cache (the streams must be idle)
+int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags); // tbrm_resources_reserve
+int ensure_reserved(tbrm_resources* r);     // the first light operator of a handle nobody reserved: reserve_resources with the defaults
+bool op_finished(tbrm_resources* r, uint64_t op); // has every sweep of operator `op` completed? (never blocks)
+hipEvent_t take_event(tbrm_resources* r);   // from the handle's pool (null: creation failed)
+void give_event(tbrm_resources* r, hipEvent_t ev);
+BlockLists* make_spare_lists(tbrm_resources* r, size_t blocks, bool with_ranks); // tbrm_block_lists.cpp
 // tbrm_block_lists.cpp
 BlockLists* block_lists_for_pass(tbrm_resources* r, const ChunkParams& p, int occ_mode);  // null: allocation failed (tbrm_last_error)
 BlockLists* block_lists_for_dual(tbrm_resources* r, const BlockLists* a, const BlockLists* b, size_t units);
@@ -346,5 +417,6 @@ struct SlabOp {
     tbrm::PropParams base{};
     int current = -1; // pass being stepped
     tbrm_host::PassPlan plan;
+    BlockLists* held_lists = nullptr; // plan.lists, kept from being recycled while the plan is stored (BlockLists::users)
 };
 

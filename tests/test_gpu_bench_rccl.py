@@ -49,3 +49,16 @@ def test_light_update_on_one_rank_and_broadcast_over_rccl(gpu):
     assert r["gathered_frame_equals_single_gpu_render"] is True, r
     d = r["distributed"]
     assert d["backend"] == "nccl" and d["world_size_seen"] == 1 and d["light_update"] == "broadcast" and len(d["ms_per_step_per_rank"]) == 1, d
+
+
+def test_gather_to_root_and_delivery_blocks_over_rccl(gpu):
+    """--gather root: the timed step's tiles go to rank 0 by RCCL's gather (send / recv), and the line's frame_delivery / tile_parallel
+    blocks time one GPU / tiles + all-gather / tiles + gather-to-root loops by wall clock with the gather inside (one rank here)."""
+    r = run_bench(["--config", "3", "--gather", "root"])
+    assert r["gather"] == "root" and r["gathered_frame_equals_single_gpu_render"] is True, r
+    for key, fb in (("frame_delivery", [1024, 1024]), ("tile_parallel", [2048, 2048])):
+        b = r[key]
+        assert b["framebuffer"] == fb, b
+        for form in ("tiles_all_gather", "tiles_gather_to_root"):
+            assert b[form]["frame_equals_one_gpu_render"] is True and b[form]["ms_per_frame"] > 0, b
+    assert r["frame_speedup_vs_one_gpu"] == r["frame_delivery"]["tiles_gather_to_root"]["speedup_vs_one_gpu"]
