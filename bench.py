@@ -337,6 +337,13 @@ def main():
         for l in lights:
             res.add_dir_light(l, True, world)
 
+    # InitializeRaymarchResources (RaymarchVolume.cpp:821-920): every buffer the light operators of this scene will need, now —
+    # the scratch stores, hand-off records, block lists and the factor cache's arena (tbrm_resources_reserve); after it no operator
+    # allocates or waits for a stream (light_paths_per_step.operator_alloc_calls / operator_host_syncs stay 0)
+    t_res = time.perf_counter()
+    res.reserve(len(lights))
+    res.flush()
+    reserve_ms = (time.perf_counter() - t_res) * 1e3
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if args.light_parallel_reset and dist is not None and not cfg["light_32bit"]:
@@ -366,9 +373,14 @@ def main():
 
         sharding.reset_all_lights_light_parallel(res, lights, world, rank, n_gpus, combine_u8)
     else:
-        reset_all_lights()  # first call: includes allocating the propagation scratch and the brick metadata kernels
+        reset_all_lights()  # first call: includes the brick metadata kernels (the buffers were reserved above)
         res.flush()
     reset_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    if not (args.light_parallel_reset and dist is not None and not cfg["light_32bit"]):
+        reset_all_lights()
+        res.flush()
+    reset_warm_wall_ms = (time.perf_counter() - t0) * 1e3
 
     # Two output tiles / gather buffers: the all-gather of frame k runs (asynchronously, on RCCL's stream) while the light
     # update of frame k+1 is already executing on the library's stream; a buffer is reused only after its gather is done.
@@ -547,17 +559,15 @@ def main():
         if h is not None:
             h.wait()
     torch.cuda.synchronize()
-    # the MEAN of the event-timed calls, without the calls that took more than 3x the median: a call in which the handle's factor
-    # cache grows (hipMemGetInfo + hipMalloc between the operator's enqueues: milliseconds of host time inside its event pair, a few
-    # times per scene) or the first launch of a kernel instantiation on a fresh box (code-object load) is not a launch duration.
-    # Every call's time, and how many were left out, are in gpu_ms_spread. (Calls that take the remove + add path — the light's
-    # major axis changes, every 6th - 7th step — are 30 - 50 % longer and stay in the mean: they are the benchmark's operators.)
+    # the plain MEAN of the event-timed calls (round 5 left out calls above 3x the median: the factor cache grew inside operators
+    # then — hipMemGetInfo + hipMalloc between an operator's enqueues; round 6's operators allocate nothing, tbrm_resources_reserve).
+    # gpu_ms_spread lists every call and says how many WOULD have been left out by that rule (0 expected). (Calls that take the
+    # remove + add path — the light's major axis changes, every 6th - 7th step — are 30 - 50 % longer: they are the benchmark's operators.)
     def robust_mean(ms):
         if not ms:
             return 0.0, 0
         med = float(np.median(ms))
-        kept = [t for t in ms if t <= 3.0 * med]
-        return float(np.mean(kept)), len(ms) - len(kept)
+        return float(np.mean(ms)), len([t for t in ms if t > 3.0 * med])
 
     ray_ms, ray_dropped = robust_mean(ms_ray)
     illum_ms, illum_dropped = robust_mean(ms_illum)
@@ -565,7 +575,8 @@ def main():
               "left_out_above_3x_median": {"raymarch": ray_dropped, "change_dir_light": illum_dropped},
               "plain_mean": {"raymarch": round(float(np.mean(ms_ray)), 4) if ms_ray else None, "change_dir_light": round(float(np.mean(ms_illum)), 4) if ms_illum else None},
               "median": {"raymarch": round(float(np.median(ms_ray)), 4) if ms_ray else None, "change_dir_light": round(float(np.median(ms_illum)), 4) if ms_illum else None},
-              "note": "every event-timed call of the gpu_ms pass; gpu_ms quotes their mean without the calls above 3x the median"}
+              "note": "every event-timed call of the gpu_ms pass; gpu_ms quotes their plain mean (left_out_above_3x_median: how many calls round 5's "
+                      "trimmed mean would have dropped — none are dropped now)"}
 
     # ---- slab mode: the partitioned + gathered light volume must equal the unpartitioned operator's (untimed replay) ----
     slab_ok = None
@@ -761,7 +772,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(dom["achieved"], 2), "peak": HBM_PEAK / 1e9,
                 "unit": "GB/s", "frac": round(dom["achieved"] * 1e9 / HBM_PEAK, 5), "traffic": traffic, "traffic_source": traffic_source,
                 "alg_bytes_per_launch": int(dom["alg_bytes"]), "launch_ms": round(dom["launch_ms"], 4),
-                "launch_ms_is": f"mean of {len(ms_ray)} event-timed calls, those above 3x the median left out (gpu_ms_spread lists every call)"}
+                "launch_ms_is": f"plain mean of {len(ms_ray)} event-timed calls (gpu_ms_spread lists every call)"}
 
     # ---- CPU baseline: the oracle on this host's cores, rank 0, N=1 only, bounded sample -------------------
     cpu = parity = None
@@ -802,7 +813,10 @@ def main():
             "slab_light_volume_equals_unpartitioned": slab_ok,
             "gpu_ms": dict({"raymarch": round(ray_ms, 4), "change_dir_light": round(illum_ms, 4)},
                            **{k: round(v, 4) for k, v in ops_ms.items()},
-                           first_reset_all_lights_host_wall_incl_allocation=round(reset_ms, 2)),
+                           # host wall clock, call to flush: the handle's first ResetAllLights (skipping metadata kernels inside; buffers
+                           # reserved before it), the second one, and tbrm_resources_reserve itself
+                           first_reset_all_lights_host_wall=round(reset_ms, 2), second_reset_all_lights_host_wall=round(reset_warm_wall_ms, 2),
+                           resources_reserve_host_wall=round(reserve_ms, 2)),
             "gpu_ms_spread": spread,
             "distributed": None if dist is None else {
                 "backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "ms_per_step_per_rank": per_rank_ms,

@@ -165,7 +165,7 @@ typedef struct tbrm_resources tbrm_resources; /* opaque: FBasicRaymarchRendering
  * trailing gpu_sync argument since 2; 3 adds tbrm_abi_version itself and the error report of tbrm_flush; 4 adds
  * tbrm_path_counters, and every entry point that waits for the handle's stream now reports a failed sweep like tbrm_flush).
  * A host built against another number must not call into the library. */
-#define TBRM_ABI_VERSION 4
+#define TBRM_ABI_VERSION 5
 TBRM_API int tbrm_abi_version(void);
 TBRM_API const char* tbrm_version(void);
 TBRM_API const char* tbrm_last_error(void);       /* thread-local message of the last failing call */
@@ -204,6 +204,16 @@ TBRM_API int tbrm_get_tunable(const char* name, int32_t* value);
 /* light volume, 4 read/write buffers per axis, skipping metadata) and one HIP stream.                */
 TBRM_API int tbrm_resources_create(const tbrm_resources_desc* desc, tbrm_resources** out);
 TBRM_API int tbrm_resources_destroy(tbrm_resources* res);
+/* Everything the whole-volume light operators of this handle will need, allocated NOW — the reference creates its buffers once, in
+ * ARaymarchVolume::InitializeRaymarchResources (RaymarchVolume.cpp:821-920), never inside AddDirLightToSingleVolume: the second
+ * stream and its events, the factor scratch buffers, hand-off records (previous-slice taps up to two texels from the pixel), block
+ * lists and ordering events for n_lights lights, and one arena for the factor cache's entries (4 entries per light, within the
+ * light_cache_mb budget, never the last 2 GiB of the device). Afterwards an operator allocates nothing, asks the device nothing and
+ * never waits for a stream (tbrm_path_counters out[12], out[13] stand still); a cache entry that does not fit the arena evicts
+ * entries nothing in flight reads, or the pass goes uncached. flags bit 0: the chunked-chain fallback's stores too (passes the
+ * sweep declines). Optional: a handle nobody reserved does the same with n_lights = 4 inside its first light operator. May be
+ * called again with more lights (drains the streams, drops the cache). */
+TBRM_API int tbrm_resources_reserve(tbrm_resources* res, int32_t n_lights, uint32_t flags);
 TBRM_API int tbrm_resources_light_volume_dims(const tbrm_resources* res, int32_t out_dims[3]);
 TBRM_API int tbrm_resources_is_initialized(const tbrm_resources* res); /* bIsInitialized: volume + TF present */
 
@@ -413,7 +423,9 @@ TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);
  * (tunable occ_dual); out[8] stream-passes whose occlusion came from the factor cache; out[9] lit-raymarch launches;
  * out[10] sweep launches that propagated two lights' passes at once (tbrm_add_dir_lights); out[11] passes / dual launches whose
  * block lists (empty-block flags, work list, ranks) had to be computed — the others found them with the handle;
- * out[12..15] reserved (0). */
+ * out[12] device-memory management calls (hipMalloc / hipHostMalloc / hipFree / hipMemGetInfo / event and stream creation) made
+ * INSIDE light operators since creation, out[13] host-side waits for a stream made inside them — both stand still once the handle
+ * is reserved (tbrm_resources_reserve) and the scene stays inside the reserved envelope; out[14..15] reserved (0). */
 #define TBRM_PATH_COUNTERS 16
 TBRM_API int tbrm_path_counters(const tbrm_resources* res, uint64_t out[TBRM_PATH_COUNTERS]);
 /* The factor cache of the light operators (no counterpart in the reference, invisible in the results). The expensive half

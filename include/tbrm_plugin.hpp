@@ -326,6 +326,7 @@ public:
     void ResetAllLights() // :418-451
     {
         if (!RaymarchResources.bIsInitialized) return;
+        ReserveForLights(); // (lights added since the resources were initialised)
         URaymarchUtils::ClearResourceLightVolumes(RaymarchResources, 0);
         ++Stats.Resets;
         bool bResetWasSuccessful = true;
@@ -443,6 +444,19 @@ private:
             return;
         }
         RaymarchResources.SizeX = X; RaymarchResources.SizeY = Y; RaymarchResources.SizeZ = Z;
+        ReservedLights = 0;
+        ReserveForLights();
+    }
+    // Every buffer the light operators will need, now (:821-920 creates the read / write buffers and the light volume here, never
+    // inside AddDirLightToSingleVolume): tbrm_resources_reserve for the lights the actor holds, four at least; again when more arrive.
+    int ReservedLights = 0;
+    void ReserveForLights()
+    {
+        if (!RaymarchResources.Handle) return;
+        const int Want = std::max<int>(4, (int) LightsArray.size());
+        if (Want <= ReservedLights) return;
+        if (tbrm_resources_reserve(RaymarchResources.Handle, Want, 0) == TBRM_OK) ReservedLights = Want;
+        else std::fprintf(stderr, "tbrm_resources_reserve: %s\n", tbrm_last_error());
     }
     void WindowingChanged()
     {

@@ -118,7 +118,7 @@ SYMBOLS = [
     "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_resources_destroy", "tbrm_resources_light_volume_dims",
     "tbrm_resources_is_initialized", "tbrm_upload_volume", "tbrm_upload_volume_device",
     "tbrm_set_tf_lut", "tbrm_color_curve_to_lut", "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_set_windowing",
-    "tbrm_add_dir_light", "tbrm_add_dir_lights", "tbrm_change_dir_light", "tbrm_clear_light_volume",
+    "tbrm_resources_reserve", "tbrm_add_dir_light", "tbrm_add_dir_lights", "tbrm_change_dir_light", "tbrm_clear_light_volume",
     "tbrm_slab_light_begin", "tbrm_slab_pass_begin", "tbrm_slab_pass_chunk", "tbrm_slab_pass_plane",
     "tbrm_slab_resident_slices", "tbrm_upload_volume_slices", "tbrm_download_light_slices", "tbrm_slab_light_halo",
     "tbrm_raymarch_lit", "tbrm_raymarch_lit_device", "tbrm_raymarch_lit_slab_device", "tbrm_raymarch_intensity", "tbrm_raymarch_intensity_device",
@@ -129,7 +129,7 @@ SYMBOLS = [
     "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
-ABI_VERSION = 4  # TBRM_ABI_VERSION of include/tbrm.h (tests/test_abi.py compares the two)
+ABI_VERSION = 5  # TBRM_ABI_VERSION of include/tbrm.h (tests/test_abi.py compares the two)
 
 _lib = None
 
@@ -206,6 +206,7 @@ def load():
     lib.tbrm_launch_counters.argtypes = [vp, P(C.c_uint64 * 3)]
     lib.tbrm_sweep_launches.argtypes = [vp, P(C.c_uint64)]
     lib.tbrm_path_counters.argtypes = [vp, P(C.c_uint64 * 16)]
+    lib.tbrm_resources_reserve.argtypes = [vp, C.c_int32, C.c_uint32]
     lib.tbrm_selftest_unorm_decode.argtypes = [C.c_int, vp, vp]
     lib.tbrm_selftest_unorm8_roundtrip.argtypes = [C.c_int, vp, C.c_size_t, vp]
     lib.tbrm_selftest_window_division.argtypes = [C.c_int, C.c_float, C.c_float, P(C.c_uint64), P(C.c_int)]
@@ -382,6 +383,10 @@ class Resources:
     def is_initialized(self):
         return bool(self.lib.tbrm_resources_is_initialized(self.handle))
 
+    def reserve(self, n_lights, flags=0):
+        """tbrm_resources_reserve: allocate now what the light operators of a scene with n_lights lights will need."""
+        check(self.lib.tbrm_resources_reserve(self.handle, int(n_lights), int(flags)))
+
     def add_dir_light(self, light, added, world, gpu_sync=False):
         flag = C.c_int(0)
         check(self.lib.tbrm_add_dir_light(self.handle, C.byref(light), int(bool(added)), C.byref(world), C.byref(flag), int(gpu_sync)))
@@ -525,7 +530,8 @@ class Resources:
         return {"chunk": int(out[0]), "slice": int(out[1]), "raymarch": int(out[2]), "sweep": int(sweeps.value)}
 
     PATH_COUNTERS = ("passes_sweep", "passes_chain", "passes_slice", "launches_sweep", "launches_chain", "launches_slice",
-                     "occlusion_single", "occlusion_dual", "occlusion_cached", "raymarch", "pair_sweeps", "block_lists_built")
+                     "occlusion_single", "occlusion_dual", "occlusion_cached", "raymarch", "pair_sweeps", "block_lists_built",
+                     "operator_alloc_calls", "operator_host_syncs")
 
     def path_counters(self):
         """tbrm_path_counters: which kernels the light operators took (per axis pass and per launch)."""

@@ -369,6 +369,11 @@ static int create_impl(const tbrm_resources_desc* desc, const tbrm_slab* owned, 
     }
     if (hipDeviceGetAttribute(&r->n_cus, hipDeviceAttributeMultiprocessorCount, desc->device) != hipSuccess || r->n_cus <= 0) r->n_cus = 256;
     {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) r->device_total_bytes = total_b; // (the factor cache's automatic budget: asked once)
+        else (void) hipGetLastError();
+    }
+    {
         tbrm_resources::Residency& q = r->res_data;
         const size_t bytes = (size_t) (q.hi - q.lo + (q.wrap_src >= 0 ? 1 : 0)) * q.layer_bytes;
         CREATE_TRY(hipMalloc(&q.alloc, bytes));
@@ -457,6 +462,14 @@ int tbrm_resources_destroy(tbrm_resources* r)
     if (r->stream) (void) hipStreamDestroy(r->stream);
     delete r;
     return TBRM_OK;
+}
+
+int tbrm_resources_reserve(tbrm_resources* r, int32_t n_lights, uint32_t flags)
+{
+    if (!r) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    if (n_lights < 0 || (flags & ~1u)) return fail(TBRM_ERR_INVALID_ARG, "n_lights %d / flags %u", (int) n_lights, (unsigned) flags);
+    if (int e = bind(r)) return e;
+    return reserve_resources(r, n_lights, flags);
 }
 
 int tbrm_resources_light_volume_dims(const tbrm_resources* r, int32_t out_dims[3])
@@ -745,6 +758,8 @@ int tbrm_path_counters(const tbrm_resources* r, uint64_t out[TBRM_PATH_COUNTERS]
     out[9] = r->launches[2];
     out[10] = r->pair_sweeps;
     out[11] = r->lists_launches;
+    out[12] = r->alloc_calls;
+    out[13] = r->sync_calls;
     return TBRM_OK;
 }
 

@@ -66,6 +66,7 @@ int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* remove
     // buffers' own idle events — no "operator done" event is recorded for it, a later operator's occlusion then waits for
     // everything enqueued so far: wait_for_readers)
     ++r->op_serial;
+    r->block_lists_op_floor = r->block_lists_serial; // (lists the stored plan points at are younger: never pruned or recycled under it)
     r->op_many_passes = true;
     *n_passes = op.n;
     return TBRM_OK;
@@ -78,7 +79,12 @@ int tbrm_slab_pass_begin(tbrm_resources* r, int32_t pass, tbrm_slab_pass* out)
     if (int e = bind(r)) return e;
     SlabOp& op = *r->slab_op;
     op.current = -1;
+    if (op.held_lists) { --op.held_lists->users; op.held_lists = nullptr; }
     const int e = plan_pass(r, op.base, op.a[pass], op.change ? &op.r[pass] : nullptr, op.b_added, &op.slab, op.plan);
+    if (e == TBRM_OK && op.plan.lists) { // the plan is stored across API calls (tbrm_slab_pass_chunk enqueues later): its lists stay put
+        op.held_lists = op.plan.lists;
+        ++op.held_lists->users;
+    }
     if (e == TBRM_ERR_UNSUPPORTED)
         return fail(e, "pass %d (axis %d) has no slab-partitioned form: %s", (int) pass, (int) op.a[pass].axis, g_plan_note);
     if (e) return e;

@@ -69,6 +69,7 @@ static void block_lists_signature(const ChunkParams& p, int occ_mode, std::vecto
 
 static void free_lists(BlockLists* l)
 {
+    if (!l) return;
     (void) hipFree(l->flags);
     (void) hipFree(l->list);
     (void) hipFree(l->slot);
@@ -82,12 +83,42 @@ void release_block_lists(tbrm_resources* r)
 {
     for (BlockLists* l : r->block_lists) free_lists(l);
     r->block_lists.clear();
+    for (BlockLists* l : r->spare_lists) free_lists(l);
+    r->spare_lists.clear();
 }
 
 static void drain(tbrm_resources* r)
 {
+    ++r->sync_calls;
     (void) hipStreamSynchronize(r->stream);
     if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
+}
+
+static BlockLists* allocate_lists(size_t blocks, bool with_ranks)
+{
+    BlockLists* l = new BlockLists{};
+    bool ok = hipMalloc((void**) &l->flags, blocks) == hipSuccess && hipMalloc((void**) &l->list, blocks * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void**) &l->count, 16 * sizeof(int)) == hipSuccess;
+    if (with_ranks)
+        ok = ok && hipMalloc((void**) &l->slot, blocks * sizeof(int32_t)) == hipSuccess &&
+             hipHostMalloc((void**) &l->count_host, sizeof(int), hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&l->ev_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void) hipGetLastError();
+        free_lists(l);
+        fail(TBRM_ERR_OUT_OF_MEMORY, "no memory for the block lists of a pass (%zu blocks)", blocks);
+        return nullptr;
+    }
+    l->cap = blocks;
+    return l;
+}
+
+// tbrm_resources_reserve: lists made ahead of their first use
+BlockLists* make_spare_lists(tbrm_resources* r, size_t blocks, bool with_ranks)
+{
+    BlockLists* l = allocate_lists(blocks, with_ranks);
+    if (l) r->spare_lists.push_back(l);
+    return l;
 }
 
 // Beyond kMaxLists (many distinct light directions under one volume / transfer function / window): the least recently used
@@ -97,6 +128,7 @@ static void prune(tbrm_resources* r)
 {
     if (r->block_lists.size() < kMaxLists) return;
     drain(r);
+    r->alloc_calls += 4;
     std::vector<BlockLists*> keep;
     std::sort(r->block_lists.begin(), r->block_lists.end(), [](const BlockLists* a, const BlockLists* b) { return a->last_use > b->last_use; });
     for (BlockLists* l : r->block_lists) {
@@ -110,33 +142,41 @@ static void prune(tbrm_resources* r)
 // New lists for `blocks` blocks: the buffers of lists that were computed from skipping metadata which is gone (a new volume,
 // transfer function or window: nothing will ask for them again) if some are large enough — no allocation while only the
 // window moves (APerformanceTest1's sweep) —, else fresh ones.
+// A list's buffers are rewritten only when nothing in flight can still read them: every launch that is handed a list's flags,
+// work list or ranks notes its operator in BlockLists::last_read_op (the planner, for every list a plan points at), and a stale
+// list — nobody's ranks (users == 0), computed from metadata that is gone — is taken again once that operator's "sweeps done"
+// event has FIRED (op_finished: asked, not waited for). Round 5 drained the streams once per metadata change instead, which left a
+// window: a list pinned by a cache entry across the change could be read by a sweep enqueued AFTER that drain and recycled when the
+// entry let go of it.
 static BlockLists* new_lists(tbrm_resources* r, size_t blocks, bool with_ranks)
 {
     BlockLists* l = nullptr;
-    for (BlockLists* c : r->block_lists)
-        if (c->empty_gen != r->empty_gen && c->users == 0 && c->cap >= blocks && (c->slot != nullptr) == with_ranks && (!l || c->cap < l->cap)) l = c;
-    if (l) {
-        // what still reads them was enqueued before the metadata changed: one drain per change covers every list of that age
-        if (r->block_lists_quiet_gen != r->empty_gen) { drain(r); r->block_lists_quiet_gen = r->empty_gen; }
-        l->sig.clear();
-        l->a_id = l->b_id = 0;
-        l->enqueued = false;
-    } else {
-        prune(r);
-        l = new BlockLists{};
-        bool ok = hipMalloc((void**) &l->flags, blocks) == hipSuccess && hipMalloc((void**) &l->list, blocks * sizeof(uint32_t)) == hipSuccess &&
-                  hipMalloc((void**) &l->count, 16 * sizeof(int)) == hipSuccess;
-        if (with_ranks)
-            ok = ok && hipMalloc((void**) &l->slot, blocks * sizeof(int32_t)) == hipSuccess &&
-                 hipHostMalloc((void**) &l->count_host, sizeof(int), hipHostMallocDefault) == hipSuccess &&
-                 hipEventCreateWithFlags(&l->ev_done, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            (void) hipGetLastError();
-            free_lists(l);
-            fail(TBRM_ERR_OUT_OF_MEMORY, "no memory for the block lists of a pass (%zu blocks)", blocks);
-            return nullptr;
+    // a spare one first (tbrm_resources_reserve): never used, nothing reads it
+    for (size_t i = 0; i < r->spare_lists.size(); ++i) {
+        BlockLists* c = r->spare_lists[i];
+        if (c->cap >= blocks && (c->slot != nullptr) == with_ranks) {
+            l = c;
+            r->spare_lists.erase(r->spare_lists.begin() + (long) i);
+            r->block_lists.push_back(l);
+            break;
         }
-        l->cap = blocks;
+    }
+    if (!l) {
+        for (BlockLists* c : r->block_lists)
+            if (c->empty_gen != r->empty_gen && c->users == 0 && c->cap >= blocks && (c->slot != nullptr) == with_ranks && c->last_use <= r->block_lists_op_floor &&
+                op_finished(r, c->last_read_op) && (!l || c->cap < l->cap))
+                l = c;
+        if (l) {
+            l->sig.clear();
+            l->a_id = l->b_id = 0;
+            l->enqueued = false;
+        }
+    }
+    if (!l) {
+        prune(r);
+        r->alloc_calls += with_ranks ? 5 : 3;
+        l = allocate_lists(blocks, with_ranks);
+        if (!l) return nullptr;
         r->block_lists.push_back(l);
     }
     l->blocks = blocks;
@@ -144,6 +184,7 @@ static BlockLists* new_lists(tbrm_resources* r, size_t blocks, bool with_ranks)
     l->empty_gen = r->empty_gen;
     l->id = ++r->block_lists_serial;
     l->last_use = l->id;
+    l->last_read_op = r->op_serial; // (the operator being planned will launch over them)
     return l;
 }
 
@@ -154,6 +195,7 @@ BlockLists* block_lists_for_pass(tbrm_resources* r, const ChunkParams& p, int oc
     for (BlockLists* l : r->block_lists)
         if (l->a_id == 0 && l->empty_gen == r->empty_gen && l->sig == sig) {
             l->last_use = ++r->block_lists_serial;
+            l->last_read_op = std::max(l->last_read_op, r->op_serial);
             return l;
         }
     BlockLists* l = new_lists(r, (size_t) p.occ_groups * p.occ_blocks_y * p.occ_blocks_x, true);
@@ -166,6 +208,7 @@ BlockLists* block_lists_for_dual(tbrm_resources* r, const BlockLists* a, const B
     for (BlockLists* l : r->block_lists)
         if (l->a_id == a->id && l->b_id == b->id && l->blocks == units) {
             l->last_use = ++r->block_lists_serial;
+            l->last_read_op = std::max(l->last_read_op, r->op_serial);
             return l;
         }
     BlockLists* l = new_lists(r, units, false);

@@ -8,24 +8,57 @@ namespace tbrm_host {
 
 void drain_streams(tbrm_resources* r)
 {
+    ++r->sync_calls;
     (void) hipStreamSynchronize(r->stream);
     if (r->occ_stream) (void) hipStreamSynchronize(r->occ_stream);
 }
 void drain_streams_public(tbrm_resources* r) { drain_streams(r); }
 
-static void free_entry(FactorEntry* e)
+// ordering events come from a pool the handle keeps (made by tbrm_resources_reserve, refilled when an entry goes)
+hipEvent_t take_event(tbrm_resources* r)
 {
-    (void) hipFree(e->base);
+    if (!r->event_pool.empty()) {
+        const hipEvent_t ev = r->event_pool.back();
+        r->event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    ++r->alloc_calls;
+    if (hipEventCreateWithFlags(&ev, event_flags()) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return ev;
+}
+void give_event(tbrm_resources* r, hipEvent_t ev)
+{
+    if (ev) r->event_pool.push_back(ev);
+}
+
+// Has every sweep of operator `op` completed? Operators record "my sweeps are done" in one of kOpEvents slots (run_passes); a slot
+// that a LATER operator has taken answers for the earlier one too (one stream, in order). Never blocks; false when in doubt.
+bool op_finished(tbrm_resources* r, uint64_t op)
+{
+    if (op == 0) return true;
+    for (int k = 0; k < tbrm_resources::kOpEvents; ++k) { // (any operator from `op` on that has recorded its event and seen it fire)
+        if (!r->op_done[k] || r->op_done_serial[k] < op) continue;
+        if (hipEventQuery(r->op_done[k]) == hipSuccess) return true;
+        (void) hipGetLastError();
+    }
+    return false; // (not recorded: the operator is being enqueued, was a slab operation, or failed half way)
+}
+
+static void free_entry(tbrm_resources* r, FactorEntry* e)
+{
+    if (r->cache_arena.owns(e->base)) r->cache_arena.give(e->base, e->bytes());
+    else if (e->base) { ++r->alloc_calls; (void) hipFree(e->base); }
     if (e->lists) --e->lists->users;
-    for (hipEvent_t ev : {e->ev_filled, e->ev_idle})
-        if (ev) (void) hipEventDestroy(ev);
+    give_event(r, e->ev_filled);
+    give_event(r, e->ev_idle);
     delete e;
 }
 
 void release_kept(tbrm_resources* r)
 {
     if (!r->kept.empty()) drain_streams(r);
-    for (FactorEntry* e : r->kept) free_entry(e);
+    for (FactorEntry* e : r->kept) free_entry(r, e);
     r->kept.clear();
 }
 
@@ -57,6 +90,12 @@ void release_occ_stores(tbrm_resources* r)
     r->d_ones = nullptr;
     release_kept(r);
     release_block_lists(r);
+    (void) hipFree(r->cache_arena_alloc);
+    r->cache_arena_alloc = nullptr;
+    r->cache_arena.reset(nullptr, 0);
+    for (hipEvent_t ev : r->event_pool) (void) hipEventDestroy(ev);
+    r->event_pool.clear();
+    r->reserved = false;
 }
 
 // room for `slices` planes of slice_elems floats behind the page of ones, and for the flags / lists of a pass
@@ -64,6 +103,8 @@ int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems
 {
     const size_t elems = (size_t) slices * slice_elems; // (the passes of a non-cubic volume have planes of different sizes)
     if (elems > st->capacity || !st->base) {
+        ++r->sync_calls;
+        r->alloc_calls += 2;
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->occ_stream) HIP_TRY(hipStreamSynchronize(r->occ_stream));
         (void) hipFree(st->base);
@@ -74,6 +115,8 @@ int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems
         st->capacity = elems;
     }
     if (flag_bytes > st->flag_bytes) {
+        ++r->sync_calls;
+        r->alloc_calls += 4;
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->occ_stream) HIP_TRY(hipStreamSynchronize(r->occ_stream));
         (void) hipFree(st->flags);
@@ -91,6 +134,7 @@ int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems
 int ensure_occ_stream(tbrm_resources* r)
 {
     if (r->occ_stream) return TBRM_OK;
+    r->alloc_calls += 1 + 4 + tbrm_resources::kOpEvents; // (a stream and its events)
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least)); // (the handle's stream's priority instead: measured, no gain)
@@ -108,11 +152,14 @@ int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int streams)
 {
     FactorScratch& f = r->f_scratch[b];
     if (!r->d_ones) {
+        ++r->alloc_calls;
+        ++r->sync_calls;
         HIP_TRY(hipMalloc((void**) &r->d_ones, 1024 * sizeof(float)));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_ones, 0x3f800000, 1024, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream)); // (read from the occlusion stream's sweeps' predecessors: simplest to have it done)
     }
     if (!f.ev_ready) {
+        r->alloc_calls += 2;
         HIP_TRY(hipEventCreateWithFlags(&f.ev_ready, event_flags()));
         HIP_TRY(hipEventCreateWithFlags(&f.ev_idle, event_flags()));
     }
@@ -121,6 +168,7 @@ int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int streams)
     for (int si = 0; si < streams; ++si) need = need || grow_store || !f.store[si];
     if (!need) return TBRM_OK;
     drain_streams(r);
+    r->alloc_calls += (uint64_t) std::max(streams, 1);
     if (grow_store) {
         for (float*& st : f.store) { (void) hipFree(st); st = nullptr; }
         f.store_blocks = 0;
@@ -194,20 +242,22 @@ static size_t kept_budget(const tbrm_resources* r)
 {
     const int mb = tune(TUNE_LIGHT_CACHE_MB);
     if (mb >= 0) return (size_t) mb << 20;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return 0; }
-    return total_b / 8;
+    return r->device_total_bytes / 8; // (asked of the device once, when the handle was created)
 }
 
-// An entry for a pass about to be computed, sized for `want` blocks: the buffer of an entry whose light has left the scene
-// if one is large enough (no allocation while lights merely move), else a fresh allocation while the budget lasts and the
-// device has room to spare, else the least recently used entry's. null: the cache is off, or nothing can be had.
+// An entry for a pass about to be computed, sized for `want` blocks: the buffer of an entry whose light has left the scene if one
+// is large enough (lights that merely move recycle each other's buffers), else a piece of the handle's arena
+// (tbrm_resources_reserve) — after giving back the pieces of entries that are of no further use and that nothing in flight
+// reads (op_finished: asked, never waited for), least recently used first. null: the cache is off, or nothing can be had
+// without waiting — the pass then computes into the scratch store alone and is sampled again next time. Nothing here
+// allocates device memory, asks the device how much it has, or waits for a stream.
 FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t want, BlockLists* lists)
 {
     const size_t bytes = want * 2048 * sizeof(float);
     FactorEntry* e = nullptr;
     auto fits = [&](const FactorEntry* c) { return !c->pinned && c->cap_blocks >= want && c->cap_blocks <= want + want / 2 + 64; };
-    auto reusable = [&](const FactorEntry* c) { return fits(c) && ((c->resolved && !c->valid) || c->spent || !c->enqueued); };
+    auto useless = [&](const FactorEntry* c) { return (c->resolved && !c->valid) || c->spent || !c->enqueued; };
+    auto reusable = [&](const FactorEntry* c) { return fits(c) && useless(c); };
     // An entry that the operator just before this one read (the removed side of its Change) is still being read by that
     // operator's sweeps when this operator's occlusion could start — beside those very sweeps, which leave two thirds of a
     // CU's issue slots idle. Reusing it would make the occlusion wait for them (measured: the whole 0.38 ms of it exposed
@@ -215,47 +265,43 @@ FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t want, Bloc
     auto settled = [&](const FactorEntry* c) { return !(c->read_yet && c->last_read_op + 1 >= r->op_serial); };
     for (FactorEntry* c : r->kept) // dropped and spent entries first, oldest first
         if (reusable(c) && settled(c) && (!e || c->last_use < e->last_use)) e = c;
-    size_t budget = 0; // (asked for only when an allocation is on the cards: hipMemGetInfo takes milliseconds)
-    auto room_for_a_new_one = [&]() {
-        budget = kept_budget(r);
-        if (kept_bytes(r) + bytes > budget) return false;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return false; }
-        return free_b >= 2 * bytes + ((size_t) 1 << 30);
+    const size_t budget = kept_budget(r);
+    if (bytes > budget) return nullptr;
+    // nothing in flight writes or reads it: its fill has completed (or never started), its last reader's operator is done
+    auto quiet = [&](const FactorEntry* c) {
+        if (c->pinned) return false;
+        if (c->enqueued && c->ev_filled && hipEventQuery(c->ev_filled) != hipSuccess) { (void) hipGetLastError(); return false; }
+        return !c->read_yet || op_finished(r, c->last_read_op);
     };
-    if (!e && !room_for_a_new_one()) // (no room to grow: the entry that is still being read, and the wait)
-        for (FactorEntry* c : r->kept)
-            if (reusable(c) && (!e || c->last_use < e->last_use)) e = c;
+    void* piece = nullptr;
     if (!e) {
-        if (budget == 0) budget = kept_budget(r);
-        // make room: entries that are of no use go first, then the least recently used
-        auto victim = [&]() -> FactorEntry* {
-            FactorEntry* v = nullptr;
-            for (FactorEntry* c : r->kept)
-                if (!c->pinned && ((c->resolved && !c->valid) || c->spent || !c->enqueued) && (!v || c->last_use < v->last_use)) v = c;
-            if (v) return v;
-            for (FactorEntry* c : r->kept)
-                if (!c->pinned && (!v || c->last_use < v->last_use)) v = c;
-            return v;
-        };
-        if (bytes > budget) return nullptr;
-        while (kept_bytes(r) + bytes > budget) {
-            FactorEntry* v = victim();
-            if (!v) return nullptr;
-            drain_streams(r);
+        auto drop = [&](FactorEntry* v) {
             r->kept.erase(std::find(r->kept.begin(), r->kept.end(), v));
-            free_entry(v);
+            free_entry(r, v);
+        };
+        for (int pass = 0; pass < 2 && !piece; ++pass) { // 0: what is of no use anyway; 1: the least recently used
+            for (;;) {
+                if (kept_bytes(r) + bytes <= budget && (piece = r->cache_arena.take(bytes))) break;
+                FactorEntry* v = nullptr;
+                for (FactorEntry* c : r->kept)
+                    if ((pass == 1 || useless(c)) && quiet(c) && (!v || c->last_use < v->last_use)) v = c;
+                if (!v) break;
+                drop(v);
+            }
         }
-        // never the last of the device's memory: whoever else allocates on this device (a renderer, torch, another handle)
-        // must not find it gone (asked at every allocation: a few per scene, hipMemGetInfo takes milliseconds)
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes + ((size_t) 1 << 30)) { (void) hipGetLastError(); return nullptr; }
+        if (!piece) // no room without waiting: the spent entry that is still being read after all (its readers are waited for on the
+                    // occlusion stream, not here: note_readers), else do without
+            for (FactorEntry* c : r->kept)
+                if (reusable(c) && (!e || c->last_use < e->last_use)) e = c;
+        if (!piece && !e) return nullptr;
+    }
+    if (!e) {
         e = new FactorEntry{};
-        bool ok = hipMalloc((void**) &e->base, bytes) == hipSuccess;
-        for (hipEvent_t* ev : {&e->ev_filled, &e->ev_idle}) ok = ok && hipEventCreateWithFlags(ev, event_flags()) == hipSuccess;
-        if (!ok) { // out of memory: do without
-            (void) hipGetLastError();
-            free_entry(e);
+        e->base = (float*) piece;
+        e->ev_filled = take_event(r);
+        e->ev_idle = take_event(r);
+        if (!e->ev_filled || !e->ev_idle) {
+            free_entry(r, e);
             return nullptr;
         }
         e->cap_blocks = want;
@@ -272,6 +318,101 @@ FactorEntry* kept_new(tbrm_resources* r, const FactorKey& key, size_t want, Bloc
     e->lists = lists; // (its blocks will be stored under these ranks)
     ++lists->users;
     return e;
+}
+
+// ---- tbrm_resources_reserve ------------------------------------------------------------------------------------------------
+// Everything the whole-volume light operators of this handle need, sized from the volume's dimensions, the number of lights the
+// scene will hold and the factor cache's budget — what the reference does in InitializeRaymarchResources (RaymarchVolume.cpp:821-920):
+// the occlusion stream and its events, the page of ones, the four factor scratch buffers (both streams: every block could be live),
+// hand-off records for previous-slice taps up to two texels from the pixel, tickets, block lists, ordering events, and ONE arena
+// for the factor cache's entries. Afterwards the operators allocate nothing (tbrm_path_counters [12] stands still); only a pass
+// outside that envelope (taps further away, the chunked-chain fallback without flag 1) still allocates what it needs, once.
+static size_t pass_blocks_max(const tbrm_resources* r, size_t* slice_elems_max, int* tiles_max, int* depth_max)
+{
+    size_t best = 0, elems = 0;
+    int tiles = 0, depth = 0;
+    for (int a = 0; a < 3; ++a) {
+        const int u = a == 0 ? 1 : 0, v = a == 2 ? 1 : 2;
+        const int W = r->lv_dims[u], H = r->lv_dims[v], D = ceil_div(r->lv_dims[a], 8) * 8;
+        best = std::max(best, (size_t) ceil_div(W, 16) * ceil_div(H, 16) * (size_t) (D / 8));
+        elems = std::max(elems, (size_t) W * H);
+        tiles = std::max(tiles, ceil_div(W, kSweepTile) * ceil_div(H, sweep_tile_rows()));
+        depth = std::max(depth, D);
+    }
+    if (slice_elems_max) *slice_elems_max = elems;
+    if (tiles_max) *tiles_max = tiles;
+    if (depth_max) *depth_max = depth;
+    return best;
+}
+
+int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
+{
+    if (r->resident) { r->reserved = true; return TBRM_OK; } // (slab-resident handles run the chunked chain on their own stores)
+    n_lights = std::max(n_lights, 1);
+    if (r->reserved && n_lights <= r->reserved_lights && !(flags & 1u)) return TBRM_OK;
+    if (int e = ensure_occ_stream(r)) return e;
+    size_t slice_elems = 0;
+    int tiles = 0, depth = 0;
+    const size_t blocks = pass_blocks_max(r, &slice_elems, &tiles, &depth);
+    // the page of ones, the scratch stores (ensure_factor_scratch drains and allocates only what is missing)
+    for (int b = 0; b < tbrm_resources::kFScratch; ++b)
+        if (int e = ensure_factor_scratch(r, b, blocks, 2)) return e;
+    // hand-off records: reach 2 x 2 for both record buffers (two-way Changes), float light volumes: 8-byte granules per stream
+    {
+        const size_t gw = r->lv_fmt != FMT_U8 ? 4 : 1;
+        const size_t words = (size_t) depth * (size_t) tiles * (size_t) sweep_record_words(2, 2, sweep_tile_rows()) * gw;
+        if (words < ((size_t) 1 << 32))
+            if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words)) return e;
+    }
+    // ordering events and block lists for n_lights lights' passes
+    const size_t want_events = (size_t) 8 * n_lights + 16;
+    while (r->event_pool.size() < want_events) {
+        hipEvent_t ev = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev, event_flags()));
+        r->event_pool.push_back(ev);
+    }
+    {
+        size_t have_ranked = 0, have_plain = 0;
+        for (const BlockLists* l : r->spare_lists) (l->slot ? have_ranked : have_plain) += 1;
+        const size_t units = (size_t) ceil_div(r->lv_dims[0], 16) * ceil_div(r->lv_dims[1], 16) * (size_t) ceil_div(r->lv_dims[2], 8);
+        for (size_t k = have_ranked; k < (size_t) 6 * n_lights + 6; ++k)
+            if (!make_spare_lists(r, blocks, true)) return TBRM_ERR_OUT_OF_MEMORY;
+        for (size_t k = have_plain; k < (size_t) 3 * n_lights + 3; ++k)
+            if (!make_spare_lists(r, std::max(units, blocks), false)) return TBRM_ERR_OUT_OF_MEMORY;
+    }
+    // the factor cache's arena: per light two passes, twice (a light that moves fills new entries while the old ones are still read),
+    // sized like an entry whose live-block count is not known yet (kept_new's caller: every block of a small pass, half of a large one)
+    if (tune(TUNE_LIGHT_CACHE_MB) != 0) {
+        const size_t entry = (blocks * 2048 * sizeof(float) <= ((size_t) 256 << 20) ? blocks : blocks / 2) * 2048 * sizeof(float);
+        size_t want = std::min(kept_budget(r), DeviceArena::rounded(entry) * (size_t) (4 * n_lights));
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, free_b > ((size_t) 2 << 30) ? (free_b - ((size_t) 2 << 30)) / 2 : 0); // (never the last of the device's memory)
+        else (void) hipGetLastError();
+        if (want > r->cache_arena.bytes && want >= DeviceArena::rounded(entry)) {
+            drain_streams(r);
+            release_kept(r); // (entries of a smaller arena, or allocated one by one before the handle was reserved)
+            (void) hipFree(r->cache_arena_alloc);
+            r->cache_arena_alloc = nullptr;
+            r->cache_arena.reset(nullptr, 0);
+            if (hipMalloc(&r->cache_arena_alloc, want) == hipSuccess) r->cache_arena.reset((char*) r->cache_arena_alloc, want);
+            else (void) hipGetLastError(); // (no arena: no cache — the operators still run)
+        }
+    }
+    if (flags & 1u) { // the chunked chain's occlusion stores too (passes the sweep declines: reaches beyond 14 texels, ...)
+        const size_t flag_bytes = blocks + 16 * (blocks / std::max<size_t>((size_t) depth / 8, 1)); // (whole spans of 128 slices: up to 16 slice groups more than the pass has)
+        for (int b = 0; b < 2; ++b)
+            for (int si = 0; si < 2; ++si)
+                if (int e = ensure_store(r, &r->occ_tmp[b][si], 128, slice_elems, si == 0 ? flag_bytes : 0)) return e;
+    }
+    r->reserved = true;
+    r->reserved_lights = std::max(r->reserved_lights, n_lights);
+    return TBRM_OK;
+}
+
+int ensure_reserved(tbrm_resources* r)
+{
+    if (r->reserved) return TBRM_OK;
+    return reserve_resources(r, 4, 0); // (a host that never said how many lights it has: the reference scenes' four)
 }
 
 void use_kept(tbrm_resources* r, FactorEntry* e, bool leaves_the_scene)

@@ -285,6 +285,7 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
         ChunkStream& st = *streams[si];
         if (plan.f_hit[si]) { // every live block is in the entry
             st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->lists->slot;
+            e->lists->last_read_op = std::max(e->lists->last_read_op, r->op_serial); // (new_lists: not rewritten under this sweep)
         } else { // computed by this pass: stream a into its entry (if it has one) and the scratch, stream r into the scratch,
                  // both under the ranks of the jointly computed work list
             FactorEntry* const filled = plan.f_entry[0];
@@ -323,6 +324,7 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
         const int tiles = p.tiles_x * p.tiles_y;
         if (tiles > r->sweep_stamp_tiles || !r->sweep_stamps) {
             drain_streams(r);
+            r->alloc_calls += 2;
             (void) hipFree(r->sweep_stamps);
             r->sweep_stamps = nullptr;
             HIP_TRY(hipMalloc((void**) &r->sweep_stamps, (size_t) tiles * 4 * sizeof(unsigned long long)));
@@ -382,8 +384,10 @@ int enqueue_sweep_pair(tbrm_resources* r, const PassPlan& pa, const PassPlan& pb
         FactorScratch& f = r->f_scratch[plan.f_buf];
         FactorEntry* const e = plan.f_entry[0];
         ChunkStream& st = *streams[si];
-        if (plan.f_hit[0]) { st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->lists->slot; }
-        else {
+        if (plan.f_hit[0]) {
+            st.fs_keep = e->base; st.fs_cap = (uint32_t) e->cap_blocks; st.fs_spill = nullptr; st.fs_slot = e->lists->slot;
+            e->lists->last_read_op = std::max(e->lists->last_read_op, r->op_serial);
+        } else {
             st.fs_keep = e ? e->base : nullptr;
             st.fs_cap = e ? (uint32_t) e->cap_blocks : 0u;
             st.fs_spill = f.store[0];

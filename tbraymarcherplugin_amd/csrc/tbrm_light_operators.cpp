@@ -40,6 +40,7 @@ struct HostProbe {
 static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<PassSpec> specs, std::vector<int> partner = {})
 {
     if (int e = sweep_failed(r)) return e; // (an earlier sweep left the light volume undefined: nothing to build on)
+    if (int e = ensure_reserved(r)) return e; // (a handle nobody reserved: once, with the defaults — tbrm_resources_reserve)
     ++r->op_serial;
     r->block_lists_op_floor = r->block_lists_serial;
     if (cache_usable(r)) // (the cache's keys depend on tbrm_resources::shell_transparent)

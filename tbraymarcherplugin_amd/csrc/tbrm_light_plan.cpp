@@ -173,12 +173,15 @@ void sweep_failure_cleared(tbrm_resources* r)
 int ensure_sweep(tbrm_resources* r, size_t words, size_t words1)
 {
     if (!r->sweep_ticket) {
+        r->alloc_calls += 2;
         HIP_TRY(hipMalloc((void**) &r->sweep_ticket, 2 * sizeof(int)));
         HIP_TRY(hipMemsetAsync(r->sweep_ticket, 0, 2 * sizeof(int), r->stream));
         HIP_TRY(hipHostMalloc((void**) &r->sweep_error, sizeof(int), hipHostMallocMapped));
         *r->sweep_error = 0;
     }
     if (words > r->sweep_rec_words) {
+        ++r->sync_calls;
+        r->alloc_calls += 2;
         HIP_TRY(hipStreamSynchronize(r->stream));
         (void) hipFree(r->sweep_rec[0]);
         r->sweep_rec[0] = nullptr;
@@ -188,6 +191,8 @@ int ensure_sweep(tbrm_resources* r, size_t words, size_t words1)
         r->sweep_rec_words = words;
     }
     if (words1 > r->sweep_rec1_words) {
+        ++r->sync_calls;
+        r->alloc_calls += 2;
         HIP_TRY(hipStreamSynchronize(r->stream));
         (void) hipFree(r->sweep_rec[1]);
         r->sweep_rec[1] = nullptr;

@@ -250,7 +250,6 @@ struct tbrm_resources {
     std::vector<BlockLists*> block_lists; // passes' and dual launches' block lists computed so far (tbrm_block_lists.cpp)
     uint64_t block_lists_serial = 0;
     uint64_t block_lists_op_floor = 0;  // block_lists_serial when the operator being planned began: its plans point at younger lists
-    uint64_t block_lists_quiet_gen = 0; // lists older than this empty_gen are read by nothing in flight (new_lists)
     std::vector<BlockLists*> spare_lists;  // made by tbrm_resources_reserve, never used yet: [with ranks], then [without]
     uint64_t lists_launches = 0;   // passes / dual launches whose lists had to be computed (tbrm_path_counters)
     // tbrm_resources_reserve: everything the light operators would otherwise allocate as they go

@@ -71,6 +71,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
         "tbrm_upload_volume": lambda: lib.tbrm_upload_volume(z, buf, 4),
         "tbrm_upload_volume_device": lambda: lib.tbrm_upload_volume_device(z, buf, 4),
         "tbrm_upload_volume_slices": lambda: lib.tbrm_upload_volume_slices(z, 0, 8, buf, 4),
+        "tbrm_resources_reserve": lambda: lib.tbrm_resources_reserve(z, 4, 0),
         "tbrm_set_tf_lut": lambda: lib.tbrm_set_tf_lut(z, buf),
         "tbrm_set_windowing": lambda: lib.tbrm_set_windowing(z, C.byref(abi.WindowingParams())),
         "tbrm_add_dir_lights": lambda: lib.tbrm_add_dir_lights(z, None, 0, 1, C.byref(abi.make_world()), None, None),
