@@ -425,7 +425,8 @@ TBRM_API int tbrm_sweep_launches(const tbrm_resources* res, uint64_t* out);
  * block lists (empty-block flags, work list, ranks) had to be computed — the others found them with the handle;
  * out[12] device-memory management calls (hipMalloc / hipHostMalloc / hipFree / hipMemGetInfo / event and stream creation) made
  * INSIDE light operators since creation, out[13] host-side waits for a stream made inside them — both stand still once the handle
- * is reserved (tbrm_resources_reserve) and the scene stays inside the reserved envelope; out[14..15] reserved (0). */
+ * is reserved (tbrm_resources_reserve) and the scene stays inside the reserved envelope; out[14] sweep launches that ran several
+ * axis passes at once (k_light_sweep_chain: the next pass fills while the one before drains; tunable sweep_chain); out[15] reserved (0). */
 #define TBRM_PATH_COUNTERS 16
 TBRM_API int tbrm_path_counters(const tbrm_resources* res, uint64_t out[TBRM_PATH_COUNTERS]);
 /* The factor cache of the light operators (no counterpart in the reference, invisible in the results). The expensive half

@@ -531,7 +531,7 @@ class Resources:
 
     PATH_COUNTERS = ("passes_sweep", "passes_chain", "passes_slice", "launches_sweep", "launches_chain", "launches_slice",
                      "occlusion_single", "occlusion_dual", "occlusion_cached", "raymarch", "pair_sweeps", "block_lists_built",
-                     "operator_alloc_calls", "operator_host_syncs")
+                     "operator_alloc_calls", "operator_host_syncs", "launches_sweep_chain")
 
     def path_counters(self):
         """tbrm_path_counters: which kernels the light operators took (per axis pass and per launch)."""

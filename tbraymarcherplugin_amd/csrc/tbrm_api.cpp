@@ -35,7 +35,7 @@ const TunableDef kTunables[TUNE_COUNT] = {
     {"force_slice_kernel", 0}, {"chunk_steps", 0}, {"occ_slices", 0}, {"sparse_occ", 1}, {"occ_list", 1}, {"light_cache_mb", -1},
     {"light_batching", 1}, {"share_grid", 1}, {"ray_wave_skip", -1}, {"ray_lanes", 0}, {"chain_fast_loop", 1},
     {"chain_rect_planes", 1}, {"occ_overlap", 2}, {"light_sweep", 1}, {"sweep_prefetch", 0}, {"stream_priority", 0}, {"sweep_debug", 0},
-    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_dual", 1}, {"ray_xcd_rows", 1},
+    {"sweep_timeout_ms", 0}, {"fast_window_div", 1}, {"slab_sweep", 0}, {"gpu_timing", 1}, {"ray_tables", 1}, {"sweep_epoch_preset", 0}, {"occ_dual", 1}, {"sweep_chain", 4}, {"ray_xcd_rows", 1},
 };
 struct TunableStore {
     std::atomic<int> v[TUNE_COUNT];
@@ -760,6 +760,7 @@ int tbrm_path_counters(const tbrm_resources* r, uint64_t out[TBRM_PATH_COUNTERS]
     out[11] = r->lists_launches;
     out[12] = r->alloc_calls;
     out[13] = r->sync_calls;
+    out[14] = r->chain_launches;
     return TBRM_OK;
 }
 

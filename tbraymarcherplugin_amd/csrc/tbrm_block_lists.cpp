@@ -128,7 +128,7 @@ static void prune(tbrm_resources* r)
 {
     if (r->block_lists.size() < kMaxLists) return;
     drain(r);
-    r->alloc_calls += 4;
+    count_alloc(r, 4, "pruned block lists");
     std::vector<BlockLists*> keep;
     std::sort(r->block_lists.begin(), r->block_lists.end(), [](const BlockLists* a, const BlockLists* b) { return a->last_use > b->last_use; });
     for (BlockLists* l : r->block_lists) {
@@ -162,10 +162,16 @@ static BlockLists* new_lists(tbrm_resources* r, size_t blocks, bool with_ranks)
         }
     }
     if (!l) {
+        // then one computed from metadata that is gone (nothing will ask for it again); then — a reserved handle keeps to the lists it
+        // was given — the least recently used one of the current metadata (a light that turns leaves a trail of signatures behind)
+        auto free_to_take = [&](const BlockLists* c) {
+            return c->users == 0 && c->cap >= blocks && (c->slot != nullptr) == with_ranks && c->last_use <= r->block_lists_op_floor;
+        };
         for (BlockLists* c : r->block_lists)
-            if (c->empty_gen != r->empty_gen && c->users == 0 && c->cap >= blocks && (c->slot != nullptr) == with_ranks && c->last_use <= r->block_lists_op_floor &&
-                op_finished(r, c->last_read_op) && (!l || c->cap < l->cap))
-                l = c;
+            if (c->empty_gen != r->empty_gen && free_to_take(c) && op_finished(r, c->last_read_op) && (!l || c->cap < l->cap)) l = c;
+        if (!l && r->reserved)
+            for (BlockLists* c : r->block_lists)
+                if (free_to_take(c) && (!l || c->last_use < l->last_use) && op_finished(r, c->last_read_op)) l = c;
         if (l) {
             l->sig.clear();
             l->a_id = l->b_id = 0;
@@ -174,7 +180,7 @@ static BlockLists* new_lists(tbrm_resources* r, size_t blocks, bool with_ranks)
     }
     if (!l) {
         prune(r);
-        r->alloc_calls += with_ranks ? 5 : 3;
+        count_alloc(r, with_ranks ? 5 : 3, "new block lists (no spare or quiet list to take)");
         l = allocate_lists(blocks, with_ranks);
         if (!l) return nullptr;
         r->block_lists.push_back(l);

@@ -14,6 +14,12 @@ void drain_streams(tbrm_resources* r)
 }
 void drain_streams_public(tbrm_resources* r) { drain_streams(r); }
 
+void count_alloc(tbrm_resources* r, int calls, const char* what)
+{
+    r->alloc_calls += (uint64_t) calls;
+    if (tune(TUNE_SWEEP_DEBUG) & 64) fprintf(stderr, "[tbrm alloc] op %llu: %d calls for %s\n", (unsigned long long) r->op_serial, calls, what);
+}
+
 // ordering events come from a pool the handle keeps (made by tbrm_resources_reserve, refilled when an entry goes)
 hipEvent_t take_event(tbrm_resources* r)
 {
@@ -23,7 +29,7 @@ hipEvent_t take_event(tbrm_resources* r)
         return ev;
     }
     hipEvent_t ev = nullptr;
-    ++r->alloc_calls;
+    count_alloc(r, 1, "an ordering event (pool empty)");
     if (hipEventCreateWithFlags(&ev, event_flags()) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
     return ev;
 }
@@ -48,7 +54,7 @@ bool op_finished(tbrm_resources* r, uint64_t op)
 static void free_entry(tbrm_resources* r, FactorEntry* e)
 {
     if (r->cache_arena.owns(e->base)) r->cache_arena.give(e->base, e->bytes());
-    else if (e->base) { ++r->alloc_calls; (void) hipFree(e->base); }
+    else if (e->base) { count_alloc(r, 1, "freeing a cache entry allocated outside the arena"); (void) hipFree(e->base); }
     if (e->lists) --e->lists->users;
     give_event(r, e->ev_filled);
     give_event(r, e->ev_idle);
@@ -104,7 +110,7 @@ int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems
     const size_t elems = (size_t) slices * slice_elems; // (the passes of a non-cubic volume have planes of different sizes)
     if (elems > st->capacity || !st->base) {
         ++r->sync_calls;
-        r->alloc_calls += 2;
+        count_alloc(r, 2, "a chunked-chain occlusion store");
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->occ_stream) HIP_TRY(hipStreamSynchronize(r->occ_stream));
         (void) hipFree(st->base);
@@ -116,7 +122,7 @@ int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems
     }
     if (flag_bytes > st->flag_bytes) {
         ++r->sync_calls;
-        r->alloc_calls += 4;
+        count_alloc(r, 4, "a chunked-chain flag store");
         HIP_TRY(hipStreamSynchronize(r->stream));
         if (r->occ_stream) HIP_TRY(hipStreamSynchronize(r->occ_stream));
         (void) hipFree(st->flags);
@@ -134,7 +140,7 @@ int ensure_store(tbrm_resources* r, OccStore* st, int slices, size_t slice_elems
 int ensure_occ_stream(tbrm_resources* r)
 {
     if (r->occ_stream) return TBRM_OK;
-    r->alloc_calls += 1 + 4 + tbrm_resources::kOpEvents; // (a stream and its events)
+    count_alloc(r, 1 + 4 + tbrm_resources::kOpEvents, "the occlusion stream and its events");
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_TRY(hipStreamCreateWithPriority(&r->occ_stream, hipStreamNonBlocking, least)); // (the handle's stream's priority instead: measured, no gain)
@@ -152,14 +158,14 @@ int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int streams)
 {
     FactorScratch& f = r->f_scratch[b];
     if (!r->d_ones) {
-        ++r->alloc_calls;
+        count_alloc(r, 1, "the page of ones");
         ++r->sync_calls;
         HIP_TRY(hipMalloc((void**) &r->d_ones, 1024 * sizeof(float)));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) r->d_ones, 0x3f800000, 1024, r->stream));
         HIP_TRY(hipStreamSynchronize(r->stream)); // (read from the occlusion stream's sweeps' predecessors: simplest to have it done)
     }
     if (!f.ev_ready) {
-        r->alloc_calls += 2;
+        count_alloc(r, 2, "a scratch buffer's events");
         HIP_TRY(hipEventCreateWithFlags(&f.ev_ready, event_flags()));
         HIP_TRY(hipEventCreateWithFlags(&f.ev_idle, event_flags()));
     }
@@ -168,7 +174,7 @@ int ensure_factor_scratch(tbrm_resources* r, int b, size_t blocks, int streams)
     for (int si = 0; si < streams; ++si) need = need || grow_store || !f.store[si];
     if (!need) return TBRM_OK;
     drain_streams(r);
-    r->alloc_calls += (uint64_t) std::max(streams, 1);
+    count_alloc(r, std::max(streams, 1), "a factor scratch store");
     if (grow_store) {
         for (float*& st : f.store) { (void) hipFree(st); st = nullptr; }
         f.store_blocks = 0;
@@ -361,8 +367,10 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
     {
         const size_t gw = r->lv_fmt != FMT_U8 ? 4 : 1;
         const size_t words = (size_t) depth * (size_t) tiles * (size_t) sweep_record_words(2, 2, sweep_tile_rows()) * gw;
-        if (words < ((size_t) 1 << 32))
-            if (int e = ensure_sweep(r, std::max<size_t>(words, 1), words)) return e;
+        // (chained passes have a region of the first buffer each: kSweepChainMax passes of reach 1, or two of reach 2)
+        const size_t first = std::max(words, (size_t) kSweepChainMax * (((size_t) depth * (size_t) tiles * (size_t) sweep_record_words(2, 2, sweep_tile_rows()) + 63) & ~(size_t) 63));
+        if (first < ((size_t) 1 << 32))
+            if (int e = ensure_sweep(r, std::max<size_t>(first, 1), words, (size_t) tiles)) return e;
     }
     // ordering events and block lists for n_lights lights' passes
     const size_t want_events = (size_t) 8 * n_lights + 16;
@@ -375,9 +383,9 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
         size_t have_ranked = 0, have_plain = 0;
         for (const BlockLists* l : r->spare_lists) (l->slot ? have_ranked : have_plain) += 1;
         const size_t units = (size_t) ceil_div(r->lv_dims[0], 16) * ceil_div(r->lv_dims[1], 16) * (size_t) ceil_div(r->lv_dims[2], 8);
-        for (size_t k = have_ranked; k < (size_t) 6 * n_lights + 6; ++k)
+        for (size_t k = have_ranked; k < (size_t) 12 * n_lights + 16; ++k)
             if (!make_spare_lists(r, blocks, true)) return TBRM_ERR_OUT_OF_MEMORY;
-        for (size_t k = have_plain; k < (size_t) 3 * n_lights + 3; ++k)
+        for (size_t k = have_plain; k < (size_t) 6 * n_lights + 8; ++k)
             if (!make_spare_lists(r, std::max(units, blocks), false)) return TBRM_ERR_OUT_OF_MEMORY;
     }
     // the factor cache's arena: per light two passes, twice (a light that moves fills new entries while the old ones are still read),

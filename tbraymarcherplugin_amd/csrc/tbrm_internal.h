@@ -204,6 +204,34 @@ struct SweepParams {
     unsigned long long give_up_ticks; // how long a poll waits for a neighbour's word, in 10 ns ticks of wall_clock64 (tunable sweep_timeout_ms)
 };
 
+// Several axis passes in ONE sweep launch (k_light_sweep_chain): the tiles of pass i + 1 take their tickets behind every tile of
+// pass i, so they start as pass i's tiles retire — the fill of a pass runs under the drain of the one before instead of behind a
+// kernel boundary (30 hops x ~2.9 us of every pass are fill / drain at 512^3). What orders the two passes' read-modify-writes of
+// the light volume is data, not a boundary: a tile writes its brick layers back with write-through (sc1) stores and then
+// publishes "k layers written back" in its progress word {16-bit launch tag, count} (relaxed agent-scope store behind a drained
+// vmcnt); a tile of the next pass reads a brick layer (sc1 loads) only after the progress word of the ONE tile of the pass before
+// that owns those bricks has reached the layer it needs. Forward progress: a tile only ever waits for tiles with smaller tickets.
+struct SweepLink {
+    uint32_t* prog_out;        // this pass's progress words, [tile]
+    const uint32_t* prog_in;   // the pass before's (the launch's first pass: any valid words — in_G = 0, it needs nothing of them)
+    uint32_t in_epoch;         // ... and its launch tag
+    int in_axis, in_tiles_x;   // ... its axis and tiles per row
+    int in_down, in_layer0, in_G; // ... its direction, first brick layer and number of layers
+    int coherent_loads;        // this pass reads its brick layers with sc1 loads: every pass but the launch's first
+    int ticket0;               // first ticket of this pass
+    int total_tiles;           // tiles of the whole launch (the last one to finish re-arms the tickets)
+};
+constexpr int kSweepChainMax = 4; // passes per launch (the kernel's arguments hold their parameter blocks: 4 x ~0.6 KB)
+struct SweepChainPass {
+    ChunkParams p;
+    SweepParams q;
+    SweepLink link;
+};
+struct SweepChainArgs {
+    int n;
+    SweepChainPass pass[kSweepChainMax];
+};
+
 struct RayParams {
     VolumeDev data;
     int data_addr_mode; // ADDR_WRAP / ADDR_CLAMP
@@ -326,6 +354,7 @@ enum Tunable : int {
                              // hand-off records start over after 65535 launches)
     TUNE_OCC_DUAL,           // 1: the two axis passes of a light share ONE occlusion launch where their sampling positions are bit-equal
                              // (DualOcc); 0: one launch per pass
+    TUNE_SWEEP_CHAIN,        // consecutive sweep passes of an operator per launch (k_light_sweep_chain): 1 = one launch per pass, up to 4
     TUNE_RAY_XCD_ROWS,       // k_raymarch_lit: rows of pixel blocks per band dealt to one XCD (0: blocks in launch order, i.e. round-robin)
     TUNE_COUNT
 };
@@ -345,6 +374,7 @@ hipError_t launch_light_occlusion(const ChunkParams& p, int mode, hipStream_t s,
 hipError_t launch_unit_flags(const ChunkParams& pc, const DualOcc& d, hipStream_t s); // + the units' work list (pc: the virtual pass along the third axis)
 hipError_t launch_light_chain(const ChunkParams& p, int mode, int lv_fmt, hipStream_t s);
 hipError_t launch_light_sweep(const ChunkParams& p, const SweepParams& q, int mode, hipStream_t s);
+hipError_t launch_light_sweep_chain(const SweepChainArgs& c, int mode, hipStream_t s); // PASS_ADD / PASS_CHANGE, UNORM8 light volumes
 hipError_t launch_fill(void* dst, int fmt, size_t n, float value, hipStream_t s);
 hipError_t launch_propagate_slice(const PropParams& p, bool change, hipStream_t s);
 hipError_t launch_raymarch(const RayParams& p, hipStream_t s);

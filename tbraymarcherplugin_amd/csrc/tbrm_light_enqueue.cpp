@@ -262,16 +262,13 @@ int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& pa, const PassPlan
     return TBRM_OK;
 }
 
-// The sweep of a sweep pass on the handle's stream, behind the occlusion it consumes
-static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
+// What a sweep launch of the plan is handed: the pass's parameters with its factor stores, the sweep's with the handle's
+// records, tickets and error word (the launch tag is the caller's: next_sweep_epoch)
+static void sweep_launch_params(tbrm_resources* r, const PassPlan& plan, ChunkParams& p, SweepParams& q)
 {
-    if (int e = enqueue_sweep_occlusion(r, plan)) return e;
     FactorScratch& f = r->f_scratch[plan.f_buf];
     const int ns = plan.n_streams();
-    if (plan.occ_mode >= 0) HIP_TRY(hipStreamWaitEvent(r->stream, f.ev_ready, 0));
-    for (int si = 0; si < ns; ++si)
-        if (plan.f_hit[si]) HIP_TRY(hipStreamWaitEvent(r->stream, plan.f_entry[si]->ev_filled, 0)); // (it may still be being filled)
-    ChunkParams p = plan.p;
+    p = plan.p;
     p.j0 = plan.start;
     p.n_steps = plan.D;
     p.first_chunk = plan.pass_begins_here ? 1 : 0; // (a slab behind the first continues from the planes it was handed)
@@ -295,11 +292,45 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
             st.fs_slot = plan.lists->slot;
         }
     }
-    SweepParams q = plan.sq;
+    q = plan.sq;
     q.rec[0] = r->sweep_rec[0];
     q.rec[1] = r->sweep_rec[1];
     q.ticket = r->sweep_ticket;
     q.error = r->sweep_error;
+}
+
+// who read what: later operators wait for this operator's "sweeps done" event (wait_for_readers); the buffers' own events
+// are recorded only where a later pass of THIS operator could take the buffer again (an operator of more than two sweep
+// passes: every marker between two dependent kernels costs the stream a few microseconds)
+static int sweep_read_marks(tbrm_resources* r, const PassPlan& plan)
+{
+    FactorScratch& f = r->f_scratch[plan.f_buf];
+    if (r->op_many_passes) HIP_TRY(hipEventRecord(f.ev_idle, r->stream));
+    f.used = true;
+    f.last_read_op = r->op_serial;
+    f.idle_recorded = r->op_many_passes;
+    for (int si = 0; si < plan.n_streams(); ++si)
+        if (FactorEntry* const e = plan.f_entry[si]) {
+            if (r->op_many_passes) HIP_TRY(hipEventRecord(e->ev_idle, r->stream));
+            e->read_yet = true;
+            e->last_read_op = r->op_serial;
+            e->idle_recorded = r->op_many_passes;
+        }
+    return TBRM_OK;
+}
+
+// The sweep of a sweep pass on the handle's stream, behind the occlusion it consumes
+static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
+{
+    if (int e = enqueue_sweep_occlusion(r, plan)) return e;
+    FactorScratch& f = r->f_scratch[plan.f_buf];
+    const int ns = plan.n_streams();
+    if (plan.occ_mode >= 0) HIP_TRY(hipStreamWaitEvent(r->stream, f.ev_ready, 0));
+    for (int si = 0; si < ns; ++si)
+        if (plan.f_hit[si]) HIP_TRY(hipStreamWaitEvent(r->stream, plan.f_entry[si]->ev_filled, 0)); // (it may still be being filled)
+    ChunkParams p;
+    SweepParams q;
+    sweep_launch_params(r, plan, p, q);
     if (q.r_from_records) {
         // the removed light's planes first: one stream in its own tile order, the light volume untouched, its hand-off
         // records (which the fused launch reads instead of waiting for them) in the second buffer
@@ -324,12 +355,13 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
         const int tiles = p.tiles_x * p.tiles_y;
         if (tiles > r->sweep_stamp_tiles || !r->sweep_stamps) {
             drain_streams(r);
-            r->alloc_calls += 2;
+            count_alloc(r, 2, "sweep stamps (diagnostics)");
             (void) hipFree(r->sweep_stamps);
             r->sweep_stamps = nullptr;
             HIP_TRY(hipMalloc((void**) &r->sweep_stamps, (size_t) tiles * 4 * sizeof(unsigned long long)));
         }
         r->sweep_stamp_tiles = tiles;
+        r->sweep_stamp_chain[0] = 0;
         r->sweep_stamp_tx = p.tiles_x;
         r->sweep_stamp_sx = q.sx;
         r->sweep_stamp_sy = q.sy;
@@ -338,21 +370,7 @@ static int enqueue_sweep(tbrm_resources* r, const PassPlan& plan)
     HIP_TRY(launch_light_sweep(p, q, plan.mode, r->stream));
     ++r->launches[0];
     ++r->sweep_launches;
-    // who read what: later operators wait for this operator's "sweeps done" event (wait_for_readers); the buffers' own events
-    // are recorded only where a later pass of THIS operator could take the buffer again (an operator of more than two sweep
-    // passes: every marker between two dependent kernels costs the stream a few microseconds)
-    if (r->op_many_passes) HIP_TRY(hipEventRecord(f.ev_idle, r->stream));
-    f.used = true;
-    f.last_read_op = r->op_serial;
-    f.idle_recorded = r->op_many_passes;
-    for (int si = 0; si < ns; ++si)
-        if (FactorEntry* const e = plan.f_entry[si]) {
-            if (r->op_many_passes) HIP_TRY(hipEventRecord(e->ev_idle, r->stream));
-            e->read_yet = true;
-            e->last_read_op = r->op_serial;
-            e->idle_recorded = r->op_many_passes;
-        }
-    return TBRM_OK;
+    return sweep_read_marks(r, plan);
 }
 
 // Two Add passes of DIFFERENT lights that leave the same cube face as ONE sweep (PASS_ADD2; SURVEY.md 8f N4, the multi-light
@@ -424,6 +442,82 @@ int enqueue_sweep_pair(tbrm_resources* r, const PassPlan& pa, const PassPlan& pb
             e->idle_recorded = r->op_many_passes;
         }
     }
+    return TBRM_OK;
+}
+
+// Several consecutive sweep passes of an operator as ONE launch (k_light_sweep_chain, tbrm_internal.h SweepLink): the fill of
+// pass i + 1 runs under the drain of pass i. Every pass's occlusion goes first (the launch waits for all of them); each pass has
+// its own region of the hand-off records and its own launch tag, and a table of progress words orders the passes' read-modify-writes
+// of the light volume, brick layer by brick layer. plans: n passes (2 .. kSweepChainMax) of one mode (PASS_ADD or PASS_CHANGE),
+// one-way, over a UNORM8 light volume, in different scratch buffers.
+int enqueue_sweep_chain(tbrm_resources* r, const PassPlan* plans, int n)
+{
+    if (n < 1 || n > kSweepChainMax) return fail(TBRM_ERR_INVALID_ARG, "a sweep chain of %d passes", n);
+    for (int k = 0; k < n; ++k) {
+        const int e = (k + 1 < n && dual_fit(plans[k], plans[k + 1])) ? enqueue_dual_occlusion(r, plans[k], plans[k + 1]) : enqueue_sweep_occlusion(r, plans[k]);
+        if (e) return e;
+    }
+    size_t offset[kSweepChainMax + 1] = {0};
+    int tiles_max = 0;
+    for (int k = 0; k < n; ++k) {
+        const PassPlan& plan = plans[k];
+        const size_t words = (size_t) plan.D * plan.p.tiles_x * plan.p.tiles_y * (size_t) sweep_record_words(plan.sq.hx, plan.sq.hy, plan.sq.tile_rows);
+        offset[k + 1] = offset[k] + ((words + 63) & ~(size_t) 63);
+        tiles_max = std::max(tiles_max, plan.p.tiles_x * plan.p.tiles_y);
+    }
+    if (offset[n] >= ((size_t) 1 << 32)) return fail(TBRM_ERR_UNSUPPORTED, "hand-off records too large");
+    if (int e = ensure_sweep(r, std::max<size_t>(offset[n], 1), 0, (size_t) tiles_max)) return e;
+    SweepChainArgs c{};
+    c.n = n;
+    int ticket0 = 0;
+    const bool stamps = (tune(TUNE_SWEEP_DEBUG) & 2) != 0; // diagnostics: per-tile time stamps of this launch (printed by tbrm_flush)
+    if (stamps) {
+        int total = 0;
+        for (int k = 0; k < n; ++k) total += plans[k].p.tiles_x * plans[k].p.tiles_y;
+        if (total > r->sweep_stamp_tiles || !r->sweep_stamps) {
+            drain_streams(r);
+            count_alloc(r, 2, "sweep stamps (diagnostics)");
+            (void) hipFree(r->sweep_stamps);
+            r->sweep_stamps = nullptr;
+            HIP_TRY(hipMalloc((void**) &r->sweep_stamps, (size_t) total * 4 * sizeof(unsigned long long)));
+        }
+        r->sweep_stamp_tiles = total;
+        for (int k = 0; k < 4; ++k) r->sweep_stamp_chain[k] = k < n ? plans[k].p.tiles_x * plans[k].p.tiles_y : 0;
+    }
+    for (int k = 0; k < n; ++k) {
+        const PassPlan& plan = plans[k];
+        FactorScratch& f = r->f_scratch[plan.f_buf];
+        if (plan.occ_mode >= 0) HIP_TRY(hipStreamWaitEvent(r->stream, f.ev_ready, 0));
+        for (int si = 0; si < plan.n_streams(); ++si)
+            if (plan.f_hit[si]) HIP_TRY(hipStreamWaitEvent(r->stream, plan.f_entry[si]->ev_filled, 0));
+        SweepChainPass& P = c.pass[k];
+        sweep_launch_params(r, plan, P.p, P.q);
+        P.q.rec[0] = r->sweep_rec[0] + offset[k];
+        P.q.rec[1] = nullptr;
+        P.q.stamps = stamps ? r->sweep_stamps + (size_t) 4 * ticket0 : nullptr;
+        P.q.debug &= stamps ? ~1 : ~3;
+        if (k > 0) P.q.stagger_ns = 0; // (its tiles start as the pass before's retire: that IS their stagger)
+        if (int e = next_sweep_epoch(r, P.q.epoch, k == 0 ? (uint32_t) n : 1u)) return e;
+        SweepLink& l = P.link;
+        l.prog_out = r->sweep_prog + (size_t) k * r->sweep_prog_stride;
+        // (the first pass: in_G = 0 — it needs nothing of the words it asks for; a table nobody writes, so that asking costs nothing)
+        l.prog_in = k > 0 ? c.pass[k - 1].link.prog_out : r->sweep_prog + (size_t) kSweepChainMax * r->sweep_prog_stride;
+        l.in_epoch = k > 0 ? c.pass[k - 1].q.epoch : 0u;
+        l.in_axis = k > 0 ? c.pass[k - 1].p.axis : 0;
+        l.in_tiles_x = k > 0 ? c.pass[k - 1].p.tiles_x : 1;
+        l.in_down = k > 0 && c.pass[k - 1].p.dir < 0 ? 1 : 0;
+        l.in_layer0 = k > 0 ? c.pass[k - 1].p.j0 >> 3 : 0;
+        l.in_G = k > 0 ? c.pass[k - 1].p.n_steps >> 3 : 0;
+        l.coherent_loads = k >= 1 ? 1 : 0;
+        l.ticket0 = ticket0;
+        ticket0 += P.p.tiles_x * P.p.tiles_y;
+    }
+    for (int k = 0; k < n; ++k) c.pass[k].link.total_tiles = ticket0;
+    HIP_TRY(launch_light_sweep_chain(c, plans[0].mode, r->stream));
+    ++r->launches[0];
+    ++r->sweep_launches;
+    ++r->chain_launches;
+    for (int k = 0; k < n; ++k) sweep_read_marks(r, plans[k]);
     return TBRM_OK;
 }
 

@@ -120,8 +120,32 @@ static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<Pas
         probe.lap("pass");
         return TBRM_OK;
     };
+    // consecutive sweep passes in ONE launch (k_light_sweep_chain): the next pass's tiles fill while this pass's drain
+    const int chain_max = std::min(tune(TUNE_SWEEP_CHAIN), kSweepChainMax);
+    auto chainable = [&](size_t k) {
+        if (k >= specs.size() || !chunked[k] || is_second[k] || partner[k] >= 0) return false;
+        const PassPlan& pl = plans[k];
+        return pl.sweep && (pl.mode == PASS_ADD || pl.mode == PASS_CHANGE) && !pl.sq.r_from_records && !pl.sq.lv_f32 && !(pl.sq.debug & 1) &&
+               sweep_halo_chunks(pl.sq.hx, pl.sq.hy, pl.sq.tile_rows) <= 3;
+    };
     for (size_t i = 0; i < specs.size(); ++i) {
         if (is_second[i]) continue; // (took its turn with its partner)
+        if (chain_max >= 2 && chainable(i)) {
+            size_t len = 1;
+            while ((int) len < chain_max && chainable(i + len) && plans[i + len].mode == plans[i].mode) {
+                bool fresh_buffer = true; // (every pass of a launch reads its own scratch buffer)
+                for (size_t k = 0; k < len; ++k) fresh_buffer = fresh_buffer && plans[i + k].f_buf != plans[i + len].f_buf;
+                if (!fresh_buffer) break;
+                ++len;
+            }
+            if (len >= 2) {
+                if (int e = enqueue_sweep_chain(r, &plans[i], (int) len)) { quiesce_occ_stream(r); return e; }
+                r->passes[0] += len;
+                probe.lap("chain");
+                i += len - 1;
+                continue;
+            }
+        }
         if (partner[i] >= 0) {
             const size_t j = (size_t) partner[i];
             SweepFit fit;

@@ -24,7 +24,7 @@ struct SpanRange { int s0, sn, c0, c1; bool sparse; };
 unsigned event_flags();
 bool force_slice_kernel();
 int chunk_steps_override();
-int ensure_sweep(tbrm_resources* r, size_t words, size_t words1 = 0);
+int ensure_sweep(tbrm_resources* r, size_t words, size_t words1 = 0, size_t chain_tiles = 0);
 int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch, uint32_t launches = 1);
 float through_light_format(int lv_fmt, float v);
 void fill_chunk_stream(ChunkStream& s, const tbrm_light_pass& p, int lv_fmt);
@@ -46,5 +46,6 @@ bool cache_usable(const tbrm_resources* r);
 int ensure_occ_stream(tbrm_resources* r);
 // tbrm_light_enqueue.cpp
 int enqueue_sweep_pair(tbrm_resources* r, const PassPlan& pa, const PassPlan& pb, const SweepFit& fit);
+int enqueue_sweep_chain(tbrm_resources* r, const PassPlan* plans, int n);
 int enqueue_pass_sliced(tbrm_resources* r, PropParams p, const tbrm_light_pass& pa, const tbrm_light_pass* pr);
 } // namespace tbrm_host

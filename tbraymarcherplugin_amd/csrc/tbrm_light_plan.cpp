@@ -112,6 +112,9 @@ void release_sweep(tbrm_resources* r)
     r->sweep_rec_words = r->sweep_rec1_words = 0;
     (void) hipFree(r->sweep_ticket);
     r->sweep_ticket = nullptr;
+    (void) hipFree(r->sweep_prog);
+    r->sweep_prog = nullptr;
+    r->sweep_prog_stride = 0;
     if (r->sweep_error) (void) hipHostFree(r->sweep_error);
     r->sweep_error = nullptr;
     (void) hipFree(r->sweep_stamps);
@@ -122,7 +125,25 @@ int sweep_check(tbrm_resources* r)
 {
     if ((tune(TUNE_SWEEP_DEBUG) & 2) && r->sweep_stamps && r->sweep_stamp_tiles > 0) { // diagnostics: the last launch's timeline
         std::vector<unsigned long long> t((size_t) r->sweep_stamp_tiles * 4);
-        if (hipMemcpy(t.data(), r->sweep_stamps, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (r->sweep_stamp_chain[0] > 0) { // a chained launch: per pass, when its tiles started and ended (us from the launch's first stamp)
+            if (hipMemcpy(t.data(), r->sweep_stamps, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+                unsigned long long t0 = ~0ull;
+                for (int i = 0; i < r->sweep_stamp_tiles; ++i) t0 = std::min(t0, t[4 * i]);
+                int first = 0;
+                for (int k = 0; k < 4 && r->sweep_stamp_chain[k] > 0; ++k) {
+                    const int nt = r->sweep_stamp_chain[k];
+                    double lo[4] = {1e30, 1e30, 1e30, 1e30}, hi[4] = {0, 0, 0, 0}, sum[4] = {0, 0, 0, 0};
+                    for (int i = first; i < first + nt; ++i)
+                        for (int s = 0; s < 4; ++s) {
+                            const double us = (double) (t[4 * i + s] - t0) * 0.01;
+                            lo[s] = std::min(lo[s], us); hi[s] = std::max(hi[s], us); sum[s] += us;
+                        }
+                    fprintf(stderr, "[tbrm chain stamps] pass %d: %d tiles; arrived %.1f / %.1f / %.1f us (first / mean / last), first slice begun %.1f / %.1f / %.1f, last slice done %.1f / %.1f / %.1f, written back %.1f / %.1f / %.1f\n",
+                            k, nt, lo[0], sum[0] / nt, hi[0], lo[1], sum[1] / nt, hi[1], lo[2], sum[2] / nt, hi[2], lo[3], sum[3] / nt, hi[3]);
+                    first += nt;
+                }
+            }
+        } else if (hipMemcpy(t.data(), r->sweep_stamps, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
             const int tx = r->sweep_stamp_tx, ty = r->sweep_stamp_tiles / tx;
             unsigned long long t0 = ~0ull;
             for (int i = 0; i < r->sweep_stamp_tiles; ++i) t0 = std::min(t0, t[4 * i]);
@@ -170,10 +191,22 @@ void sweep_failure_cleared(tbrm_resources* r)
 
 // room for the hand-off records of a pass (words1: of the removed light's own sweep, two-way Changes), the tickets and the
 // error word
-int ensure_sweep(tbrm_resources* r, size_t words, size_t words1)
+int ensure_sweep(tbrm_resources* r, size_t words, size_t words1, size_t chain_tiles)
 {
+    if (chain_tiles + 256 > r->sweep_prog_stride && chain_tiles > 0) { // the progress words of chained passes (tagged with their launch: never cleared)
+        ++r->sync_calls;
+        count_alloc(r, 2, "progress words of chained sweeps");
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        (void) hipFree(r->sweep_prog);
+        r->sweep_prog = nullptr;
+        r->sweep_prog_stride = 0;
+        const size_t stride = ((chain_tiles + 63) & ~(size_t) 63) + 256; // (+ slack: a launch's first pass asks for words near its own, needing nothing of them)
+        HIP_TRY(hipMalloc((void**) &r->sweep_prog, stride * (kSweepChainMax + 1) * sizeof(uint32_t))); // (+ the table nobody writes)
+        HIP_TRY(hipMemsetAsync(r->sweep_prog, 0, stride * (kSweepChainMax + 1) * sizeof(uint32_t), r->stream));
+        r->sweep_prog_stride = stride;
+    }
     if (!r->sweep_ticket) {
-        r->alloc_calls += 2;
+        count_alloc(r, 2, "sweep tickets and error word");
         HIP_TRY(hipMalloc((void**) &r->sweep_ticket, 2 * sizeof(int)));
         HIP_TRY(hipMemsetAsync(r->sweep_ticket, 0, 2 * sizeof(int), r->stream));
         HIP_TRY(hipHostMalloc((void**) &r->sweep_error, sizeof(int), hipHostMallocMapped));
@@ -181,7 +214,7 @@ int ensure_sweep(tbrm_resources* r, size_t words, size_t words1)
     }
     if (words > r->sweep_rec_words) {
         ++r->sync_calls;
-        r->alloc_calls += 2;
+        count_alloc(r, 2, "hand-off records (a pass beyond the reserved reach)");
         HIP_TRY(hipStreamSynchronize(r->stream));
         (void) hipFree(r->sweep_rec[0]);
         r->sweep_rec[0] = nullptr;
@@ -192,7 +225,7 @@ int ensure_sweep(tbrm_resources* r, size_t words, size_t words1)
     }
     if (words1 > r->sweep_rec1_words) {
         ++r->sync_calls;
-        r->alloc_calls += 2;
+        count_alloc(r, 2, "hand-off records of a two-way Change (beyond the reserved reach)");
         HIP_TRY(hipStreamSynchronize(r->stream));
         (void) hipFree(r->sweep_rec[1]);
         r->sweep_rec[1] = nullptr;
@@ -214,6 +247,7 @@ int next_sweep_epoch(tbrm_resources* r, uint32_t& epoch, uint32_t launches)
     if (++r->sweep_epoch + (launches - 1) >= (1u << 16)) { // 2^16 launches later: tags start over
         HIP_TRY(hipMemsetAsync(r->sweep_rec[0], 0, r->sweep_rec_words * sizeof(uint32_t), r->stream));
         if (r->sweep_rec[1]) HIP_TRY(hipMemsetAsync(r->sweep_rec[1], 0, r->sweep_rec1_words * sizeof(uint32_t), r->stream));
+        if (r->sweep_prog) HIP_TRY(hipMemsetAsync(r->sweep_prog, 0, r->sweep_prog_stride * kSweepChainMax * sizeof(uint32_t), r->stream));
         r->sweep_epoch = 1;
     }
     epoch = r->sweep_epoch;

@@ -73,5 +73,7 @@ int sweep_tile_rows();
 // one translation unit per (mode, tile height): tbrm_light_sweep.hip compiled with -DTBRM_SWEEP_UNIT_MODE / _TH
 template <int MODE, int TH>
 hipError_t launch_sweep_unit(const ChunkParams& p, const SweepParams& q, hipStream_t s);
+template <int MODE, int TH>
+hipError_t launch_sweep_chain_unit(const SweepChainArgs& c, hipStream_t s);
 
 } // namespace tbrm

@@ -88,6 +88,40 @@ __device__ __noinline__ uint64_t sweep_poll(const uint64_t* src, uint32_t epoch,
     return w;
 }
 
+// CHAIN (k_light_sweep_chain, tbrm_internal.h SweepLink): the slow path of waiting for the pass before — the tile that owns the
+// bricks about to be read has not written them back yet. Same form as sweep_poll.
+__device__ __noinline__ uint32_t sweep_poll_progress(const uint32_t* src, uint32_t epoch, uint32_t needed, int* error, unsigned long long give_up_ticks)
+{
+    uint32_t w = 0;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
+        if ((w >> 16) == epoch && (w & 0xffffu) >= needed) return w;
+        if (wall_clock64() - t0 >= give_up_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    atomicOr(error, 1);
+    return w;
+}
+// 16 bytes of the light volume past the XCD's L2 in both directions (MI355X_MICROARCH.md: "16-B sc1 stores AND sc1 loads")
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sweep_store16_sc1(void* dst, uint4 v)
+{
+    v4u d;
+    d.x = v.x; d.y = v.y; d.z = v.z; d.w = v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(d) : "memory");
+}
+// ... as TWO vector-memory operations whether coherent (sc1) or not: the slice loop counts them (s_waitcnt vmcnt(2) leaves exactly
+// these two in flight and nothing older — the layer written back before them has left the wave)
+template <bool COHERENT>
+__device__ __forceinline__ uint4 sweep_load16_two_ops(const void* src)
+{
+    constexpr int SCOPE = COHERENT ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP;
+    const uint64_t a = __hip_atomic_load((const uint64_t*) src, __ATOMIC_RELAXED, SCOPE);
+    const uint64_t b = __hip_atomic_load((const uint64_t*) src + 1, __ATOMIC_RELAXED, SCOPE);
+    return make_uint4((uint32_t) a, (uint32_t) (a >> 32), (uint32_t) b, (uint32_t) (b >> 32));
+}
+
 // One block slice of occlusion factors (64 lanes x 16 bytes = the 256 floats of a 16 x 16 block) from global memory straight
 // into LDS at `lds_dst` (wave-uniform byte address) + lane * 16: no registers, counted by vmcnt like any load — but invisible
 // to the compiler's own wait-count bookkeeping, which is the point: the loader waits with sweep_wait_loads<N>() for exactly
@@ -134,12 +168,14 @@ __device__ __forceinline__ v2f quantize2_unfloored(v2f x) // (>= 0.5: the conver
 // tag} (one per stream, written by one store and read by one load), and the light volume is updated
 // in place — fire-and-forget fp32 atomic adds, the removed light's as a second add of -L: (LV + La) - Lr rounds twice, like the
 // reference's expression (ChangeDirLightShader.usf:152-154).
-template <int MODE, int AXIS, int PF, int HC, bool RREC, int LFMT, int TH>
-__global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 : 1) void k_light_sweep(const ChunkParams p, const SweepParams q)
+// CHAIN: the tile belongs to one of several passes of ONE launch (k_light_sweep_chain; SweepLink says how it waits for the pass
+// before and what it publishes for the pass behind); `ticket` is the tile's ticket within its pass.
+template <int MODE, int AXIS, int PF, int HC, bool RREC, int LFMT, int TH, bool CHAIN>
+__device__ __forceinline__ void sweep_tile(const ChunkParams& p, const SweepParams& q, const SweepLink& link, const int ticket)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_ticket;
     static_assert(TH == 32 || TH == 16, "a tile is 32 x 32 or 32 x 16 pixels");
+    static_assert(!CHAIN || (LFMT == FMT_U8 && !RREC && (MODE == PASS_ADD || MODE == PASS_CHANGE)), "chained passes: Add / fused Change over a UNORM8 light volume");
     constexpr int T = kSweepTile, CS = sweep_col_stride(TH), PLANE = sweep_plane(TH), LVB = kSweepLvBrick;
     constexpr int R = 2, NWC = sweep_compute_waves(TH), NTC = NWC * 64, NT = sweep_threads(MODE, TH);
     constexpr int NB = sweep_blocks(TH), NBR = sweep_bricks(TH);
@@ -155,10 +191,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
     static_assert(PF >= 1 && PF < RING, "the request ring holds 8 slices");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
 
-    // ---- which tile: tickets in upstream-first order -------------------------------------------------------------------
-    if (threadIdx.x == 0) s_ticket = atomicAdd(q.ticket, 1);
-    __syncthreads();
-    const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    // ---- which tile: tickets in upstream-first order (taken by the kernel) -------------------------------------------
     const int n_tiles = p.tiles_x * p.tiles_y;
     const int ui = ticket % p.tiles_x, uj = ticket / p.tiles_x;
     const int tile_x = q.sx > 0 ? p.tiles_x - 1 - ui : ui, tile_y = q.sy > 0 ? p.tiles_y - 1 - uj : uj;
@@ -166,6 +199,9 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
     const int base_x = tile_x * T, base_y = tile_y * TH;
     const int n = p.n_steps, G = n >> 3; // whole brick layers (the launcher's check)
     const int hx = q.hx, hy = q.hy;
+    if constexpr (CHAIN) {
+        if ((q.debug & 2) != 0 && q.stamps != nullptr && threadIdx.x == 0) q.stamps[4 * tile_lin + 0] = wall_clock64();
+    }
     // LDS plane coordinates of tile pixel (0, 0): behind the guard ring and whatever halo lies on the low side
     const int ox = 1 + max(q.sx < 0 ? hx : 0, (RREC && q.r_sx < 0) ? q.r_hx : 0), oy = 1 + max(q.sy < 0 ? hy : 0, (RREC && q.r_sy < 0) ? q.r_hy : 0);
     const bool down = p.dir < 0;
@@ -233,11 +269,75 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
     constexpr int kLvBuf = NBR * LVB;
     auto layer_of = [&](int g) -> int { return down ? layer0 - g : layer0 + g; };
     // (a layer past the span's end is loaded from the span's last layer instead and never used: no branch around the load)
-    auto load_layer = [&](int g) -> uint4 { return *(const uint4*) ((const uint8_t*) p.light + (piece_off + (uint32_t) layer_of(min(g, G - 1)) * layer_stride)); };
+    auto load_layer = [&](int g) -> uint4 {
+        const uint8_t* const src = (const uint8_t*) p.light + (piece_off + (uint32_t) layer_of(min(g, G - 1)) * layer_stride);
+        if constexpr (CHAIN) {
+            // sc1 for every pass but the launch's first: this CU's L1 may still hold a brick as the tile it ran BEFORE read it (no kernel
+            // boundary has invalidated it since, and the write-through store that replaced it in memory went past the L1), and from
+            // the launch's third pass on this XCD's L2 may hold what a tile of the pass before the last read here
+            return link.coherent_loads ? sweep_load16_two_ops<true>(src) : sweep_load16_two_ops<false>(src);
+        } else return *(const uint4*) src;
+    };
     auto write_back_layer = [&](int g) {
-        if (piece_exists) *(uint4*) ((uint8_t*) p.light + (piece_off + (uint32_t) layer_of(g) * layer_stride)) = *(const uint4*) ((const uint8_t*) piece_lds + (g % 3) * kLvBuf);
+        if (piece_exists) {
+            uint8_t* const dst = (uint8_t*) p.light + (piece_off + (uint32_t) layer_of(g) * layer_stride);
+            const uint4 v = *(const uint4*) ((const uint8_t*) piece_lds + (g % 3) * kLvBuf);
+            if constexpr (CHAIN) sweep_store16_sc1(dst, v);
+            else *(uint4*) dst = v;
+        }
+    };
+    // CHAIN: which tile of the pass before owns the bricks of this tile's layer g, and how many of ITS layers it must have written
+    // back (SweepLink). The tile's bricks along the pass before's axis a: one layer when a is this pass's axis, else the four (TH / 8)
+    // bricks of the tile's extent along a; along the pass before's plane axes they lie inside one of its tiles (a range of bricks
+    // under a tile is aligned to it, a single layer lies inside one). Both are affine in the volume layer L = layer_of(g):
+    //   progress word  dep_base[dep_c1 * (L >> 2)]      (L >> 2: the tile of the pass before that holds layer L, when this pass's
+    //   layers needed  dep_n0 + dep_n1 * L               axis is one of its plane axes — 4 brick layers per 32-pixel tile)
+    // worked out once per tile and kept in vector registers (the slice loop has no scalar registers to spare: what it would
+    // otherwise fetch from the argument block again costs a scalar-memory round trip inside a slice).
+    const uint32_t* dep_base = link.prog_in;
+    int dep_c1 = 0, dep_n0 = 0, dep_n1 = 0;
+    int dep_G = link.in_G;
+    uint32_t dep_epoch = link.in_epoch & 0xffffu;
+    uint32_t* prog_word = link.prog_out + tile_lin;
+    if constexpr (CHAIN) {
+        const int a = link.in_axis;
+        const int ua = a == 0 ? 1 : 0, va = a == 2 ? 1 : 2;
+        int lo[3]; // first brick of the tile per volume axis (along this pass's axis: filled in per layer)
+        lo[dim_u] = base_x >> 3;
+        lo[dim_v] = base_y >> 3;
+        lo[dim_s] = 0;
+        const int lo_a = a == 0 ? lo[0] : (a == 1 ? lo[1] : lo[2]), lo_u = ua == 0 ? lo[0] : lo[1], lo_v = va == 1 ? lo[1] : lo[2];
+        static_assert(TH == 32 || !CHAIN, "chained passes: four brick layers per tile along both plane axes");
+        int c0;
+        if (dim_s == a) { // same axis: the same tile of the pass before, layer by layer
+            c0 = (lo_v >> 2) * link.in_tiles_x + (lo_u >> 2);
+            dep_n0 = link.in_down ? link.in_layer0 + 1 : 1 - link.in_layer0;
+            dep_n1 = link.in_down ? -1 : 1;
+        } else {
+            // the tile's four bricks along a, [lo_a, lo_a + 4): the last of them in the pass before's order
+            dep_n0 = (link.in_down ? link.in_layer0 - lo_a : lo_a + 3 - link.in_layer0) + 1;
+            if (dim_s == ua) { c0 = (lo_v >> 2) * link.in_tiles_x; dep_c1 = 1; }
+            else { c0 = lo_u >> 2; dep_c1 = link.in_tiles_x; }
+        }
+        dep_base = link.prog_in + c0; // (the launch's first pass: in_G = 0 — it needs nothing of the words it is pointed at, its own)
+        asm volatile("" : "+v"(dep_c1), "+v"(dep_n0), "+v"(dep_n1), "+v"(dep_G), "+v"(dep_epoch));
+        asm volatile("" : "+v"(dep_base), "+v"(prog_word));
+    }
+    auto depends_on = [&](int g, uint32_t& needed) -> const uint32_t* {
+        const int L = layer_of(min(g, G - 1));
+        needed = (uint32_t) min(max(dep_n0 + dep_n1 * L, 0), dep_G); // (bricks past the volume's end belong to no layer of the pass before)
+        return dep_base + dep_c1 * (L >> 2);
+    };
+    auto wait_for_layer = [&](int g) { // blocking form: the tile's first two layers
+        uint32_t needed = 0;
+        const uint32_t* const src = depends_on(g, needed);
+        if (needed > 0) (void) sweep_poll_progress(src, dep_epoch, needed, q.error, q.give_up_ticks);
     };
     uint4 lv_next = make_uint4(0, 0, 0, 0);
+    if constexpr (CHAIN) { // the tile's first two layers: ONE wave waits for the pass before (a poll costs the CU's other workgroups issue slots)
+        if (wave == 0) { wait_for_layer(0); wait_for_layer(1); }
+        __syncthreads();
+    }
     if (LVS && wave < NWC) {
         *piece_lds = load_layer(0);
         lv_next = load_layer(1);
@@ -256,7 +356,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
     if (q.give_up_ticks == 0 && ticket == 0 && threadIdx.x == 0) atomicOr(q.error, 1); // (tunable sweep_timeout_ms < 0, a test hook: "the
                                                                                        // first tile gave up" — what a starved device reports after its timeout)
     const bool stamping = (q.debug & 2) != 0 && q.stamps != nullptr && threadIdx.x == 0;
-    if (stamping) q.stamps[4 * tile_lin + 0] = wall_clock64();
+    if (stamping) q.stamps[4 * tile_lin + (CHAIN ? 1 : 0)] = wall_clock64(); // (CHAIN: [0] is the workgroup's arrival, in front of its wait for the pass before)
 
     constexpr int HW = kSweepHandoffWaves;
     if (wave >= NWC && wave < NWC + HW) {
@@ -477,6 +577,18 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
             sweep_wait_loads<AW * L>();
         };
         __builtin_amdgcn_s_setprio(3); // (like the hand-off wave: few instructions, and every other wave waits for them at the barrier)
+        // CHAIN: this wave — a prefetcher seven slices ahead of everybody, with time to spare — also keeps the barrier behind slice 2
+        // of a group until the pass before has written back the brick layer the compute waves load in slice 3. The progress word is
+        // asked for a group ahead, like the wave's other loads in inline assembly (none of its waits is the compiler's): eight
+        // slices' requests are issued and waited for behind it, and vmcnt retires in order — it has landed when it is looked at.
+        // Measured placements (profiles/r06_sweep_chain.txt): in the compute waves a compiler-visible load made the compiler drain
+        // the write-back stores two slices after their issue (+ 6 % per slice); in the hand-off consumer its ring of halo requests
+        // retires behind the extra load (+ 1.2 us per hop); in the publisher a warm reset was 1.88 ms against 1.80 - 1.83 here.
+        uint32_t dep_needed = 0, dep_word = 0;
+        const uint32_t* dep_src = depends_on(2, dep_needed);
+        constexpr bool DEP = CHAIN;
+        const bool dep_mine = DEP && lsi == 0;
+        if (dep_mine) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dep_word) : "v"(dep_src) : "memory");
         rebase(0);
         for (int t = 0; t < A; ++t) request();
         landed(); // slice 0
@@ -484,6 +596,15 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
         for (int s = 0; s < n; ++s) {
             request(); // slice s + A, into the slot slice s - 1 was read from
             landed();  // slice s + 1
+            if constexpr (DEP) {
+                if (dep_mine && (s & 7) == 2 && (s >> 3) < G - 1) {
+                    asm volatile("" : "+v"(dep_word)); // (written behind the compiler's back, eight slices ago)
+                    if (dep_needed > 0 && ((dep_word >> 16) != dep_epoch || (dep_word & 0xffffu) < dep_needed))
+                        (void) sweep_poll_progress(dep_src, dep_epoch, dep_needed, q.error, q.give_up_ticks);
+                    dep_src = depends_on((s >> 3) + 3, dep_needed); // the next group's
+                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(dep_word) : "v"(dep_src) : "memory");
+                }
+            }
             lds_barrier();
         }
         sweep_wait_loads<0>();
@@ -636,6 +757,17 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
             uint8_t* const lv_layer = lvt + (g % 3) * kLvBuf;
             sweep_each_const([&](auto kc) {
                 constexpr int K8 = decltype(kc)::value, CUR = K8 & 1;
+                if constexpr (CHAIN && K8 == 0) {
+                    // The wave's vector-memory operations of the group before, in order: [slice 1: the write-back of layer g - 2] [slice 3:
+                    // the two loads of layer g + 1]. At most the two loads stay in flight: the write-back (seven slices old) has left the
+                    // wave (gfx9 counts loads and stores in issue order); the barrier behind this slice collects the compute waves and
+                    // slice 1 publishes it. (Whether the pass before has written back the layer loaded in slice 3 is the factor
+                    // loader's business: it holds the barrier behind slice 2 until it has.)
+                    if (g > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+                if constexpr (CHAIN && K8 == 1) { // "g - 1 layers written back" (in front of this slice's own write-back)
+                    if (g > 1 && wave == 0 && lane == 0) sweep_store_word(prog_word, tag | (uint32_t) (g - 1));
+                }
                 if constexpr (LVS && K8 == 1) { // (the last voxels of the layer before were updated in slice 0 of this group)
                     if (g > 0) write_back_layer(g - 1);
                 }
@@ -741,7 +873,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
 #pragma unroll
                     for (int k = 0; k < R; ++k) code_n[k] = lv_prev[lv_at[k]];
                 }
-                if constexpr (LV && LAST && K8 == 7) { // the state the next span starts from
+                if constexpr (LV && LAST && K8 == 7 && !CHAIN) { // the state the next span starts from (a chained pass is a whole pass: nothing continues it)
 #pragma unroll
                     for (int si = 0; si < NS; ++si) {
                         if (in_pl[0]) stream(si).plane_out[own_idx[0]] = pval[si].x;
@@ -755,7 +887,7 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
         if (q.reinit_slice > 0) group(0, std::true_type{}, std::false_type{});
         for (int g = q.reinit_slice > 0 ? 1 : 0; g < G - 1; ++g) {
             group(g, std::false_type{}, std::false_type{});
-            if (g == 7 && stamping) q.stamps[4 * tile_lin + 1] = wall_clock64();
+            if (g == 7 && stamping && !CHAIN) q.stamps[4 * tile_lin + 1] = wall_clock64();
         }
         group(G - 1, std::false_type{}, std::true_type{});
         __builtin_amdgcn_s_setprio(0);
@@ -770,16 +902,60 @@ __global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 
 
     __syncthreads(); // the last slice's voxels are in the layer buffers
     if (LVS && wave < NWC) write_back_layer(G - 1);
+    if constexpr (CHAIN) { // every layer of this tile is in memory: say so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) sweep_store_word(prog_word, tag | (uint32_t) G);
+    }
     if (stamping) q.stamps[4 * tile_lin + 3] = wall_clock64();
 
     // ---- the last tile to finish re-arms the tickets for the next launch -----------------------------------------------------
     if (threadIdx.x == 0) {
         const int done = atomicAdd(q.ticket + 1, 1);
-        if (done == n_tiles - 1) {
+        if (done == (CHAIN ? link.total_tiles : n_tiles) - 1) {
             atomicExch(q.ticket + 1, 0);
             atomicExch(q.ticket, 0);
         }
     }
+}
+
+template <int MODE, int AXIS, int PF, int HC, bool RREC, int LFMT, int TH>
+__global__ __launch_bounds__(sweep_threads(MODE, TH), (TH == 16 && HC <= 3) ? 4 : 1) void k_light_sweep(const ChunkParams p, const SweepParams q)
+{
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(q.ticket, 1);
+    __syncthreads();
+    sweep_tile<MODE, AXIS, PF, HC, RREC, LFMT, TH, false>(p, q, SweepLink{}, __builtin_amdgcn_readfirstlane(s_ticket));
+}
+
+// Up to kSweepChainMax consecutive passes of an operator in ONE launch (SweepChainArgs): tickets run through the passes in order —
+// every tile of pass i in front of every tile of pass i + 1 — and a workgroup becomes whatever tile its ticket says, of whatever
+// axis that pass runs along (the three bodies side by side: the launch's registers and LDS are the largest body's).
+template <int MODE, int PF, int HC, int TH>
+__global__ __launch_bounds__(sweep_threads(MODE, TH), 1) void k_light_sweep_chain(const SweepChainArgs)
+{
+    // The argument block is read where it lies, in the kernel-argument segment (constant address space: scalar loads), through a
+    // pointer — a by-value struct indexed with the pass number would be copied to scratch first (3 KB per lane, every field a
+    // vector register). It is the kernel's only explicit argument: offset 0 of the segment.
+    typedef const __attribute__((address_space(4))) SweepChainArgs* KernArgs;
+    const KernArgs c = (KernArgs) __builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ int s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(c->pass[0].q.ticket, 1);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(s_ticket);
+    int pi = 0;
+#pragma unroll
+    for (int k = 1; k < kSweepChainMax; ++k)
+        if (k < c->n && t >= c->pass[k].link.ticket0) pi = k;
+    // The pass's parameter blocks as VALUES (loaded once, here): read through the pointer inside the slice loops they would be
+    // fetched again behind every barrier — a scalar-memory round trip per slice in the hand-off waves, measured as +15 % per slice
+    const ChunkParams p = *(const ChunkParams*) &c->pass[pi].p;
+    const SweepParams q = *(const SweepParams*) &c->pass[pi].q;
+    const SweepLink link = *(const SweepLink*) &c->pass[pi].link;
+    const int local = t - link.ticket0;
+    if (p.axis == 0) sweep_tile<MODE, 0, PF, HC, false, FMT_U8, TH, true>(p, q, link, local);
+    else if (p.axis == 1) sweep_tile<MODE, 1, PF, HC, false, FMT_U8, TH, true>(p, q, link, local);
+    else sweep_tile<MODE, 2, PF, HC, false, FMT_U8, TH, true>(p, q, link, local);
 }
 
 template <int MODE, int AXIS, int PF, int HC, int TH, bool RREC = false, int LFMT = FMT_U8>
@@ -831,8 +1007,38 @@ hipError_t launch_sweep_unit(const ChunkParams& p, const SweepParams& q, hipStre
     return p.axis == 0 ? launch_sweep4<MODE, 0, TH>(p, q, s) : (p.axis == 1 ? launch_sweep4<MODE, 1, TH>(p, q, s) : launch_sweep4<MODE, 2, TH>(p, q, s));
 }
 
+// the chained form: every pass of the launch with the hand-off geometry of the widest (HC chunks of 64 words per slice)
+template <int MODE, int TH>
+hipError_t launch_sweep_chain_unit(const SweepChainArgs& c, hipStream_t s)
+{
+    if constexpr (MODE != PASS_ADD && MODE != PASS_CHANGE) return hipErrorInvalidConfiguration;
+    else {
+        int hc = 0, grid = 0;
+        size_t lds = 0;
+        for (int k = 0; k < c.n; ++k) {
+            hc = std::max(hc, sweep_halo_chunks(c.pass[k].q.hx, c.pass[k].q.hy, TH));
+            grid += c.pass[k].p.tiles_x * c.pass[k].p.tiles_y;
+            lds = std::max(lds, sweep_lds_bytes(MODE, c.pass[k].p.n_steps, FMT_U8, TH));
+        }
+        // ONE workgroup per CU (a one-stream tile takes 80 KiB: two would fit): a tile of the next pass that is resident beside a
+        // tile of this one spends the whole pass polling for it (measured: a warm reset 2.94 ms against 1.92) — it is to arrive
+        // when this pass's tile retires
+        lds = std::max<size_t>(lds, 84 * 1024);
+        auto go = [&](auto kernel) -> hipError_t {
+            static std::atomic<uint64_t> attr_done{0};
+            if (const hipError_t e = allow_big_lds(kernel, attr_done, 159 * 1024); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(sweep_threads(MODE, TH)), lds, s, c);
+            return hipGetLastError();
+        };
+        if (hc <= 2) return go(k_light_sweep_chain<MODE, 2, 2, TH>);
+        if (hc <= 3) return go(k_light_sweep_chain<MODE, 2, 3, TH>);
+        return hipErrorInvalidConfiguration; // (the host chains passes of up to three chunks)
+    }
+}
+
 #ifdef TBRM_SWEEP_UNIT_MODE
 template hipError_t launch_sweep_unit<TBRM_SWEEP_UNIT_MODE, TBRM_SWEEP_UNIT_TH>(const ChunkParams&, const SweepParams&, hipStream_t);
+template hipError_t launch_sweep_chain_unit<TBRM_SWEEP_UNIT_MODE, TBRM_SWEEP_UNIT_TH>(const SweepChainArgs&, hipStream_t);
 #else
 // (no unit named: every mode and tile height in this one translation unit — what a plain `hipcc -c` of this file builds)
 template hipError_t launch_sweep_unit<PASS_ADD, 32>(const ChunkParams&, const SweepParams&, hipStream_t);

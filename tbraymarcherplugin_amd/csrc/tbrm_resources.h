@@ -221,6 +221,9 @@ struct tbrm_resources {
     uint32_t* sweep_rec[2] = {nullptr, nullptr};
     size_t sweep_rec_words = 0;    // capacity of [0]
     size_t sweep_rec1_words = 0;   // capacity of [1] (two-way Changes only)
+    uint32_t* sweep_prog = nullptr; // chained sweeps (SweepLink): kSweepChainMax tables of per-tile progress words, sweep_prog_stride apart
+    size_t sweep_prog_stride = 0;
+    uint64_t chain_launches = 0;   // sweep launches that ran several passes (k_light_sweep_chain)
     int* sweep_ticket = nullptr;   // device: [0] next tile, [1] tiles finished (re-armed by the last tile of every launch)
     int* sweep_error = nullptr;    // pinned host memory the kernels write to: a tile gave up waiting (1) / taps outside its halo (2)
     uint32_t sweep_epoch = 0;      // tag of the last sweep launch
@@ -228,6 +231,7 @@ struct tbrm_resources {
     int sweep_failed_bits = 0;     // latched error word (sweep_failed): the light volume is undefined until it is cleared
     unsigned long long* sweep_stamps = nullptr; // diagnostics (sweep_debug & 2): the last launch's per-tile time stamps
     int sweep_stamp_tiles = 0, sweep_stamp_tx = 0, sweep_stamp_sx = 0, sweep_stamp_sy = 0;
+    int sweep_stamp_chain[4] = {0, 0, 0, 0}; // a chained launch's stamps: tiles per pass (0: not a chain)
     std::vector<FactorEntry*> kept; // the factor cache
     uint64_t kept_clock = 0;       // its LRU clock
     uint64_t op_serial = 0;        // whole-volume light operators run so far (run_passes)
@@ -385,6 +389,7 @@ bool dual_fit(const PassPlan& a, const PassPlan& b);                    // may O
 int enqueue_dual_occlusion(tbrm_resources* r, const PassPlan& a, const PassPlan& b);
 void quiesce_occ_stream(tbrm_resources* r);  // waits for the occlusion stream and forgets what its buffers hold
 void release_kept(tbrm_resources* r);       // frees the factor cache (the streams must be idle)
+void count_alloc(tbrm_resources* r, int calls, const char* what); // tbrm_path_counters [12] (sweep_debug bit 6: says what, on stderr)
 int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags); // tbrm_resources_reserve
 int ensure_reserved(tbrm_resources* r);     // the first light operator of a handle nobody reserved: reserve_resources with the defaults
 bool op_finished(tbrm_resources* r, uint64_t op); // has every sweep of operator `op` completed? (never blocks)

@@ -41,8 +41,10 @@ def test_sweep_runs_where_it_applies_and_declines_the_rest(gpu, oracle_mod):
             res.add_dir_light(S.light(i), True, world)
             orc.add_dir_light(S.light(i), True, world)
             n += abi.host_light_passes(S.light(i), world, (64, 48, 56))[1]
-        c = res.launch_counters()
-        assert c["sweep"] == n and c["chunk"] == n and c["slice"] == 0, c
+        c, pc = res.launch_counters(), res.path_counters()
+        # every pass a sweep; a light's two passes share ONE launch (k_light_sweep_chain), a light with one pass takes one of its own
+        assert pc["passes_sweep"] == n and pc["passes_chain"] == 0 and c["sweep"] == c["chunk"] and c["slice"] == 0, (c, pc)
+        assert c["sweep"] == n - pc["launches_sweep_chain"] > 0, (c, pc)
         same(res, orc, "sweeps")
     # a depth that is not whole brick layers along one axis: the sweep runs over the padded volume (round 4; the chain before)
     dims = (64, 48, 52)
@@ -507,7 +509,7 @@ def test_launch_tags_start_over_after_65535_launches(gpu, oracle_mod, tunables):
             res.add_dir_light(new, False, world)
             orc.add_dir_light(new, False, world)
             same(res, orc, f"round {k} after the removal")
-        assert res.launch_counters()["sweep"] > 40
+        assert res.path_counters()["passes_sweep"] > 40
 
 
 @pytest.mark.parametrize("dims", [(64, 48, 56), (67, 45, 53), (128, 128, 128)])
@@ -662,3 +664,43 @@ def test_block_lists_are_kept_with_the_handle(gpu, oracle_mod, tunables):
             res.change_dir_light(abi.DirLightParams(d, 0.4), abi.DirLightParams(S.rotate_z(d, -3.0), 0.4), world)
             orc.change_dir_light(abi.DirLightParams(d, 0.4), abi.DirLightParams(S.rotate_z(d, -3.0), 0.4), world)
             same(res, orc, f"cache {cache}, change under the new window")
+
+
+def test_chained_sweeps_equal_one_launch_per_pass(gpu, oracle_mod, tunables):
+    """k_light_sweep_chain (tunable sweep_chain: passes per launch): the next pass's tiles take their tickets behind this pass's and
+    wait, brick layer by brick layer, for the tile of the pass before that owns the bricks — Adds (one stream), fused Changes (two),
+    resets of four lights as one tbrm_add_dir_lights call (chains of four passes: sc1 loads from the third pass on), ragged depths,
+    planes that are not whole tiles, upward and downward passes — against the oracle, and the launches counted."""
+    world = S.default_world()
+    for dims in ((96, 72, 64), (64, 100, 52)):
+        for chain in (4, 2):
+            tunables("sweep_chain", chain)
+            res, orc = scene(oracle_mod, dims)
+            with res:
+                lights = [S.light(i) for i in (0, 1, 2, 5)]
+                for la, pa, lb, pb in res.add_dir_lights(lights, True, world):
+                    orc.add_dir_light_pass(lights[la], True, world, pa)
+                    if lb >= 0:
+                        orc.add_dir_light_pass(lights[lb], True, world, pb)
+                same(res, orc, f"{dims} chain {chain}: batched reset")
+                pc = res.path_counters()
+                assert pc["launches_sweep_chain"] >= 2 and pc["passes_chain"] == 0, pc
+                for k in range(6):
+                    li = k % 4
+                    new = abi.DirLightParams(S.rotate_z(S.LIGHTS[(0, 1, 2, 5)[li]][0], 7.0 * (k + 1)), lights[li].light_intensity)
+                    res.change_dir_light(lights[li], new, world)
+                    orc.change_dir_light(lights[li], new, world)
+                    lights[li] = new
+                    same(res, orc, f"{dims} chain {chain}: change {k}")
+                for l in lights[:2]:
+                    res.add_dir_light(l, False, world)
+                    orc.add_dir_light(l, False, world)
+                same(res, orc, f"{dims} chain {chain}: removals")
+                assert res.path_counters()["launches_sweep_chain"] > pc["launches_sweep_chain"]
+    tunables("sweep_chain", 1)
+    res, orc = scene(oracle_mod, (64, 64, 64))
+    with res:
+        res.add_dir_light(S.light(0), True, world)
+        orc.add_dir_light(S.light(0), True, world)
+        same(res, orc, "chain off")
+        assert res.path_counters()["launches_sweep_chain"] == 0
