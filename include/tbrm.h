@@ -208,11 +208,13 @@ TBRM_API int tbrm_resources_destroy(tbrm_resources* res);
  * ARaymarchVolume::InitializeRaymarchResources (RaymarchVolume.cpp:821-920), never inside AddDirLightToSingleVolume: the second
  * stream and its events, the factor scratch buffers, hand-off records (previous-slice taps up to two texels from the pixel), block
  * lists and ordering events for n_lights lights, and one arena for the factor cache's entries (4 entries per light, within the
- * light_cache_mb budget, never the last 2 GiB of the device). Afterwards an operator allocates nothing, asks the device nothing and
+ * light_cache_mb budget, at most half of what the device has free beyond 8 GiB). Afterwards an operator allocates nothing, asks the device nothing and
  * never waits for a stream (tbrm_path_counters out[12], out[13] stand still); a cache entry that does not fit the arena evicts
  * entries nothing in flight reads, or the pass goes uncached. flags bit 0: the chunked-chain fallback's stores too (passes the
- * sweep declines). Optional: a handle nobody reserved does the same with n_lights = 4 inside its first light operator. May be
- * called again with more lights (drains the streams, drops the cache). */
+ * sweep declines). Optional: a handle nobody reserved takes the arena, the events and the block lists for n_lights = 4 inside its
+ * first light operator and allocates scratch stores and hand-off records when the first pass that needs them runs (a few
+ * allocations per scene: a host that holds many handles of a large volume does not pay 8 KiB per 16 x 16 x 8 block of every one
+ * of them up front). May be called again with more lights (drains the streams, drops the cache). */
 TBRM_API int tbrm_resources_reserve(tbrm_resources* res, int32_t n_lights, uint32_t flags);
 TBRM_API int tbrm_resources_light_volume_dims(const tbrm_resources* res, int32_t out_dims[3]);
 TBRM_API int tbrm_resources_is_initialized(const tbrm_resources* res); /* bIsInitialized: volume + TF present */

@@ -20,6 +20,8 @@ int tbrm_slab_light_begin(tbrm_resources* r, const tbrm_dir_light_params* remove
     if (!r || !light || !world || !slab || !n_passes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     if (!initialized(r)) return fail(TBRM_ERR_NOT_INITIALIZED, "resources have no volume or transfer function");
     *n_passes = 0;
+    if (int e = bind(r)) return e;
+    if (int e = ensure_reserved(r)) return e; // (a handle nobody reserved: once, with the defaults — tbrm_resources_reserve)
     if (!r->slab_op) r->slab_op = new SlabOp;
     SlabOp& op = *r->slab_op;
     op.slab = *slab;

@@ -355,20 +355,29 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
 {
     if (r->resident) { r->reserved = true; return TBRM_OK; } // (slab-resident handles run the chunked chain on their own stores)
     n_lights = std::max(n_lights, 1);
-    if (r->reserved && n_lights <= r->reserved_lights && !(flags & 1u)) return TBRM_OK;
+    // flags bit 31 (internal: ensure_reserved): what EVERY handle needs to run its operators without allocating in the steady
+    // state — the arena, the event pool, the spare block lists — but not the scratch stores and hand-off records of the largest
+    // pass the volume could ever see (32 GiB at 1024^3: a host with several handles, or one that only ever runs slab passes, says
+    // so itself by calling tbrm_resources_reserve); those are then allocated by the first pass that needs them, as before round 6
+    const bool eager = !(flags & 0x80000000u);
+    flags &= 0x7fffffffu;
+    if (r->reserved && n_lights <= r->reserved_lights && !(flags & 1u) && (!eager || r->reserved_eagerly)) return TBRM_OK;
     if (int e = ensure_occ_stream(r)) return e;
     size_t slice_elems = 0;
     int tiles = 0, depth = 0;
     const size_t blocks = pass_blocks_max(r, &slice_elems, &tiles, &depth);
     // the page of ones, the scratch stores (ensure_factor_scratch drains and allocates only what is missing)
-    for (int b = 0; b < tbrm_resources::kFScratch; ++b)
-        if (int e = ensure_factor_scratch(r, b, blocks, 2)) return e;
+    if (eager)
+        for (int b = 0; b < tbrm_resources::kFScratch; ++b)
+            if (int e = ensure_factor_scratch(r, b, blocks, 2)) return e;
     // hand-off records: reach 2 x 2 for both record buffers (two-way Changes), float light volumes: 8-byte granules per stream
-    {
+    if (eager) {
         const size_t gw = r->lv_fmt != FMT_U8 ? 4 : 1;
-        const size_t words = (size_t) depth * (size_t) tiles * (size_t) sweep_record_words(2, 2, sweep_tile_rows()) * gw;
+        // (reach 4 where that is small — a volume of up to 256^3 —, else 2)
+        const int reach = (size_t) depth * (size_t) tiles * (size_t) sweep_record_words(4, 4, sweep_tile_rows()) * gw * 4 <= ((size_t) 64 << 20) ? 4 : 2;
+        const size_t words = (size_t) depth * (size_t) tiles * (size_t) sweep_record_words(reach, reach, sweep_tile_rows()) * gw;
         // (chained passes have a region of the first buffer each: kSweepChainMax passes of reach 1, or two of reach 2)
-        const size_t first = std::max(words, (size_t) kSweepChainMax * (((size_t) depth * (size_t) tiles * (size_t) sweep_record_words(2, 2, sweep_tile_rows()) + 63) & ~(size_t) 63));
+        const size_t first = std::max(words, (size_t) kSweepChainMax * (((size_t) depth * (size_t) tiles * (size_t) sweep_record_words(reach, reach, sweep_tile_rows()) + 63) & ~(size_t) 63));
         if (first < ((size_t) 1 << 32))
             if (int e = ensure_sweep(r, std::max<size_t>(first, 1), words, (size_t) tiles)) return e;
     }
@@ -394,8 +403,13 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
         const size_t entry = (blocks * 2048 * sizeof(float) <= ((size_t) 256 << 20) ? blocks : blocks / 2) * 2048 * sizeof(float);
         size_t want = std::min(kept_budget(r), DeviceArena::rounded(entry) * (size_t) (4 * n_lights));
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::min(want, free_b > ((size_t) 2 << 30) ? (free_b - ((size_t) 2 << 30)) / 2 : 0); // (never the last of the device's memory)
-        else (void) hipGetLastError();
+        // never the last of the device's memory — whoever else allocates on it (a renderer, torch, other handles, the runtime's own
+        // scratch for kernels in flight: a queue that cannot get it aborts the process) must not find it gone: half of what is free
+        // beyond 8 GiB for a host that reserves, an eighth for a handle that was never reserved (there may be many of them)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t spare = free_b > ((size_t) 8 << 30) ? free_b - ((size_t) 8 << 30) : 0;
+            want = std::min(want, eager ? spare / 2 : spare / 8);
+        } else (void) hipGetLastError();
         if (want > r->cache_arena.bytes && want >= DeviceArena::rounded(entry)) {
             drain_streams(r);
             release_kept(r); // (entries of a smaller arena, or allocated one by one before the handle was reserved)
@@ -413,6 +427,7 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
                 if (int e = ensure_store(r, &r->occ_tmp[b][si], 128, slice_elems, si == 0 ? flag_bytes : 0)) return e;
     }
     r->reserved = true;
+    r->reserved_eagerly = r->reserved_eagerly || eager;
     r->reserved_lights = std::max(r->reserved_lights, n_lights);
     return TBRM_OK;
 }
@@ -420,7 +435,7 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
 int ensure_reserved(tbrm_resources* r)
 {
     if (r->reserved) return TBRM_OK;
-    return reserve_resources(r, 4, 0); // (a host that never said how many lights it has: the reference scenes' four)
+    return reserve_resources(r, 4, 0x80000000u); // (a host that never said how many lights it has: the reference scenes' four)
 }
 
 void use_kept(tbrm_resources* r, FactorEntry* e, bool leaves_the_scene)

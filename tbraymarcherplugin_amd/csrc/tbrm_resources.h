@@ -258,6 +258,7 @@ struct tbrm_resources {
     uint64_t lists_launches = 0;   // passes / dual launches whose lists had to be computed (tbrm_path_counters)
     // tbrm_resources_reserve: everything the light operators would otherwise allocate as they go
     bool reserved = false;
+    bool reserved_eagerly = false; // (by tbrm_resources_reserve: scratch stores and hand-off records too)
     int reserved_lights = 0;
     DeviceArena cache_arena;       // the factor cache's entries
     void* cache_arena_alloc = nullptr;

