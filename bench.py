@@ -640,8 +640,21 @@ def main():
                 best = t if best is None else min(best, t)
             return best
 
+        # the same reset as ONE tbrm_add_dir_lights call (the facade's bBatchLightsOnReset): every light's passes are
+        # planned together — passes of different lights that leave the same cube face and pull the same way share a sweep (PASS_ADD2),
+        # the others run in the lights' order in chained launches of up to four passes
+        batch_info = {}
+
+        def reset_all_lights_batched():
+            res.clear_light_volume(0.0)
+            sched = res.add_dir_lights(lights, True, world)
+            batch_info["sweeps"] = len(sched)
+            batch_info["paired_sweeps"] = sum(1 for e in sched if e[2] >= 0)
+
         cache_default = abi.get_tunable("light_cache_mb")
         ops_ms["reset_all_lights_warm"] = timed(reset_all_lights)
+        ops_ms["reset_all_lights_batched_warm"] = timed(reset_all_lights_batched)
+        ops_ms["reset_all_lights_batched_cold"] = timed(reset_all_lights_batched, before=stale_window)
         ops_ms["reset_all_lights_plus_frame_warm"] = timed(lambda: (reset_all_lights(), res.raymarch_lit_device(cam, full_tile, rp, world, full.data_ptr())), reps=1)
         ops_ms["reset_all_lights_cold"] = timed(reset_all_lights, before=stale_window)
         # one step of APerformanceTest1's window sweep: new window centre, every light again, the frame
@@ -827,6 +840,10 @@ def main():
             "light_paths_per_step": light_paths,  # tbrm_path_counters over the timed loop: sweep / chain / slice passes and launches, occlusion launches
             "raymarch_only_msamples_per_s": round(total_samples / (ray_ms * 1e-3) / 1e6, 2),
             "light_cache": res.light_cache_stats(),  # factor cache (include/tbrm.h tbrm_light_cache_stats)
+            # gpu_ms.reset_all_lights_batched_*: what tbrm_add_dir_lights made of this scene's lights
+            "reset_batching": None if not ops_ms else dict(batch_info, note=(
+                "no two passes of different lights share a sweep: every same-face couple of this scene's lights pulls opposite ways along a plane axis "
+                "(no tile order serves both); the lights' passes run in order, chained" if batch_info.get("paired_sweeps") == 0 else "PASS_ADD2 pairs")),
             # N > 1: this line's step against the SAME workload on one GPU in the same run (whole step; the frame alone)
             "speedup_vs_one_gpu": None if scaling_note is None else scaling_note["speedup_vs_one_gpu"],
             # the frame alone, WALL CLOCK WITH THE GATHER INSIDE (frame_delivery: the form of the timed step's --gather)

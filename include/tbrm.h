@@ -185,7 +185,9 @@ TBRM_API int tbrm_device_count(int* out_count);   /* TBRM_ERR_NO_DEVICE when the
  * wait for each other, bits 3 / 4 skip buffer hazards — WRONG light volumes —; bit 1 prints per-tile time stamps at tbrm_flush,
  * bit 2 the host's time per operator phase, bit 5 leaves out the events behind tbrm_last_gpu_time_ms), occ_dual (1 = the two
  * axis passes of a light share one occlusion launch — their sampling positions are the same, LightingShaders.cpp:114-124 —,
- * 0 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
+ * 0 = one launch per pass), sweep_chain (4 = up to four consecutive sweep passes of an operator share ONE launch —
+ * k_light_sweep_chain: the next pass's tiles take their tickets behind this pass's and start as its tiles retire, ordered brick
+ * layer by brick layer through progress words; 1 = one launch per pass), sweep_timeout_ms (0 = a sweep tile waits 2 s of wall time for a neighbour's hand-off word before it
  * gives up and the handle reports the light volume undefined; < 0 = not at all: a test hook), sweep_epoch_preset (0; > 0: a
  * handle's first sweep launch continues from this 16-bit launch tag: a test hook for the tags' wrap-around), fast_window_div (1 = where the host can vouch for the window — finite, moderate centre / width, UNORM data — the kernels
  * compute the transfer-function position with three fmas instead of the IEEE division: the same bits, tbrm_selftest_window_division; 0 = always

@@ -368,8 +368,8 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
     const size_t blocks = pass_blocks_max(r, &slice_elems, &tiles, &depth);
     // the page of ones, the scratch stores (ensure_factor_scratch drains and allocates only what is missing)
     if (eager)
-        for (int b = 0; b < tbrm_resources::kFScratch; ++b)
-            if (int e = ensure_factor_scratch(r, b, blocks, 2)) return e;
+        for (int b = 0; b < tbrm_resources::kFScratch; ++b) // (both streams for four of them: an uncached Change computes two streams per pass)
+            if (int e = ensure_factor_scratch(r, b, blocks, b < 4 ? 2 : 1)) return e;
     // hand-off records: reach 2 x 2 for both record buffers (two-way Changes), float light volumes: 8-byte granules per stream
     if (eager) {
         const size_t gw = r->lv_fmt != FMT_U8 ? 4 : 1;

@@ -166,7 +166,6 @@ struct DualOcc {
     int on;
     DualPass pass[2];
 };
-
 // k_light_sweep (tbrm_light_sweep.hip): one launch advances every 32x32 tile of the slice plane through a whole span of
 // slices. The previous-slice taps of a pass lie on ONE side of the pixel per plane axis (the constant PrevPixelOffset,
 // AddDirLightShader.usf:81-82), so a tile depends on at most three neighbours — the ones towards the light — and the tiles

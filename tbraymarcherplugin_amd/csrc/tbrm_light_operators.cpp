@@ -133,6 +133,12 @@ static int run_passes(tbrm_resources* r, const PropParams& base, std::vector<Pas
         if (chain_max >= 2 && chainable(i)) {
             size_t len = 1;
             while ((int) len < chain_max && chainable(i + len) && plans[i + len].mode == plans[i].mode) {
+                // A launch waits for the occlusion of ALL its passes: a pass whose factors are still to be computed joins only the
+                // pass it shares its occlusion launch with (the two passes of a light, dual_fit) — the occlusion of the light after
+                // runs beside this launch instead of in front of it (measured, cold reset of four lights: 3.18 ms light by light,
+                // 3.25 with two lights' occlusion in front of one launch of four passes)
+                const PassPlan& nx = plans[i + len];
+                if (nx.occ_mode >= 0 && !nx.occ_enqueued && !dual_fit(plans[i + len - 1], nx)) break;
                 bool fresh_buffer = true; // (every pass of a launch reads its own scratch buffer)
                 for (size_t k = 0; k < len; ++k) fresh_buffer = fresh_buffer && plans[i + k].f_buf != plans[i + len].f_buf;
                 if (!fresh_buffer) break;
@@ -234,6 +240,39 @@ int enqueue_add_batch(tbrm_resources* r, const tbrm_dir_light_params* lights, in
         };
         std::vector<std::vector<size_t>> of_light((size_t) n_lights);
         for (size_t k = 0; k < all.size(); ++k) of_light[(size_t) all[k].light].push_back(k);
+        // Nothing pairs (every same-face couple pulls opposite ways along a plane axis — config 3's four lights —, or none shares a
+        // face): the lights four at a time, in the caller's order — exactly light after light, voxel by voxel —, their sweeps chained
+        // (k_light_sweep_chain: up to four passes per launch where the factors are at hand). Eight scratch buffers hold a group's
+        // passes. (One occlusion launch for all four lights was built and measured: 0.46 ms per light against 0.28 for the dual
+        // launch — 4 x 4 x 3 staged bricks per unit instead of 3 x 3 x 2 cost two of five workgroups per CU;
+        // tools/diagnostics/multi_light_occlusion.patch, profiles/EXPERIMENTS.md.)
+        bool any_pair_fits = false;
+        for (size_t x = 0; x < all.size() && !any_pair_fits; ++x)
+            for (size_t y = x + 1; y < all.size() && !any_pair_fits; ++y) any_pair_fits = all[x].light != all[y].light && pair_fits(all[x].p, all[y].p);
+        if (!any_pair_fits) {
+            int entries = 0;
+            constexpr int kGroup = tbrm_resources::kFScratch / 2; // lights per run_passes: two passes each, a scratch buffer per pass
+            for (int l0 = 0; l0 < n_lights; l0 += kGroup) {
+                std::vector<PassSpec> specs;
+                for (int li = l0; li < std::min(l0 + kGroup, n_lights); ++li)
+                    for (size_t k : of_light[(size_t) li]) {
+                        PassSpec q;
+                        q.a = all[k].p;
+                        q.b_added = b;
+                        specs.push_back(q);
+                        if (schedule) {
+                            schedule[4 * entries + 0] = all[k].light; schedule[4 * entries + 1] = all[k].pass;
+                            schedule[4 * entries + 2] = -1; schedule[4 * entries + 3] = -1;
+                        }
+                        ++entries;
+                    }
+                if (n_entries) *n_entries = entries;
+                if (specs.empty()) continue;
+                if (int e = run_passes(r, base, specs)) return e;
+            }
+            if (n_entries) *n_entries = entries;
+            return TBRM_OK;
+        }
         std::vector<char> light_done((size_t) n_lights, 0);
         int entries = 0;
         for (int la = 0; la < n_lights; ++la) {

@@ -246,9 +246,9 @@ struct tbrm_resources {
     size_t f_est_blocks = 0;       // live blocks per pass seen under f_est_key (what a new entry is sized for)
     uint64_t f_est_key[2] = {0, 0};
     float f_est_win[4] = {0, 0, 0, 0};
-    // Four, taken in rotation: a light's two passes are filled by ONE occlusion launch (DualOcc) while the sweeps of the operator
+    // Taken in rotation: a light's two passes are filled by ONE occlusion launch (DualOcc) while the sweeps of the operator
     // before may still be reading the two before them
-    static constexpr int kFScratch = 4;
+    static constexpr int kFScratch = 8; // (round 6: eight — tbrm_add_dir_lights plans the passes of four lights together, each pass its own buffer)
     FactorScratch f_scratch[kFScratch];
     int f_buf = 0;                 // buffer of the most recent sweep pass
     std::vector<BlockLists*> block_lists; // passes' and dual launches' block lists computed so far (tbrm_block_lists.cpp)
