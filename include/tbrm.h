@@ -476,6 +476,13 @@ TBRM_API int tbrm_selftest_unorm8_roundtrip(int device, const float* in, size_t 
 TBRM_API int tbrm_host_light_passes(const tbrm_dir_light_params* light, const tbrm_world_params* world,
                                     const int32_t light_volume_dims[3], int border_mode,
                                     tbrm_light_pass out[2], int* n_passes);
+/* The planner alone (no device): which kernel each axis pass of AddDirLightToSingleVolume(light) takes for a light volume of these
+ * dimensions. Per pass k: out[4k] = 0 the pipelined sweep, 1 the chunked chain, 2 one slice per launch (-1: no such pass);
+ * out[4k+1], out[4k+2] = the sweep's reach in texels along the plane's x / y (chain: the chunk length in out[4k+1]); out[4k+3] = why
+ * the sweep declined: 1 previous-slice taps on both sides of the pixel, 2 a reach beyond 14 texels, 3 more hand-off words than the
+ * hand-off wave carries, 4 a short ragged downward pass, 5 sweeps off, 6 more than 1024 slices. */
+TBRM_API int tbrm_host_plan_light(const tbrm_dir_light_params* light, const tbrm_world_params* world, const int32_t light_volume_dims[3],
+                                  int light_volume_32bit, int32_t out[8], int* n_passes);
 /* GetLocalClippingParameters (LightingShaderUtils.cpp:205-220), narrowed to float[3] + float[3].        */
 TBRM_API int tbrm_host_local_clipping(const tbrm_world_params* world, float out_center[3], float out_dir[3]);
 /* Data-volume border colour of the propagation sampler (LightingShaders.h:82-85).                      */

@@ -126,7 +126,7 @@ SYMBOLS = [
     "tbrm_count_nominal_samples",
     "tbrm_download_light_volume", "tbrm_upload_light_volume", "tbrm_light_volume_device_ptr",
     "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_selftest_window_division", "tbrm_selftest_opacity_correction", "tbrm_launch_counters", "tbrm_sweep_launches", "tbrm_path_counters", "tbrm_light_cache_stats", "tbrm_light_cache_clear", "tbrm_flush", "tbrm_stream", "tbrm_last_gpu_time_ms",
-    "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
+    "tbrm_host_light_passes", "tbrm_host_plan_light", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local",
 ]
 
 ABI_VERSION = 5  # TBRM_ABI_VERSION of include/tbrm.h (tests/test_abi.py compares the two)
@@ -215,6 +215,7 @@ def load():
     lib.tbrm_stream.argtypes = [vp, P(vp)]
     lib.tbrm_last_gpu_time_ms.argtypes = [vp, C.c_int, P(C.c_float)]
     lib.tbrm_host_light_passes.argtypes = [P(DirLightParams), P(WorldParams), P(C.c_int32 * 3), C.c_int, P(LightPass * 2), P(C.c_int)]
+    lib.tbrm_host_plan_light.argtypes = [P(DirLightParams), P(WorldParams), P(C.c_int32 * 3), C.c_int, P(C.c_int32 * 8), P(C.c_int)]
     lib.tbrm_host_local_clipping.argtypes = [P(WorldParams), P(C.c_float * 3), P(C.c_float * 3)]
     lib.tbrm_host_world_to_local.argtypes = [P(Transform), P(C.c_float * 12)]
     _lib = lib
@@ -256,6 +257,15 @@ def host_light_passes(light, world, lv_dims, border_mode=BORDER_ENGINE_8BIT):
     dims = (C.c_int32 * 3)(*lv_dims)
     check(load().tbrm_host_light_passes(C.byref(light), C.byref(world), C.byref(dims), border_mode, C.byref(out), C.byref(n)))
     return [out[0], out[1]], n.value
+
+
+def host_plan_light(light, world, lv_dims, light_32bit=False):
+    """The planner alone (no device): per axis pass of AddDirLight(light) (path, a, b, why) — path 0 sweep / 1 chain / 2 slice."""
+    out = (C.c_int32 * 8)()
+    n = C.c_int(0)
+    dims = (C.c_int32 * 3)(*lv_dims)
+    check(load().tbrm_host_plan_light(C.byref(light), C.byref(world), C.byref(dims), int(bool(light_32bit)), C.byref(out), C.byref(n)))
+    return [tuple(out[4 * k:4 * k + 4]) for k in range(n.value)]
 
 
 def host_local_clipping(world):

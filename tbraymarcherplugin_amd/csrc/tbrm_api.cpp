@@ -10,6 +10,7 @@
 // structs are copied at call time (the reference captures them by value, RaymarchUtils.cpp:63-66).
 // There is no CPU path: without a HIP device every data call fails with TBRM_ERR_NO_DEVICE.
 #include "tbrm_resources.h"
+#include "tbrm_light_sweep.h"
 
 #include <algorithm>
 #include <atomic>
@@ -814,6 +815,33 @@ int tbrm_host_light_passes(const tbrm_dir_light_params* light, const tbrm_world_
 {
     if (!light || !world || !lv_dims || !out || !n_passes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
     host_light_passes(*light, *world, lv_dims, border_mode, out, n_passes);
+    return TBRM_OK;
+}
+
+// Which kernel each axis pass of AddDirLight(light) would take for a light volume of these dimensions — the planner alone, no device
+// (tools/planner_anisotropic.py: how often do real CT shapes fall off the sweep, and why?)
+int tbrm_host_plan_light(const tbrm_dir_light_params* light, const tbrm_world_params* world, const int32_t lv_dims[3], int light_volume_32bit,
+                         int32_t out[8], int* n_passes)
+{
+    if (!light || !world || !lv_dims || !out || !n_passes) return fail(TBRM_ERR_INVALID_ARG, "null argument");
+    tbrm_resources fake{}; // (the planner reads the dimensions, the format and the CU count of a handle: no device behind this one)
+    for (int c = 0; c < 3; ++c) fake.lv_dims[c] = lv_dims[c];
+    fake.lv_fmt = light_volume_32bit ? FMT_F32 : FMT_U8;
+    fake.desc.border_mode = TBRM_BORDER_ENGINE_8BIT;
+    tbrm_light_pass passes[2];
+    int n = 0;
+    host_light_passes(*light, *world, lv_dims, TBRM_BORDER_ENGINE_8BIT, passes, &n);
+    *n_passes = n;
+    for (int k = 0; k < 2; ++k) {
+        int32_t* o = out + 4 * k;
+        o[0] = -1; o[1] = o[2] = o[3] = 0;
+        if (k >= n) continue;
+        SweepFit sf;
+        ChunkFit cf;
+        if (sweep_fit(&fake, passes[k], nullptr, PASS_ADD, sf) && ceil_div(passes[k].td[2], 8) * 8 <= sweep_max_slices()) { o[0] = 0; o[1] = sf.hx; o[2] = sf.hy; }
+        else if (chunk_fit(&fake, passes[k], nullptr, cf)) { o[0] = 1; o[1] = cf.M; o[3] = ceil_div(passes[k].td[2], 8) * 8 > sweep_max_slices() ? 6 : sweep_decline_reason(&fake, passes[k]); }
+        else { o[0] = 2; o[3] = ceil_div(passes[k].td[2], 8) * 8 > sweep_max_slices() ? 6 : sweep_decline_reason(&fake, passes[k]); }
+    }
     return TBRM_OK;
 }
 

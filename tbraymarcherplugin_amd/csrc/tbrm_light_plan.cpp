@@ -106,6 +106,21 @@ bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_li
     return room[0] <= 14 && room[1] <= 14 && sweep_halo_chunks(fit.hx, fit.hy, th) <= (f32 ? 3 : 6) && sweep_halo_chunks(fit.r_hx, fit.r_hy, th) <= (f32 ? 3 : 6);
 }
 
+// Why sweep_fit declines a one-stream pass (tbrm_host_plan_light; diagnostics): 0 it does not, 1 previous-slice taps on both sides of
+// the pixel along a plane axis or an offset out of range, 2 taps more than 14 texels from the pixel, 3 more hand-off words per slice
+// than a lane of the hand-off wave carries, 4 a downward pass over a ragged depth of fewer than nine slices, 5 sweeps are off for
+// the handle (tunable, slab-resident, a failed sweep)
+int sweep_decline_reason(const tbrm_resources* r, const tbrm_light_pass& pa)
+{
+    if (tune(TUNE_LIGHT_SWEEP) == 0 || force_slice_kernel() || r->resident || r->sweep_failed_bits) return 5;
+    if (pa.td[2] % 8 != 0 && pa.dir < 0 && pa.td[2] < 9) return 4;
+    const TapSide tx = prev_tap_side(pa.td[0], pa.prev_pixel_offset[0]), ty = prev_tap_side(pa.td[1], pa.prev_pixel_offset[1]);
+    if (!tx.ok || !ty.ok) return 1;
+    if (tx.reach > 14 || ty.reach > 14) return 2;
+    if (sweep_halo_chunks(tx.reach, ty.reach, sweep_tile_rows()) > (r->lv_fmt != FMT_U8 ? 3 : 6)) return 3;
+    return 0;
+}
+
 void release_sweep(tbrm_resources* r)
 {
     for (auto& rec : r->sweep_rec) { (void) hipFree(rec); rec = nullptr; }

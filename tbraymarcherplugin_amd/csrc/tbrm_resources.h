@@ -377,6 +377,7 @@ int plan_pass(tbrm_resources* r, const PropParams& base, const tbrm_light_pass& 
 // on their own (r_*), and the fused sweep runs in the added light's order (SweepParams::r_from_records)
 struct SweepFit { int sx = 0, sy = 0, hx = 0, hy = 0; bool two_way = false; int r_sx = 0, r_sy = 0, r_hx = 0, r_hy = 0; };
 bool sweep_fit(const tbrm_resources* r, const tbrm_light_pass& pa, const tbrm_light_pass* pr, int mode, SweepFit& fit);
+int sweep_decline_reason(const tbrm_resources* r, const tbrm_light_pass& pa);
 void release_sweep(tbrm_resources* r);
 int sweep_check(tbrm_resources* r);  // after the stream has drained: did a sweep kernel raise its error word? (+ the stamps' print-out)
 int sweep_failed(tbrm_resources* r); // latches the error word; TBRM_OK or the (sticky) error

@@ -113,7 +113,7 @@ def test_every_handle_taking_entry_point_rejects_a_null_handle():
                             "tbrm_raymarch_intensity_device", "tbrm_raymarch_octree_device", "tbrm_download_octree_mip"}
     free = {"tbrm_abi_version", "tbrm_version", "tbrm_last_error", "tbrm_device_count", "tbrm_set_tunable", "tbrm_get_tunable", "tbrm_resources_create", "tbrm_resources_create_slab", "tbrm_color_curve_to_lut",
             "tbrm_make_default_tf_lut", "tbrm_host_bake_tf_lut", "tbrm_selftest_unorm_decode", "tbrm_selftest_unorm8_roundtrip", "tbrm_selftest_window_division", "tbrm_selftest_opacity_correction",
-            "tbrm_host_light_passes", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local"}
+            "tbrm_host_light_passes", "tbrm_host_plan_light", "tbrm_host_local_clipping", "tbrm_host_data_border", "tbrm_host_world_to_local"}
     assert set(abi.SYMBOLS) == covered | free, set(abi.SYMBOLS) ^ (covered | free)
 
 

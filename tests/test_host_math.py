@@ -156,3 +156,16 @@ def test_split_reciprocal_decode_is_exact():
         for c in range(d + 1):
             t = rn(c * r2)
             assert rn(c * r + t) == rn(Fraction(c, d)), (d, c)
+
+
+def test_planner_alone_says_which_kernel_a_pass_takes():
+    """tbrm_host_plan_light (no device): the passes of config 3's lights at 512^3 all take the pipelined sweep; a light that grazes a
+    thin volume's large face reaches too far for it (the reason is reported)"""
+    world = S.default_world()
+    for i in range(4):
+        plan = abi.host_plan_light(S.light(i), world, (512, 512, 512))
+        assert len(plan) == 2 and all(p[0] == 0 and 1 <= max(p[1], p[2]) <= 14 and p[3] == 0 for p in plan), plan
+    plan = abi.host_plan_light(abi.DirLightParams((1.0, 0.3, 0.9), 1.0), world, (512, 512, 64))
+    assert plan[0][0] == 0, plan                      # the major axis sweeps (its taps lie within a texel or two)
+    assert plan[1][0] in (1, 2) and plan[1][3] in (2, 3), plan  # the second axis: reach beyond 14 texels / too many hand-off words
+    assert abi.host_plan_light(abi.DirLightParams((0.0, 0.0, 0.0), 1.0), world, (64, 64, 64)) == []  # zero direction: no pass

@@ -31,6 +31,10 @@ python bench.py --raymarch-only --no-cpu-baseline > "$OUT/bench_n1_raymarch_only
  echo "== tools/sweep_stamps.py (timeline of one sweep launch)"; python tools/sweep_stamps.py 2>&1 | grep -v amdgpu.ids | tee /tmp/stamps32.txt
  echo "== tools/stamps_summary.py of the above (32 x 32 tiles)"; python tools/stamps_summary.py < /tmp/stamps32.txt
  echo "== tools/host_enqueue_time.py"; python tools/host_enqueue_time.py 2>&1 | grep -v amdgpu.ids) >> "$OUT/operators.txt"
+(echo "== tools/chain_ab.py: chained sweeps (sweep_chain = 4) against one launch per pass, 512^3"; python tools/chain_ab.py 2>&1 | grep -v amdgpu.ids
+ for n in 256 128; do echo "== the same at $n^3"; N=$n python tools/chain_ab.py 2>&1 | grep -v amdgpu.ids; done
+ echo "== tools/chain_stamps.py: timeline of chained launches, 512^3"; python tools/chain_stamps.py 2>&1 | grep "chain stamps\|^--"
+ echo "== the same at 256^3"; N=256 python tools/chain_stamps.py 2>&1 | grep "chain stamps\|^--") > "$OUT/sweep_chain.txt"
 for c in 1 2 4 5; do python bench.py --config $c --no-cpu-baseline --timed-only 2> /dev/null | tail -1 > "$OUT/bench_n1_config$c.json"; done
 TBRM_BENCH_ONE_GPU_DRY_RUN=1 python bench.py --gpus 2 --steps 5 --warmup 2 2> /dev/null | tail -1 > "$OUT/bench_dry_run_2_ranks_on_one_gpu.json"
 # the parity suite last (a slow box must not cost the measurements above their place in the call's time limit)
