@@ -20,7 +20,7 @@ namespace tbrm_host {
 using namespace tbrm;
 
 static constexpr int kBlock = 16, kDepth = 8; // kOccTile, kOccDepth (tbrm_light_kernels.hip)
-static constexpr size_t kMaxLists = 96;       // per handle; beyond: the least recently used ones nobody refers to go
+static constexpr size_t kMaxLists = 384;      // per handle (a reserved handle of eight lights starts with 240 spare ones); beyond: the least recently used ones nobody refers to go
 
 // texel_split (tbrm_device_math.h): the index of the lower tap
 static int base_tap(float u, float n)

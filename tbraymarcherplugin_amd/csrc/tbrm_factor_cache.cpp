@@ -382,7 +382,7 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
             if (int e = ensure_sweep(r, std::max<size_t>(first, 1), words, (size_t) tiles)) return e;
     }
     // ordering events and block lists for n_lights lights' passes
-    const size_t want_events = (size_t) 8 * n_lights + 16;
+    const size_t want_events = (size_t) 16 * n_lights + 32;
     while (r->event_pool.size() < want_events) {
         hipEvent_t ev = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&ev, event_flags()));
@@ -392,9 +392,9 @@ int reserve_resources(tbrm_resources* r, int n_lights, unsigned flags)
         size_t have_ranked = 0, have_plain = 0;
         for (const BlockLists* l : r->spare_lists) (l->slot ? have_ranked : have_plain) += 1;
         const size_t units = (size_t) ceil_div(r->lv_dims[0], 16) * ceil_div(r->lv_dims[1], 16) * (size_t) ceil_div(r->lv_dims[2], 8);
-        for (size_t k = have_ranked; k < (size_t) 12 * n_lights + 16; ++k)
+        for (size_t k = have_ranked; k < (size_t) 16 * n_lights + 32; ++k)
             if (!make_spare_lists(r, blocks, true)) return TBRM_ERR_OUT_OF_MEMORY;
-        for (size_t k = have_plain; k < (size_t) 6 * n_lights + 8; ++k)
+        for (size_t k = have_plain; k < (size_t) 8 * n_lights + 16; ++k)
             if (!make_spare_lists(r, std::max(units, blocks), false)) return TBRM_ERR_OUT_OF_MEMORY;
     }
     // the factor cache's arena: per light two passes, twice (a light that moves fills new entries while the old ones are still read),

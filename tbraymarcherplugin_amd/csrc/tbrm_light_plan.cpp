@@ -559,6 +559,9 @@ static int plan_pass_sweep(tbrm_resources* r, const PropParams& base, const tbrm
         }
     };
     plan.f_buf = (r->f_buf + 1) % tbrm_resources::kFScratch;
+    // (a pass that computes BOTH streams' occlusion — an uncached fused Change — keeps to the first four buffers: the ones a reserved
+    // handle holds a second stream's store for; consecutive passes still get different buffers)
+    if (change && !have_a && !have_r) plan.f_buf %= 4;
     plan.occ_mode = -1;
     if (have_a) { plan.f_entry[0] = have_a; plan.f_hit[0] = true; use_kept(r, have_a, !change && b_added < 0.0f); ++r->kept_hits; }
     if (have_r) { plan.f_entry[1] = have_r; plan.f_hit[1] = true; use_kept(r, have_r, true); ++r->kept_hits; }

@@ -15,8 +15,8 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from tbraymarcherplugin_amd import abi, synthetic as S
-NAMES = ["positions, clip test, texel split", "offset tables (LDS)", "leap-distance byte (gather) + range arithmetic", "16 taps issued and landed",
-         "decode, 2 trilinear filters, window, TF, opacity correction", "exchange (LDS) + in-order accumulation", "empty trips taken in one go / epilogue", "loop control"]
+NAMES = ["positions (every addition of the ray), clip test", "texel split, offset tables (LDS), leap-distance byte landed, range arithmetic", "tap offsets, 16 taps issued and landed",
+         "decode, 2 trilinear filters, window, TF, opacity correction", "exchange (LDS) + in-order accumulation", "empty trips taken in one go, range renewal", "loop control + what the trip before left in flight"]
 for config in (3, 5):
     cfg = S.CONFIGS[config]
     n = cfg["n"]
@@ -43,7 +43,7 @@ for config in (3, 5):
     ms = res.last_gpu_time_ms(1)
     lib.tbrm_debug_ray_probe(st, 0)
     v = [int(x) for x in st]
-    total = sum(v[:8])
+    total = sum(v[:7])
     waves, trips, sampling, accumulating = v[11], v[8], v[9], v[10]
     print(f"config {config}: frame {ms:.3f} ms with the probe ({waves} waves, {trips} wave trips: {sampling / max(trips, 1):.3f} sample, {accumulating / max(trips, 1):.3f} accumulate); "
           f"cycles per wave {total / max(waves, 1):.0f}, per sampling trip {total / max(sampling, 1):.0f} (s_memtime ticks, as lane 0 of each wave saw them)")
